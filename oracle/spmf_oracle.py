@@ -1,0 +1,358 @@
+"""CPU oracle for the spmf variational-inference hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  Nothing under ``spmf_amd/`` imports anything from ``oracle/``.
+
+PARITY UNPINNED.  The reference (mederrata/spmf @ 2024-12-18) cannot be run in
+this image (``import mederrata_spmf`` raises ``ModuleNotFoundError: No module
+named 'tensorflow'`` at mederrata_spmf/poisson.py:11) and its own tests assert
+no values (tests/spmf_test.py:13-44).  The third-party arithmetic it relies on
+lives in un-vendored, un-pinned dependencies: ``tensorflow``,
+``tensorflow_probability`` (tfd.Poisson / HalfNormal / InverseGamma /
+JointDistributionNamed) and ``bayesianquilts`` (SqrtInverseGamma, setup.py:37,
+no commit pinned).  Their published densities are restated here and are pinned
+by (1) scipy.stats cross-checks, (2) the HalfCauchy marginal identity,
+(3) finite differences against torch fp64 autograd, (4) tiny hand-computed
+known-answer cases -- see tests/test_oracle.py.
+
+What is restated (dense, float64, line by line; S = leading sample axis):
+
+  encoder_function / decoder_function   mederrata_spmf/poisson.py:34-54
+  compute_scales                        mederrata_spmf/poisson.py:113-154
+  log_likelihood_components             mederrata_spmf/poisson.py:156-184
+  prior (horseshoe-plus)                mederrata_spmf/poisson.py:212-401
+  unormalized_log_prob(_parts)          mederrata_spmf/poisson.py:575-621
+  encode / encoding_matrix /
+  decoding_matrix / intercept_matrix    mederrata_spmf/poisson.py:623-701
+
+Gradients come from torch.autograd in float64 over this restatement.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+F64 = torch.float64
+HALF_LOG_2_OVER_PI = 0.5 * math.log(2.0 / math.pi)
+LGAMMA_HALF = math.lgamma(0.5)
+
+#: Order of the variables as the reference's surrogate_dict lists them
+#: (poisson.py:403-539 -> var_list at :572).  Also the checkpoint order.
+VAR_ORDER = ("v", "w", "u", "u_eta", "u_tau", "s_eta", "s_tau", "s",
+             "u_eta_a", "u_tau_a", "s_eta_a", "s_tau_a")
+
+
+def var_shapes(D: int, K: int) -> Dict[str, tuple]:
+    """Event shapes of the 12 latent variables (poisson.py:228-377)."""
+    return {
+        "v": (K, D), "w": (1, D), "u": (D, K),
+        "u_eta": (D, K), "u_tau": (1, K),
+        "s_eta": (2, D), "s_tau": (1, D), "s": (2, D),
+        "u_eta_a": (D, K), "u_tau_a": (1, K),
+        "s_eta_a": (2, D), "s_tau_a": (1, D),
+    }
+
+
+@dataclass
+class OracleConfig:
+    """Constructor state of PoissonFactorization (poisson.py:56-111)."""
+    latent_dim: int
+    feature_dim: int
+    u_tau_scale: float = 0.01
+    s_tau_scale: float = 1.0
+    symmetry_breaking_decay: float = 0.99
+    scale_columns: bool = True
+    scale_rows: bool = True
+    log_transform: bool = False
+    eta_i: object = 1.0          # poisson.py:88-91  ([1,D] tensor or scalar 1.)
+    xi_u_global: object = 1.0    # poisson.py:89
+    extra: dict = field(default_factory=dict)
+
+
+def _t(x):
+    if isinstance(x, torch.Tensor):
+        return x.to(F64)
+    return torch.as_tensor(np.asarray(x, dtype=np.float64), dtype=F64)
+
+
+# --------------------------------------------------------------------------
+# densities (tensorflow_probability / bayesianquilts restated)
+# --------------------------------------------------------------------------
+def halfnormal_log_prob(y, scale):
+    """tfd.HalfNormal(scale).log_prob(y) for y >= 0."""
+    return HALF_LOG_2_OVER_PI - torch.log(scale) - 0.5 * (y / scale) ** 2
+
+
+def inverse_gamma_log_prob(x, concentration, scale):
+    """tfd.InverseGamma(concentration, scale).log_prob(x)."""
+    a, b = concentration, scale
+    return a * torch.log(b) - torch.lgamma(a) - (a + 1.0) * torch.log(x) - b / x
+
+
+def sqrt_inverse_gamma_log_prob(y, concentration, scale):
+    """bayesianquilts SqrtInverseGamma: law of sqrt(X), X ~ InverseGamma.
+    p(y) = InvGamma(y^2; a, b) * 2y."""
+    return (inverse_gamma_log_prob(y * y, concentration, scale)
+            + math.log(2.0) + torch.log(y))
+
+
+def poisson_log_prob(x, rate):
+    """tfd.Poisson(rate).log_prob(x) = xlogy(x, rate) - lgamma(x+1) - rate
+    (multiply_no_nan: 0 * log 0 := 0)."""
+    return torch.xlogy(x, rate) - torch.lgamma(x + 1.0) - rate
+
+
+# --------------------------------------------------------------------------
+# model pieces
+# --------------------------------------------------------------------------
+def encoder_function(cfg: OracleConfig, x):
+    """poisson.py:34-43"""
+    eta = _t(cfg.eta_i)
+    if cfg.log_transform:
+        return torch.log(x / eta + 1.0)
+    return x / eta
+
+
+def decoder_function(cfg: OracleConfig, y):
+    """poisson.py:45-54"""
+    eta = _t(cfg.eta_i)
+    if cfg.log_transform:
+        return torch.exp(y * eta) - 1.0
+    return y * eta
+
+
+def compute_scales(cfg: OracleConfig, batches, compute_normalization=True):
+    """poisson.py:113-154.  ``batches`` is an iterable of dense [B,D] arrays.
+    Mutates cfg.eta_i / cfg.xi_u_global exactly as the reference does
+    (NaN xi when a column is empty, :139-140, reproduced verbatim here)."""
+    if not (cfg.scale_columns and compute_normalization):
+        return cfg
+    colsums, colnz, N = None, None, 0
+    for b in batches:
+        b = _t(b)
+        cs = b.sum(0, keepdim=True)
+        nz = (b > 0).to(torch.float32).sum(0, keepdim=True)
+        colsums = cs if colsums is None else colsums + cs
+        colnz = nz if colnz is None else colnz + nz
+        N += b.shape[0]
+    colmeans_nonzero = colsums.to(F64) / colnz.to(F64)
+    rowmean_nonzero = colmeans_nonzero.sum()
+    cfg.eta_i = torch.where(colmeans_nonzero > 1, colmeans_nonzero,
+                            torch.ones_like(colmeans_nonzero))
+    cfg.xi_u_global = rowmean_nonzero if cfg.scale_rows else 1.0
+    return cfg
+
+
+def encoding_matrix(u, s):
+    """poisson.py:652-666:  A = (s0/(s0+s1))^T * u   -> [S,D,K]"""
+    weights = s / s.sum(-2, keepdim=True)
+    return weights[..., 0, :].unsqueeze(-1) * u
+
+
+def intercept_matrix(cfg: OracleConfig, w, s):
+    """poisson.py:680-701:  phi = eta * (s1/(s0+s1)) * w   -> [S,1,D]"""
+    weights = s / s.sum(-2).unsqueeze(-2)
+    weights_2 = weights[..., 1, :].unsqueeze(-1).transpose(-1, -2)
+    return _t(cfg.eta_i) * weights_2 * w
+
+
+def decoding_matrix(v):
+    """poisson.py:668-678"""
+    return v
+
+
+def encode(cfg: OracleConfig, x, u, s):
+    """poisson.py:623-650"""
+    A = encoding_matrix(u, s)
+    z = torch.matmul(encoder_function(cfg, x), A)
+    if cfg.scale_rows:
+        xi_u = x.sum(-1, keepdim=True) / _t(cfg.xi_u_global)
+        z = z * xi_u
+    return z
+
+
+def log_likelihood_components(cfg: OracleConfig, x, s, u, v, w):
+    """poisson.py:156-184"""
+    theta_u = encode(cfg, x, u, s)
+    phi = intercept_matrix(cfg, w, s)
+    B = decoding_matrix(v)
+    theta_beta = decoder_function(cfg, torch.matmul(theta_u, B))
+    rate = theta_beta + phi
+    return {"log_likelihood": poisson_log_prob(x, rate), "rate": rate}
+
+
+def prior_log_prob_parts(cfg: OracleConfig, p: Dict[str, torch.Tensor]):
+    """JointDistributionNamed.log_prob_parts over poisson.py:228-377
+    (horseshoe-plus branch, the default :62,244).  Each part is summed over
+    its two event dims (reinterpreted_batch_ndims=2) -> shape [S]."""
+    K = cfg.latent_dim
+    decay = (cfg.symmetry_breaking_decay
+             ** torch.arange(K, dtype=F64))[None, :]          # :225-226
+    half = torch.tensor(0.5, dtype=F64)
+    one = torch.tensor(1.0, dtype=F64)
+    sm = lambda t: t.sum((-1, -2))
+    out = {}
+    out["v"] = sm(halfnormal_log_prob(p["v"], torch.tensor(0.1, dtype=F64)))
+    out["w"] = sm(halfnormal_log_prob(p["w"], one))
+    out["u"] = sm(halfnormal_log_prob(
+        p["u"], p["u_eta"] * p["u_tau"] * decay))                # :247-251
+    out["s"] = sm(halfnormal_log_prob(p["s"], p["s_eta"] * p["s_tau"]))
+    out["u_eta"] = sm(sqrt_inverse_gamma_log_prob(
+        p["u_eta"], half, 1.0 / p["u_eta_a"]))                   # :303-311
+    out["u_eta_a"] = sm(inverse_gamma_log_prob(p["u_eta_a"], half, one))
+    out["u_tau"] = sm(sqrt_inverse_gamma_log_prob(
+        p["u_tau"], half, 1.0 / p["u_tau_a"]))                   # :323-331
+    out["u_tau_a"] = sm(inverse_gamma_log_prob(
+        p["u_tau_a"], half,
+        torch.tensor(1.0 / cfg.u_tau_scale ** 2, dtype=F64)))    # :332-341
+    out["s_eta"] = sm(sqrt_inverse_gamma_log_prob(
+        p["s_eta"], half, 1.0 / p["s_eta_a"]))                   # :343-351
+    out["s_eta_a"] = sm(inverse_gamma_log_prob(p["s_eta_a"], half, one))
+    out["s_tau"] = sm(sqrt_inverse_gamma_log_prob(
+        p["s_tau"], half, 1.0 / p["s_tau_a"]))                   # :360-367
+    out["s_tau_a"] = sm(inverse_gamma_log_prob(
+        p["s_tau_a"], half,
+        torch.tensor(1.0 / cfg.s_tau_scale ** 2, dtype=F64)))    # :368-377
+    return out
+
+
+def unormalized_log_prob_parts(cfg: OracleConfig, counts, params,
+                               prior_weight: float = 1.0):
+    """poisson.py:582-621 -- the energy.  ``counts`` dense [B,D];
+    ``params``: dict name -> [S, *event] float64 tensors."""
+    x = _t(counts)
+    p = {k: _t(v) for k, v in params.items()}
+    parts = prior_log_prob_parts(cfg, p)
+    parts = {k: v * prior_weight for k, v in parts.items()}        # :591
+    ll = log_likelihood_components(
+        cfg, x, p["s"], p["u"], p["v"], p["w"])["log_likelihood"]  # :592-593
+    theta = encode(cfg, x, p["u"], p["s"])                         # :598
+    parts["z"] = (HALF_LOG_2_OVER_PI - 0.5 * theta ** 2).sum((-1, -2))  # :599-604
+    finite = torch.isfinite(ll)
+    finite_portion = torch.where(finite, ll, torch.zeros_like(ll))  # :606-608
+    min_val = finite_portion.min() - 10.0                           # :609
+    ll = torch.clamp(ll, min=min_val, max=torch.tensor(0.0, dtype=F64))  # :611
+    ll = torch.where(torch.isfinite(ll), ll,
+                     torch.ones_like(ll) * min_val)                 # :612-616
+    parts["x"] = ll.sum(-1).sum(-1)                                 # :617-619
+    return parts
+
+
+def unormalized_log_prob(cfg: OracleConfig, counts, params, prior_weight=1.0):
+    """poisson.py:575-580.  NB the reference ignores its ``prior_weight``
+    argument and passes the literal 1. (:577); reproduced."""
+    parts = unormalized_log_prob_parts(cfg, counts, params, prior_weight=1.0)
+    return sum(parts.values())
+
+
+def energy_and_grads(cfg: OracleConfig, counts, params):
+    """Energy parts and d(sum over S of sum of parts)/d(param) via fp64
+    autograd.  Since samples are independent, the gradient slice [s] is the
+    per-sample gradient.  Also returns per-group gradients:
+      'data'  : d(x + z)/d(u,v,w,s)
+      'prior' : d(sum of prior parts)/d(all 12)
+    """
+    p = {k: _t(v).clone().requires_grad_(True) for k, v in params.items()}
+    parts = unormalized_log_prob_parts(cfg, counts, p)
+    names = list(p.keys())
+    data_term = (parts["x"] + parts["z"]).sum()
+    prior_term = sum(v.sum() for k, v in parts.items() if k not in ("x", "z"))
+    gd = torch.autograd.grad(data_term, [p[n] for n in names],
+                             retain_graph=True, allow_unused=True)
+    gp = torch.autograd.grad(prior_term, [p[n] for n in names],
+                             allow_unused=True)
+    zero = lambda n: torch.zeros_like(p[n])
+    grads_data = {n: (g if g is not None else zero(n)).detach()
+                  for n, g in zip(names, gd)}
+    grads_prior = {n: (g if g is not None else zero(n)).detach()
+                   for n, g in zip(names, gp)}
+    grads = {n: grads_data[n] + grads_prior[n] for n in names}
+    return ({k: v.detach() for k, v in parts.items()}, grads,
+            {"data": grads_data, "prior": grads_prior})
+
+
+# --------------------------------------------------------------------------
+# surrogate posterior as the reference initialises it (poisson.py:403-539).
+# The parameterisation inside bayesianquilts' build_trainable_* is
+# [UNVERIFIED-3P]; the build DEFINES: positive parameters are softplus(raw).
+# --------------------------------------------------------------------------
+def softplus_inverse(y):
+    y = np.asarray(y, dtype=np.float64)
+    return y + np.log(-np.expm1(-y))
+
+
+def surrogate_initial_state(cfg: OracleConfig):
+    """dict name -> dict(kind, and the initial *constrained* parameter
+    values) for the horseshoe-plus surrogate, poisson.py:403-539."""
+    D, K = cfg.feature_dim, cfg.latent_dim
+    sh = var_shapes(D, K)
+    ones = lambda n: np.ones(sh[n])
+    st = {}
+    st["v"] = dict(kind="normal", loc=-6.0 * ones("v"), scale=5e-4 * ones("v"))
+    st["w"] = dict(kind="normal", loc=-6.0 * ones("w"), scale=5e-4 * ones("w"))
+    st["u"] = dict(kind="normal", loc=-6.0 * ones("u"), scale=5e-4 * ones("u"))
+    st["u_eta"] = dict(kind="invgamma", concentration=3.0 * ones("u_eta"),
+                       scale=ones("u_eta"))
+    st["u_tau"] = dict(kind="invgamma", concentration=3.0 * ones("u_tau"),
+                       scale=ones("u_tau"))
+    st["s_eta"] = dict(kind="invgamma", concentration=ones("s_eta"),
+                       scale=ones("s_eta"))
+    st["s_tau"] = dict(kind="invgamma", concentration=ones("s_tau"),
+                       scale=ones("s_tau"))
+    st["s"] = dict(kind="normal",
+                   loc=ones("s") * np.array([[-2.0], [-1.0]]),
+                   scale=1e-3 * ones("s"))
+    st["u_eta_a"] = dict(kind="invgamma", concentration=2.0 * ones("u_eta_a"),
+                         scale=ones("u_eta_a"))
+    st["u_tau_a"] = dict(kind="invgamma", concentration=2.0 * ones("u_tau_a"),
+                         scale=ones("u_tau_a") / cfg.u_tau_scale ** 2)
+    st["s_eta_a"] = dict(kind="invgamma", concentration=2.0 * ones("s_eta_a"),
+                         scale=ones("s_eta_a"))
+    st["s_tau_a"] = dict(kind="invgamma", concentration=2.0 * ones("s_tau_a"),
+                         scale=ones("s_tau_a") / cfg.s_tau_scale ** 2)
+    return st
+
+
+def surrogate_transform(kind, t0, t1, noise):
+    """Map (trainables, base noise) -> (theta, log q(theta)) in fp64 torch.
+
+    normal  : t0=loc, t1=raw_scale; sigma=softplus(t1); y=loc+sigma*eps;
+              theta=softplus(y)                 (tfb.Softplus(tfd.Normal))
+    invgamma: t0=raw_conc, t1=raw_scale; a=softplus(t0), b=softplus(t1);
+              noise = gamma(a,1) draw g; y=b/g; theta=softplus(y)
+                                          (tfb.Softplus(tfd.InverseGamma))
+    log q(theta) = log q_y(y) - log sigmoid(y), summed over the event dims.
+    """
+    sp = torch.nn.functional.softplus
+    if kind == "normal":
+        sigma = sp(t1)
+        y = t0 + sigma * noise
+        lq = (-0.5 * noise ** 2 - torch.log(sigma)
+              - 0.5 * math.log(2 * math.pi))
+    else:
+        a, b = sp(t0), sp(t1)
+        y = b / noise
+        lq = inverse_gamma_log_prob(y, a, b)
+    theta = sp(y)
+    lq = lq - torch.nn.functional.logsigmoid(y)
+    return theta, lq.sum((-1, -2))
+
+
+def random_params(cfg: OracleConfig, S: int, seed: int, spread: float = 0.3):
+    """Seeded positive parameter draws of realistic magnitude for parity
+    tests (NOT the surrogate: just well-conditioned positive tensors)."""
+    rng = np.random.default_rng(seed)
+    D, K = cfg.feature_dim, cfg.latent_dim
+    sh = var_shapes(D, K)
+    base = {"v": 0.3, "w": 0.2, "u": 0.3, "u_eta": 0.8, "u_tau": 0.5,
+            "s_eta": 0.9, "s_tau": 0.7, "s": 0.4, "u_eta_a": 1.2,
+            "u_tau_a": 1.5, "s_eta_a": 1.1, "s_tau_a": 0.9}
+    out = {}
+    for n in VAR_ORDER:
+        out[n] = base[n] * np.exp(spread * rng.standard_normal((S,) + sh[n]))
+    return out

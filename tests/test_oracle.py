@@ -1,0 +1,213 @@
+"""Pins for the CPU oracle (PARITY UNPINNED by the reference -- these are the
+substitutes SURVEY.md section 8c lists): scipy densities, the HalfCauchy
+marginal identity, finite differences, hand-computed known answers and
+sparse-exact == dense."""
+import math
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.stats as st
+import torch
+from scipy import integrate
+
+from oracle import spmf_oracle as O
+from oracle import sparse_exact as SE
+
+F64 = torch.float64
+
+
+def T(x):
+    return torch.as_tensor(np.asarray(x, dtype=np.float64))
+
+
+def test_densities_match_scipy():
+    rng = np.random.default_rng(0)
+    y = rng.uniform(0.05, 4.0, size=50)
+    sc = rng.uniform(0.2, 3.0, size=50)
+    np.testing.assert_allclose(
+        O.halfnormal_log_prob(T(y), T(sc)).numpy(),
+        st.halfnorm.logpdf(y, scale=sc), rtol=1e-13, atol=1e-13)
+    a = rng.uniform(0.3, 4.0, size=50)
+    np.testing.assert_allclose(
+        O.inverse_gamma_log_prob(T(y), T(a), T(sc)).numpy(),
+        st.invgamma.logpdf(y, a, scale=sc), rtol=1e-12, atol=1e-12)
+    x = rng.poisson(3.0, size=50).astype(np.float64)
+    r = rng.uniform(0.1, 9.0, size=50)
+    np.testing.assert_allclose(
+        O.poisson_log_prob(T(x), T(r)).numpy(), st.poisson.logpmf(x, r),
+        rtol=1e-12, atol=1e-12)
+    # 0 * log 0 := 0 (multiply_no_nan), tfd.Poisson semantics
+    assert O.poisson_log_prob(T([0.0]), T([0.0])).item() == 0.0
+    assert O.poisson_log_prob(T([2.0]), T([0.0])).item() == -math.inf
+
+
+def test_sqrt_inverse_gamma_is_change_of_variables():
+    # P(Y<=y) for Y=sqrt(X), X~InvGamma(a,b) equals InvGamma cdf at y^2
+    a, b = 0.5, 1.7
+    for y in (0.3, 1.0, 2.5):
+        val, _ = integrate.quad(
+            lambda t: math.exp(O.sqrt_inverse_gamma_log_prob(
+                T(t), T(a), T(b)).item()), 0, y, limit=200)
+        assert abs(val - st.invgamma.cdf(y * y, a, scale=b)) < 1e-7
+
+
+@pytest.mark.parametrize("tau", [0.01, 1.0, 3.0])
+def test_horseshoe_plus_hierarchy_marginalises_to_halfcauchy(tau):
+    # y|a ~ SqrtInvGamma(1/2, 1/a), a ~ InvGamma(1/2, 1/tau^2) => y ~ HalfCauchy(tau)
+    # (poisson.py:303-341 replaces the HalfCauchy entries at :252-295)
+    for y in (0.2 * tau, tau, 4.0 * tau):
+        f = lambda la: math.exp(
+            O.sqrt_inverse_gamma_log_prob(T(y), T(0.5), T(math.exp(-la))).item()
+            + O.inverse_gamma_log_prob(T(math.exp(la)), T(0.5), T(1 / tau ** 2)).item()
+            + la)
+        val, _ = integrate.quad(f, -40, 40, limit=400)
+        assert abs(val / st.halfcauchy.pdf(y, scale=tau) - 1) < 1e-6
+
+
+def _tiny_cfg():
+    return O.OracleConfig(latent_dim=1, feature_dim=3, scale_rows=True,
+                          eta_i=T([[2.0, 1.0, 4.0]]), xi_u_global=5.0)
+
+
+def test_known_answer_B2_D3_K1():
+    """Hand-computed: B=2, D=3, K=1."""
+    cfg = _tiny_cfg()
+    x = np.array([[2.0, 0.0, 4.0], [0.0, 3.0, 0.0]])
+    u = np.array([[[0.5], [0.2], [0.1]]])
+    s = np.array([[[1.0, 3.0, 1.0], [1.0, 1.0, 3.0]]])
+    v = np.array([[[0.3, 0.6, 0.9]]])
+    w = np.array([[[0.2, 0.4, 0.1]]])
+    # A = w1*u : w1 = [.5,.75,.25] -> A = [.25,.15,.025]
+    # g(x) = x/eta: row0 [1,0,1], row1 [0,3,0]
+    # z (unscaled) = [0.275, 0.45]; xi = rowsum/5 = [1.2, 0.6]
+    z = np.array([0.275 * 1.2, 0.45 * 0.6])
+    np.testing.assert_allclose(
+        O.encode(cfg, T(x), T(u), T(s)).numpy().reshape(-1), z, rtol=1e-14)
+    phi = np.array([2.0 * 0.5 * 0.2, 1.0 * 0.25 * 0.4, 4.0 * 0.75 * 0.1])
+    np.testing.assert_allclose(
+        O.intercept_matrix(cfg, T(w), T(s)).numpy().reshape(-1), phi, rtol=1e-14)
+    rate = z[:, None] * v.reshape(1, 3) * np.array([2.0, 1.0, 4.0]) + phi[None]
+    ll = st.poisson.logpmf(x, rate).sum()
+    zp = 2 * (0.5 * math.log(2 / math.pi)) - 0.5 * (z ** 2).sum()
+    params = dict(u=u, s=s, v=v, w=w)
+    for n, shp in O.var_shapes(3, 1).items():
+        if n not in params:
+            params[n] = np.ones((1,) + shp)
+    parts = O.unormalized_log_prob_parts(cfg, x, params)
+    assert abs(parts["x"].item() - ll) < 1e-12
+    assert abs(parts["z"].item() - zp) < 1e-13
+    # prior parts, all-ones hyper parameters: v ~ HalfNormal(.1)
+    assert abs(parts["v"].item() - st.halfnorm.logpdf(v, scale=0.1).sum()) < 1e-12
+    assert abs(parts["w"].item() - st.halfnorm.logpdf(w, scale=1.0).sum()) < 1e-12
+    assert abs(parts["u"].item() - st.halfnorm.logpdf(
+        u.reshape(3, 1), scale=1.0).sum()) < 1e-12
+    # SqrtInvGamma(.5, 1)(1) = InvGamma(.5,1).pdf(1) * 2
+    sig = math.log(st.invgamma.pdf(1.0, 0.5, scale=1.0) * 2.0)
+    assert abs(parts["u_eta"].item() - 3 * sig) < 1e-12
+    assert abs(parts["s_eta"].item() - 6 * sig) < 1e-12
+    assert abs(parts["u_tau_a"].item()
+               - st.invgamma.logpdf(1.0, 0.5, scale=1 / 0.01 ** 2)) < 1e-10
+    assert set(parts) == {"v", "w", "u", "s", "u_eta", "u_tau", "s_eta", "s_tau",
+                          "u_eta_a", "u_tau_a", "s_eta_a", "s_tau_a", "z", "x"}
+
+
+def _problem(B, D, K, S, seed, density=0.3, scale_rows=True, empty=True):
+    rng = np.random.default_rng(seed)
+    mask = rng.random((B, D)) < density
+    x = (mask * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    if empty and B > 2 and D > 2:
+        x[1, :] = 0.0          # empty row
+        x[:, 2] = 0.0          # empty column
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, scale_rows=scale_rows,
+                         u_tau_scale=1.0 / math.sqrt(B * D))
+    cfg.eta_i = T(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = float(rng.uniform(2.0, 6.0))
+    params = O.random_params(cfg, S, seed + 1)
+    return cfg, x, params
+
+
+def test_non_finite_rule():
+    """poisson.py:606-616: non-finite cells are replaced by (global min - 10)."""
+    cfg, x, params = _problem(4, 5, 2, 2, 3, empty=False)
+    params["w"][0, 0, 0] = 0.0     # phi=0 for sample 0, column 0
+    params["u"][0, 0, :] = 0.0
+    x[:, 0] = np.array([3.0, 0, 0, 0])
+    x[0, 1:] = 0                    # z_0 comes only from column 0 -> z_0 = 0, rate 0
+    ll = O.log_likelihood_components(
+        cfg, T(x), T(params["s"]), T(params["u"]), T(params["v"]),
+        T(params["w"]))["log_likelihood"]
+    assert torch.isinf(ll[0, 0, 0])
+    fin = torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll))
+    m = fin.min() - 10
+    expect = torch.where(torch.isfinite(ll), ll, m).sum((-1, -2))
+    got = O.unormalized_log_prob_parts(cfg, x, params)["x"]
+    np.testing.assert_allclose(got.numpy(), expect.numpy(), rtol=1e-13)
+
+
+def test_autograd_matches_finite_differences():
+    cfg, x, params = _problem(6, 5, 2, 1, 11)
+    parts, grads, _ = O.energy_and_grads(cfg, x, params)
+    total = lambda p: float(O.unormalized_log_prob(cfg, x, p).sum())
+    rng = np.random.default_rng(5)
+    for name in O.VAR_ORDER:
+        for _ in range(3):
+            idx = tuple(rng.integers(0, n) for n in params[name].shape)
+            h = 1e-6 * max(1.0, abs(params[name][idx]))
+            pp = {k: v.copy() for k, v in params.items()}
+            pm = {k: v.copy() for k, v in params.items()}
+            pp[name][idx] += h
+            pm[name][idx] -= h
+            fd = (total(pp) - total(pm)) / (2 * h)
+            an = grads[name][idx].item()
+            assert abs(fd - an) <= 2e-6 * max(1.0, abs(an)), (name, idx, fd, an)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("scale_rows", [True, False])
+def test_sparse_exact_equals_dense_oracle(seed, scale_rows):
+    B, D, K = [(7, 11, 3), (16, 9, 1), (5, 20, 4), (12, 12, 2), (3, 4, 5), (30, 17, 8)][seed]
+    cfg, x, params = _problem(B, D, K, 2, 100 + seed, scale_rows=scale_rows)
+    parts, grads, groups = O.energy_and_grads(cfg, x, params)
+    decay = cfg.symmetry_breaking_decay ** np.arange(K)
+    for smp in range(2):
+        one = {k: v[smp] for k, v in params.items()}
+        out = SE.data_term(sp.csr_matrix(x), cfg.eta_i.numpy().reshape(-1),
+                           cfg.xi_u_global, scale_rows,
+                           one["u"], one["v"], one["w"], one["s"])
+        assert out["n_nonfinite"] == 0
+        np.testing.assert_allclose(out["x"], parts["x"][smp].item(), rtol=1e-12)
+        np.testing.assert_allclose(out["z"], parts["z"][smp].item(), rtol=1e-12)
+        for n in ("u", "v", "w", "s"):
+            ref = groups["data"][n][smp].numpy()
+            np.testing.assert_allclose(out["grads"][n], ref, rtol=1e-10,
+                                       atol=1e-11 * np.abs(ref).max())
+        pparts, pg = SE.prior_term(one, cfg.u_tau_scale, cfg.s_tau_scale, decay)
+        for n in O.VAR_ORDER:
+            np.testing.assert_allclose(pparts[n], parts[n][smp].item(), rtol=1e-12)
+            ref = groups["prior"][n][smp].numpy()
+            np.testing.assert_allclose(pg[n], ref, rtol=1e-10,
+                                       atol=1e-12 * max(1.0, np.abs(ref).max()))
+
+
+def test_compute_scales_reference_semantics():
+    """poisson.py:113-154: eta = colmean over non-zero entries where > 1 else 1;
+    xi = sum of those column means."""
+    x = np.array([[4.0, 0, 1, 0], [2.0, 1, 0, 0], [0, 1, 1, 0], [6.0, 0, 0, 2.0]])
+    cfg = O.OracleConfig(latent_dim=2, feature_dim=4)
+    O.compute_scales(cfg, [x[:2], x[2:]])
+    np.testing.assert_allclose(cfg.eta_i.numpy().reshape(-1), [4.0, 1.0, 1.0, 2.0])
+    assert abs(float(cfg.xi_u_global) - (4.0 + 1.0 + 1.0 + 2.0)) < 1e-14
+
+
+def test_surrogate_initial_state_shapes_and_order():
+    cfg = O.OracleConfig(latent_dim=3, feature_dim=5, u_tau_scale=0.02)
+    st_ = O.surrogate_initial_state(cfg)
+    assert tuple(st_.keys()) == O.VAR_ORDER
+    assert st_["s"]["loc"][0, 0] == -2.0 and st_["s"]["loc"][1, 0] == -1.0
+    assert st_["u_tau_a"]["scale"][0, 0] == pytest.approx(1 / 0.02 ** 2)
+    # softplus(N(-6, 5e-4)) is tiny and positive, as the reference initialises u,v,w
+    th, lq = O.surrogate_transform(
+        "normal", T(st_["u"]["loc"]), T(O.softplus_inverse(st_["u"]["scale"])),
+        torch.zeros(5, 3, dtype=F64))
+    assert torch.all(th > 0) and th.max() < 3e-3 and torch.isfinite(lq)
