@@ -1,0 +1,169 @@
+/* spmf_hip.h -- C-ABI of libspmf_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of mederrata/spmf: the per-batch energy
+ * (ELBO integrand) of PoissonFactorization and its gradient through the
+ * factor matrices.  The reference has no FFI; the seam this library sits
+ * behind is the Python method
+ *     PoissonFactorization.unormalized_log_prob_parts(data, **params)
+ *         mederrata_spmf/poisson.py:582-621
+ * (called once per optimiser step by bayesianquilts' fit/calibrate_advi,
+ * tests/spmf_test.py:35-43, bin/factorize_csv.py:121-124) and the helpers it
+ * calls: encode :623-650, encoding_matrix :652-666, intercept_matrix
+ * :680-701, log_likelihood_components :156-184, compute_scales :113-154 and
+ * the prior of create_distributions :212-401.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch tensors on
+ *    the Python side) unless marked "host"; the library allocates nothing on
+ *    the device: the caller supplies the workspace (spmf_workspace_bytes).
+ *  - all calls are asynchronous on the hipStream_t passed as `stream`
+ *    (void* so the header needs no HIP include); one ctx per (process,
+ *    device); calls on one ctx are stream-ordered and not re-entrant.
+ *  - return value: 0 = ok, <0 = error (SPMF_E_*); spmf_last_error() gives
+ *    the message.  Nothing throws across this boundary.
+ *  - arithmetic: fp32 storage and fp32 FMA, fp64 accumulation of every
+ *    scalar reduction ("dtype": "f32" in bench.py).
+ *  - S = number of Monte-Carlo draws = leading axis of every parameter.
+ *
+ * Variable order everywhere (= the reference's surrogate var_list,
+ * poisson.py:403-539,572):
+ *   0 v[K,D] 1 w[1,D] 2 u[D,K] 3 u_eta[D,K] 4 u_tau[1,K] 5 s_eta[2,D]
+ *   6 s_tau[1,D] 7 s[2,D] 8 u_eta_a[D,K] 9 u_tau_a[1,K] 10 s_eta_a[2,D]
+ *   11 s_tau_a[1,D]
+ * Energy parts order: the 12 prior parts in that order, then 12 = 'z',
+ * 13 = 'x' (poisson.py:604,619).
+ */
+#ifndef SPMF_HIP_H
+#define SPMF_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPMF_NVARS 12
+#define SPMF_NPARTS 14
+#define SPMF_PART_Z 12
+#define SPMF_PART_X 13
+
+#define SPMF_OK 0
+#define SPMF_E_ARG (-1)       /* bad argument (null pointer, bad size, K unsupported) */
+#define SPMF_E_HIP (-2)       /* a HIP runtime call failed */
+#define SPMF_E_WORKSPACE (-3) /* caller's workspace too small */
+#define SPMF_E_UNSUPPORTED (-4)
+
+/* flags for spmf_ctx_create */
+#define SPMF_FLAG_SCALE_ROWS 1u     /* poisson.py:61,644-649 */
+#define SPMF_FLAG_LOG_TRANSFORM 2u  /* poisson.py:41-42,52-53 (dense path only) */
+
+typedef struct spmf_ctx spmf_ctx;
+
+/* One batch (or one row shard) of the count matrix, device resident.
+ * Row-major CSR for the row pass and a row-panel CSC ("panel-CSC": for each
+ * panel of `panel_rows` consecutive rows, a CSC of that panel) for the
+ * column pass.  Replaces the dense [B,D] tensor data[count_key] the
+ * reference feeds to encode/log_likelihood_components (poisson.py:170,182).
+ */
+typedef struct spmf_counts {
+  int64_t n_rows;           /* B: rows of this batch */
+  int64_t nnz;              /* stored entries of this batch */
+  int32_t n_cols;           /* D */
+  int32_t n_panels;         /* row panels covering the batch */
+  int32_t panel_rows;       /* rows per panel (last one may be short) */
+  int32_t row_base;         /* row id stored in pc_row for batch row 0 */
+  const int32_t* row_ptr;   /* [B+1] absolute offsets into col_idx/val */
+  const int32_t* col_idx;   /* base pointer (not offset) */
+  const float* val;         /* base pointer: raw counts x_bd */
+  const float* row_scale;   /* [B] xi_b = rowsum_b / xi_u_global, or NULL => 1 */
+  const int32_t* pc_ptr;    /* [n_panels*(D+1)] absolute offsets into pc_row/pc_val */
+  const int32_t* pc_row;    /* base pointer: row id (row_base + batch row) */
+  const float* pc_val;      /* base pointer */
+  double lgamma_sum;        /* sum over the batch of lgamma(x+1) (parameter free) */
+} spmf_counts;
+
+int spmf_version(void);
+
+/* K = latent_dim, D = feature_dim (poisson.py:58,102-104). */
+int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out);
+void spmf_ctx_destroy(spmf_ctx* ctx);
+const char* spmf_last_error(const spmf_ctx* ctx); /* host string */
+
+/* Hyper-parameters of the prior (poisson.py:59,106-107,225-226). */
+int spmf_ctx_set_prior(spmf_ctx* ctx, double u_tau_scale, double s_tau_scale,
+                       double symmetry_breaking_decay);
+
+/* Bytes of caller-owned device workspace needed for batches of up to
+ * max_rows rows and S draws. */
+size_t spmf_workspace_bytes(const spmf_ctx* ctx, int64_t max_rows, int S);
+int spmf_ctx_set_workspace(spmf_ctx* ctx, void* workspace, size_t bytes);
+
+/* ---- dataset pre-pass ------------------------------------------------- */
+/* compute_scales (poisson.py:113-154): column sums and per-column counts of
+ * x>0 of a CSR block, ACCUMULATED into colsum[D] (fp64) / colnnz[D] (fp64),
+ * plus per-row sums row_sum[B] (fp32) and per-row sums of lgamma(x+1)
+ * row_lgamma[B] (fp64).  Any output pointer may be NULL. */
+int spmf_counts_stats(spmf_ctx* ctx, int64_t n_rows, const int32_t* row_ptr,
+                      const int32_t* col_idx, const float* val, double* colsum,
+                      double* colnnz, float* row_sum, double* row_lgamma,
+                      void* stream);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* Phase 1: sparse data term for S draws.  Reads u,v,w,s (params[2,0,1,7])
+ * and eta[D] (eta_i, poisson.py:88-91,142-149; ones when unscaled).  Leaves
+ * per-draw accumulators in the workspace:
+ *   acc[S][acc_len] fp32 = [ gA'(D*KP) | gV'(D*KP) | gphi(D) | tail ]
+ * where the tail carries the fp64 scalars (sum x log r, sum z^2, sum_b z_b,
+ * non-finite count) as (hi,lo) float pairs so ONE fp32 sum-all-reduce of
+ * acc over row shards finishes the reduction. */
+int spmf_data_pass(spmf_ctx* ctx, const spmf_counts* counts, int S,
+                   const float* const params[SPMF_NVARS], const float* eta,
+                   void* stream);
+float* spmf_acc_ptr(const spmf_ctx* ctx);      /* device pointer into the workspace */
+int64_t spmf_acc_len(const spmf_ctx* ctx, int S); /* floats, all S draws */
+
+/* Phase 2: chain the accumulators to d/d(u,v,w,s), add the horseshoe-plus
+ * prior (poisson.py:228-377) parts and gradients for all 12 variables, and
+ * finish the 14 energy parts.  n_rows_global / lgamma_sum_global are the
+ * batch totals over all shards (= this shard's when single GPU).
+ *   parts[S][14] fp64 (unweighted), grads[i] has the shape of params[i]
+ *   (fp32) and holds d(x + z + prior_weight * sum of prior parts)/d(param):
+ *   prior_weight = 1 is the reference's energy (poisson.py:577 passes the
+ *   literal 1.); a minibatch driver passes B/N.
+ *   n_nonfinite[S] (fp64, may be NULL): stored cells whose log-pmf was not
+ *   finite; the sparse fast path assumes 0 (poisson.py:606-616 is then the
+ *   identity). */
+int spmf_finish(spmf_ctx* ctx, int S, int64_t n_rows_global,
+                double lgamma_sum_global, double prior_weight,
+                const float* const params[SPMF_NVARS], const float* eta,
+                double* parts, float* const grads[SPMF_NVARS],
+                double* n_nonfinite, void* stream);
+
+/* Phases 1+2 back to back (single shard). */
+int spmf_elbo_fwd_bwd(spmf_ctx* ctx, const spmf_counts* counts, int S,
+                      double prior_weight,
+                      const float* const params[SPMF_NVARS], const float* eta,
+                      double* parts, float* const grads[SPMF_NVARS],
+                      double* n_nonfinite, void* stream);
+
+/* encode (poisson.py:623-650) for one (u,s) draw: z[B,K] row-major fp32. */
+int spmf_encode(spmf_ctx* ctx, const spmf_counts* counts, const float* u,
+                const float* s, const float* eta, float* z_out, void* stream);
+
+/* Test/diagnostic taps: per-row z and d/dz of the LAST draw processed by
+ * spmf_data_pass, [B,KP] fp32 with KP = spmf_padded_k(). */
+int spmf_padded_k(const spmf_ctx* ctx);
+const float* spmf_z_ptr(const spmf_ctx* ctx);
+const float* spmf_gz_ptr(const spmf_ctx* ctx);
+
+/* Per-kernel device time of the last spmf_data_pass/spmf_finish when
+ * profiling was enabled (hipEvents on `stream`; synchronises): ms[5] =
+ * prep, row pass, column pass, finish, total.  For bench.py's roofline. */
+int spmf_ctx_enable_timing(spmf_ctx* ctx, int on);
+int spmf_last_timing(spmf_ctx* ctx, float* ms5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMF_HIP_H */

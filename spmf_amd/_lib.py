@@ -1,0 +1,101 @@
+"""ctypes binding of libspmf_hip.so (the C-ABI in include/spmf_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this
+module raises.  PyTorch tensors are used purely as device storage
+(``tensor.data_ptr()`` handed to ctypes).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspmf_hip.so")
+
+NVARS = 12
+NPARTS = 14
+#: variable order of the C-ABI = the reference's var_list (poisson.py:403-539,572)
+VAR_ORDER = ("v", "w", "u", "u_eta", "u_tau", "s_eta", "s_tau", "s",
+             "u_eta_a", "u_tau_a", "s_eta_a", "s_tau_a")
+PART_ORDER = VAR_ORDER + ("z", "x")
+
+FLAG_SCALE_ROWS = 1
+FLAG_LOG_TRANSFORM = 2
+
+
+class SpmfError(RuntimeError):
+    pass
+
+
+class CountsStruct(C.Structure):
+    """struct spmf_counts (include/spmf_hip.h)."""
+    _fields_ = [
+        ("n_rows", C.c_int64), ("nnz", C.c_int64),
+        ("n_cols", C.c_int32), ("n_panels", C.c_int32),
+        ("panel_rows", C.c_int32), ("row_base", C.c_int32),
+        ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("val", C.c_void_p),
+        ("row_scale", C.c_void_p),
+        ("pc_ptr", C.c_void_p), ("pc_row", C.c_void_p), ("pc_val", C.c_void_p),
+        ("lgamma_sum", C.c_double),
+    ]
+
+
+PtrArray = C.c_void_p * NVARS
+
+#: every symbol include/spmf_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "spmf_version": (C.c_int, []),
+    "spmf_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint,
+                                  C.POINTER(C.c_void_p)]),
+    "spmf_ctx_destroy": (None, [C.c_void_p]),
+    "spmf_last_error": (C.c_char_p, [C.c_void_p]),
+    "spmf_ctx_set_prior": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "spmf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int]),
+    "spmf_ctx_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "spmf_counts_stats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 7
+                          + [C.c_void_p]),
+    "spmf_data_pass": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int,
+                                 PtrArray, C.c_void_p, C.c_void_p]),
+    "spmf_acc_ptr": (C.c_void_p, [C.c_void_p]),
+    "spmf_acc_len": (C.c_int64, [C.c_void_p, C.c_int]),
+    "spmf_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double,
+                              C.c_double, PtrArray, C.c_void_p, C.c_void_p, PtrArray,
+                              C.c_void_p, C.c_void_p]),
+    "spmf_elbo_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int,
+                                    C.c_double, PtrArray, C.c_void_p, C.c_void_p, PtrArray,
+                                    C.c_void_p, C.c_void_p]),
+    "spmf_encode": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct)] + [C.c_void_p] * 5),
+    "spmf_padded_k": (C.c_int, [C.c_void_p]),
+    "spmf_z_ptr": (C.c_void_p, [C.c_void_p]),
+    "spmf_gz_ptr": (C.c_void_p, [C.c_void_p]),
+    "spmf_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "spmf_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libspmf_hip.so (built in-tree by ``__graft_entry__.build()`` /
+    ``make -C spmf_amd/csrc``).  Raises SpmfError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpmfError(
+            f"{LIB_PATH} not found: build it with `make -C spmf_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError -> missing export
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, rc, what):
+    if rc != 0:
+        msg = load().spmf_last_error(ctx_handle)
+        raise SpmfError(f"{what} failed (rc={rc}): "
+                        f"{msg.decode() if msg else '?'}")

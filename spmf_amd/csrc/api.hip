@@ -1,0 +1,298 @@
+// api.hip -- the C-ABI of libspmf_hip.so (see include/spmf_hip.h).
+// Host-side orchestration only: argument checks, workspace carving, stream
+// ordered launches.  No device allocation, no host<->device copies, no
+// synchronisation on the hot path (timing taps excepted, off by default).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/spmf_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace spmf;
+
+struct spmf_ctx {
+  int device = 0, K = 0, D = 0, KP = 0;
+  unsigned flags = 0;
+  double u_tau_scale = 0.01, s_tau_scale = 1.0, decay = 0.99;  // poisson.py:59
+  // workspace carve
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  int64_t ws_rows = 0;
+  int ws_S = 0;
+  float* acc = nullptr;
+  double* dacc = nullptr;
+  double* dprep = nullptr;
+  float *Ap = nullptr, *Vp = nullptr, *phi = nullptr, *z = nullptr, *gzs = nullptr;
+  // timing taps
+  int timing = 0;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int ev_valid = 0;
+  std::string err;
+};
+
+static int fail(spmf_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define HIPCHK(c, call)                                                            \
+  do {                                                                             \
+    hipError_t e_ = (call);                                                        \
+    if (e_ != hipSuccess)                                                          \
+      return fail((c), SPMF_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+static int padded_k(int K) {
+  int kp = 4;
+  while (kp < K) kp <<= 1;
+  return kp;
+}
+static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t var_size(const spmf_ctx* c, int i) {
+  const size_t D = c->D, K = c->K;
+  switch (i) {
+    case 0: case 2: case 3: case 8: return D * K;
+    case 4: case 9: return K;
+    case 1: case 6: case 11: return D;
+    default: return 2 * D;  // 5 s_eta, 7 s, 10 s_eta_a
+  }
+}
+
+struct Carve {
+  size_t acc, dacc, dprep, Ap, Vp, phi, z, gzs, total;
+};
+static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
+  Carve k;
+  size_t o = 0;
+  const size_t KP = c->KP, D = c->D;
+  k.acc = o;   o += al((size_t)S * acc_len(c->D, c->KP) * sizeof(float));
+  k.dacc = o;  o += al((size_t)S * (kDaccHead + KP) * sizeof(double));
+  k.dprep = o; o += al((size_t)S * (KP + 1) * sizeof(double));
+  k.Ap = o;    o += al(D * KP * sizeof(float));
+  k.Vp = o;    o += al(D * KP * sizeof(float));
+  k.phi = o;   o += al(D * sizeof(float));
+  k.z = o;     o += al((size_t)rows * KP * sizeof(float));
+  k.gzs = o;   o += al((size_t)rows * KP * sizeof(float));
+  k.total = o;
+  return k;
+}
+
+extern "C" {
+
+int spmf_version(void) { return 1; }
+
+int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
+  if (!out) return SPMF_E_ARG;
+  *out = nullptr;
+  if (K < 1 || K > 64 || D < 1) return SPMF_E_ARG;
+  spmf_ctx* c = new spmf_ctx();
+  c->device = device;
+  c->K = K;
+  c->D = D;
+  c->KP = padded_k(K);
+  c->flags = flags;
+  *out = c;
+  return SPMF_OK;
+}
+
+void spmf_ctx_destroy(spmf_ctx* c) {
+  if (!c) return;
+  for (auto& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete c;
+}
+
+const char* spmf_last_error(const spmf_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int spmf_ctx_set_prior(spmf_ctx* c, double u_tau_scale, double s_tau_scale, double decay) {
+  if (!c || !(u_tau_scale > 0) || !(s_tau_scale > 0) || !(decay > 0)) return fail(c, SPMF_E_ARG, "set_prior: scales must be > 0");
+  c->u_tau_scale = u_tau_scale;
+  c->s_tau_scale = s_tau_scale;
+  c->decay = decay;
+  return SPMF_OK;
+}
+
+int spmf_padded_k(const spmf_ctx* c) { return c ? c->KP : 0; }
+
+size_t spmf_workspace_bytes(const spmf_ctx* c, int64_t max_rows, int S) {
+  if (!c || max_rows < 0 || S < 1) return 0;
+  return carve(c, max_rows, S).total;
+}
+
+int spmf_ctx_set_workspace(spmf_ctx* c, void* workspace, size_t bytes) {
+  if (!c) return SPMF_E_ARG;
+  if (!workspace || ((uintptr_t)workspace & 255)) return fail(c, SPMF_E_ARG, "workspace must be 256-byte aligned and non-null");
+  c->ws = (char*)workspace;
+  c->ws_bytes = bytes;
+  c->ws_rows = -1;
+  c->ws_S = 0;
+  return SPMF_OK;
+}
+
+static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
+  if (!c->ws) return fail(c, SPMF_E_WORKSPACE, "no workspace set (spmf_ctx_set_workspace)");
+  Carve k = carve(c, rows, S);
+  if (k.total > c->ws_bytes) {
+    char b[160];
+    snprintf(b, sizeof b, "workspace too small: need %zu bytes for rows=%lld S=%d, have %zu", k.total, (long long)rows, S, c->ws_bytes);
+    return fail(c, SPMF_E_WORKSPACE, b);
+  }
+  c->acc = (float*)(c->ws + k.acc);
+  c->dacc = (double*)(c->ws + k.dacc);
+  c->dprep = (double*)(c->ws + k.dprep);
+  c->Ap = (float*)(c->ws + k.Ap);
+  c->Vp = (float*)(c->ws + k.Vp);
+  c->phi = (float*)(c->ws + k.phi);
+  c->z = (float*)(c->ws + k.z);
+  c->gzs = (float*)(c->ws + k.gzs);
+  c->ws_rows = rows;
+  c->ws_S = S;
+  return SPMF_OK;
+}
+
+float* spmf_acc_ptr(const spmf_ctx* c) { return c ? c->acc : nullptr; }
+int64_t spmf_acc_len(const spmf_ctx* c, int S) { return c ? (int64_t)S * acc_len(c->D, c->KP) : 0; }
+const float* spmf_z_ptr(const spmf_ctx* c) { return c ? c->z : nullptr; }
+const float* spmf_gz_ptr(const spmf_ctx* c) { return c ? c->gzs : nullptr; }
+
+int spmf_ctx_enable_timing(spmf_ctx* c, int on) {
+  if (!c) return SPMF_E_ARG;
+  if (on && !c->ev[0])
+    for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
+  c->timing = on;
+  c->ev_valid = 0;
+  return SPMF_OK;
+}
+
+int spmf_last_timing(spmf_ctx* c, float* ms5) {
+  if (!c || !ms5) return SPMF_E_ARG;
+  if (!c->timing || c->ev_valid != 3) return fail(c, SPMF_E_ARG, "no timing recorded (enable timing, run data_pass + finish)");
+  HIPCHK(c, hipEventSynchronize(c->ev[5]));
+  for (int i = 0; i < 3; ++i) HIPCHK(c, hipEventElapsedTime(&ms5[i], c->ev[i], c->ev[i + 1]));
+  HIPCHK(c, hipEventElapsedTime(&ms5[3], c->ev[4], c->ev[5]));
+  ms5[4] = ms5[0] + ms5[1] + ms5[2] + ms5[3];
+  return SPMF_OK;
+}
+
+static int check_counts(spmf_ctx* c, const spmf_counts* ct) {
+  if (!ct) return fail(c, SPMF_E_ARG, "counts is null");
+  if (ct->n_cols != c->D) return fail(c, SPMF_E_ARG, "counts.n_cols != ctx D");
+  if (ct->n_rows < 0 || ct->nnz < 0 || ct->nnz > 2147483647LL) return fail(c, SPMF_E_ARG, "counts: bad n_rows/nnz (nnz must fit int32)");
+  if (ct->n_rows * (int64_t)c->KP > 2147483647LL * 4) return fail(c, SPMF_E_ARG, "counts: too many rows for this K");
+  if (!ct->row_ptr || (ct->nnz > 0 && (!ct->col_idx || !ct->val))) return fail(c, SPMF_E_ARG, "counts: null CSR arrays");
+  return SPMF_OK;
+}
+
+int spmf_counts_stats(spmf_ctx* c, int64_t n_rows, const int32_t* row_ptr, const int32_t* col_idx, const float* val, double* colsum, double* colnnz, float* row_sum, double* row_lgamma, void* stream) {
+  if (!c || !row_ptr || n_rows < 0) return fail(c, SPMF_E_ARG, "counts_stats: bad arguments");
+  if (n_rows == 0) return SPMF_OK;
+  StatsArgs a{n_rows, row_ptr, col_idx, val, colsum, colnnz, row_sum, row_lgamma};
+  launch_stats(a, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, void* stream) {
+  if (!c || !params || !eta || S < 1) return fail(c, SPMF_E_ARG, "data_pass: bad arguments");
+  if (c->flags & SPMF_FLAG_LOG_TRANSFORM) return fail(c, SPMF_E_UNSUPPORTED, "log_transform has no sparse closed form; use the dense path");
+  int rc = check_counts(c, ct);
+  if (rc) return rc;
+  if (ct->n_rows > 0 && ct->nnz > 0 && (!ct->pc_ptr || !ct->pc_row || !ct->pc_val || ct->n_panels < 1)) return fail(c, SPMF_E_ARG, "counts: panel-CSC arrays missing");
+  for (int i : {0, 1, 2, 7})
+    if (!params[i]) return fail(c, SPMF_E_ARG, "data_pass: params v,w,u,s must be non-null");
+  rc = bind_ws(c, ct->n_rows, S);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int KP = c->KP, D = c->D;
+  const size_t al_ = acc_len(D, KP);
+  // zero acc | dacc | dprep (contiguous in the carve)
+  HIPCHK(c, hipMemsetAsync(c->acc, 0, (size_t)((char*)c->Ap - (char*)c->acc), st));
+  for (int s = 0; s < S; ++s) {
+    const bool tm = c->timing && s == S - 1;
+    float* acc = c->acc + (size_t)s * al_;
+    double* dacc = c->dacc + (size_t)s * (kDaccHead + KP);
+    double* dprep = c->dprep + (size_t)s * (KP + 1);
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep};
+    launch_prep(KP, pa, st);
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    if (ct->n_rows > 0) {
+      RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 0};
+      launch_row_pass(KP, ra, st);
+    }
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    if (ct->n_rows > 0 && ct->nnz > 0) {
+      ColArgs ca{D, ct->n_panels, ct->row_base, ct->pc_ptr, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, acc + (size_t)D * KP, acc + (size_t)2 * D * KP};
+      launch_col_pass(KP, ca, st);
+    }
+    PackArgs pk{KP, dacc, acc + (size_t)2 * D * KP + D};
+    launch_pack(pk, st);
+    if (tm) {
+      HIPCHK(c, hipEventRecord(c->ev[3], st));
+      c->ev_valid = 1;
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_global, double prior_weight, const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS], double* n_nonfinite, void* stream) {
+  if (!c || !params || !grads || !eta || !parts || S < 1) return fail(c, SPMF_E_ARG, "finish: bad arguments");
+  if (!c->acc || c->ws_S < S) return fail(c, SPMF_E_ARG, "finish: no data pass precedes it for this S");
+  for (int i = 0; i < SPMF_NVARS; ++i)
+    if (!params[i] || !grads[i]) return fail(c, SPMF_E_ARG, "finish: all 12 params/grads must be non-null");
+  hipStream_t st = (hipStream_t)stream;
+  const int KP = c->KP, D = c->D;
+  const size_t al_ = acc_len(D, KP);
+  HIPCHK(c, hipMemsetAsync(parts, 0, (size_t)S * SPMF_NPARTS * sizeof(double), st));
+  HIPCHK(c, hipMemsetAsync(grads[4], 0, (size_t)S * c->K * sizeof(float), st));
+  for (int s = 0; s < S; ++s) {
+    const bool tm = c->timing && s == S - 1;
+    const float* P[SPMF_NVARS];
+    float* G[SPMF_NVARS];
+    for (int i = 0; i < SPMF_NVARS; ++i) {
+      P[i] = params[i] + s * var_size(c, i);
+      G[i] = grads[i] + s * var_size(c, i);
+    }
+    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr};
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
+    launch_finish(KP, fa, st);
+    if (tm) {
+      HIPCHK(c, hipEventRecord(c->ev[5], st));
+      c->ev_valid |= 2;
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_elbo_fwd_bwd(spmf_ctx* c, const spmf_counts* ct, int S, double prior_weight, const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS], double* n_nonfinite, void* stream) {
+  int rc = spmf_data_pass(c, ct, S, params, eta, stream);
+  if (rc) return rc;
+  return spmf_finish(c, S, ct->n_rows, ct->lgamma_sum, prior_weight, params, eta, parts, grads, n_nonfinite, stream);
+}
+
+int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* s, const float* eta, float* z_out, void* stream) {
+  if (!c || !u || !s || !eta || !z_out) return fail(c, SPMF_E_ARG, "encode: bad arguments");
+  if (c->flags & SPMF_FLAG_LOG_TRANSFORM) return fail(c, SPMF_E_UNSUPPORTED, "encode: log_transform needs g(x) values; not in the sparse path yet");
+  int rc = check_counts(c, ct);
+  if (rc) return rc;
+  if (ct->n_rows == 0) return SPMF_OK;
+  rc = bind_ws(c, ct->n_rows, 1);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipMemsetAsync(c->dprep, 0, (c->KP + 1) * sizeof(double), st));
+  PrepArgs pa{c->D, c->K, u, nullptr, nullptr, s, eta, c->Ap, c->Vp, c->phi, c->dprep};
+  launch_prep(c->KP, pa, st);
+  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1};
+  launch_row_pass(c->KP, ra, st);
+  HIPCHK(c, hipMemcpy2DAsync(z_out, (size_t)c->K * sizeof(float), c->z, (size_t)c->KP * sizeof(float), (size_t)c->K * sizeof(float), (size_t)ct->n_rows, hipMemcpyDeviceToDevice, st));
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// common.h -- shared device helpers for libspmf_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPMF_WAVE 64
+
+namespace spmf {
+
+constexpr double kHalfLog2OverPi = 0.22579135264472743236;  // 0.5*log(2/pi)
+constexpr double kLgammaHalf = 0.57236494292470008707;      // lgamma(0.5)
+constexpr double kLog2 = 0.69314718055994530942;
+
+// Layout of the fp64 scalar block a data pass accumulates per draw.
+//   [0] sum_nnz x*log r   [1] sum z^2   [2] non-finite stored cells
+//   [3] reserved          [4 .. 4+KP)   sum_b z_b
+constexpr int kDaccHead = 4;
+
+// fp32 accumulator tail: the fp64 scalars as (hi,lo) float pairs.
+__host__ __device__ inline int acc_tail_len(int KP) { return 2 * (kDaccHead + KP); }
+__host__ __device__ inline int64_t acc_len(int D, int KP) {
+  return (int64_t)2 * D * KP + D + acc_tail_len(KP);
+}
+
+__device__ __forceinline__ float4 shfl4(float4 v, int src) {
+  return make_float4(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src), __shfl(v.w, src));
+}
+__device__ __forceinline__ float4 shfl_xor4(float4 v, int m) {
+  return make_float4(__shfl_xor(v.x, m), __shfl_xor(v.y, m), __shfl_xor(v.z, m),
+                     __shfl_xor(v.w, m));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
+  return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z),
+                     fmaf(s, a.w, acc.w));
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// Block-wide fp64 sum of `v`; result valid in thread 0. `red` >= 16 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+}  // namespace spmf

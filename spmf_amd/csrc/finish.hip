@@ -1,0 +1,275 @@
+// finish.hip -- chain rule from the sparse accumulators to d/d(u,v,w,s), the
+// horseshoe-plus prior parts and gradients for all 12 variables, and the 14
+// energy parts (gfx950).
+//
+//   data term:   dA = gA'/eta        du = w1*dA
+//       dv[k,d] = eta_d (gV'[d,k] - sum_b z_b[k])
+//       dphi_d  = gphi_d - B ; dw = eta w2 dphi
+//       ds0 = (GA - Gphi) s1/T^2, ds1 = (Gphi - GA) s0/T^2,
+//       GA_d = sum_k u dA,  Gphi_d = eta w dphi,  T = s0+s1
+//   prior (poisson.py:228-377, tfd.HalfNormal / tfd.InverseGamma and
+//   bayesianquilts SqrtInverseGamma restated):
+//       HalfNormal(sig)(y)      = c0 - log sig - y^2/(2 sig^2)
+//       SqrtInvGamma(1/2,1/a)(y)= -log(a)/2 - lgamma(1/2) - 2 log y - 1/(a y^2) + log 2
+//       InvGamma(1/2,beta)(a)   = log(beta)/2 - lgamma(1/2) - 3/2 log a - beta/a
+//   parts 'x','z' (poisson.py:599-619) from the fp64 scalars in the
+//   accumulator tail and the closed-form sum of the rate over all cells.
+//
+// One block per 64 features; [D,K]-shaped arrays are walked flat (coalesced),
+// the [K,D]-shaped v / dv through an LDS transpose tile.  O(D*K) elementwise
+// work with fp64 block reductions: HBM-bound and tiny next to the nnz passes.
+#include "common.h"
+#include "kernels.h"
+
+namespace spmf {
+
+constexpr int FTD = 64;
+constexpr int SPMF_NPARTS_LOCAL = 12;
+
+struct Ptrs12 {
+  const float* p[12];
+};
+struct MPtrs12 {
+  float* p[12];
+};
+
+enum { V_ = 0, W_, U_, UETA_, UTAU_, SETA_, STAU_, S_, UETAA_, UTAUA_, SETAA_, STAUA_ };
+
+__device__ __forceinline__ double unpack(const float* tail, int i) {
+  return (double)tail[2 * i] + (double)tail[2 * i + 1];
+}
+
+// HalfNormal(sig) at y: log-prob, d/dy, d/dsig
+__device__ __forceinline__ void halfnormal(float y, float sig, float& lp, float& gy, float& gs) {
+  const float is = 1.f / sig;
+  const float q = y * is;
+  lp = (float)kHalfLog2OverPi - logf(sig) - 0.5f * q * q;
+  gy = -q * is;
+  gs = (q * q - 1.f) * is;
+}
+// SqrtInvGamma(1/2, scale=1/a) at y: log-prob, d/dy, d/da
+__device__ __forceinline__ void sqrt_ig(float y, float a, float& lp, float& gy, float& ga) {
+  const float iy = 1.f / y, ia = 1.f / a;
+  const float t = ia * iy * iy;  // 1/(a y^2)
+  lp = -0.5f * logf(a) - (float)kLgammaHalf - 2.f * logf(y) - t + (float)kLog2;
+  gy = -2.f * iy + 2.f * t * iy;
+  ga = -0.5f * ia + t * ia;
+}
+// InvGamma(1/2, beta) at a: log-prob, d/da
+__device__ __forceinline__ void ig_half(float a, float beta, float half_log_beta, float& lp,
+                                        float& ga) {
+  const float ia = 1.f / a;
+  lp = half_log_beta - (float)kLgammaHalf - 1.5f * logf(a) - beta * ia;
+  ga = -1.5f * ia + beta * ia * ia;
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
+                                                     double lgamma_sum, float u_tau_scale,
+                                                     float s_tau_scale, float decay, float pw,
+                                                     const float* __restrict__ acc,
+                                                     const double* __restrict__ dprep, Ptrs12 P,
+                                                     const float* __restrict__ eta, MPtrs12 G,
+                                                     double* __restrict__ parts,
+                                                     double* __restrict__ nnf_out) {
+  __shared__ float tile[KP][FTD + 1];
+  __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
+  __shared__ float zsum_s[KP], utau_s[KP], dec_s[KP], gutau_s[KP];
+  __shared__ double red[16];
+  const int t = threadIdx.x;
+  const int d0 = blockIdx.x * FTD;
+  const float* gAp = acc;
+  const float* gVp = acc + (size_t)D * KP;
+  const float* gph = acc + (size_t)2 * D * KP;
+  const float* tail = gph + D;
+  double part[SPMF_NPARTS_LOCAL];
+#pragma unroll
+  for (int i = 0; i < SPMF_NPARTS_LOCAL; ++i) part[i] = 0.0;
+
+  if (t < KP) {
+    zsum_s[t] = (float)unpack(tail, kDaccHead + t);
+    utau_s[t] = t < K ? P.p[UTAU_][t] : 1.f;
+    dec_s[t] = powf(decay, (float)t);
+    gutau_s[t] = 0.f;
+  }
+  if (t < FTD) {
+    const int d = d0 + t;
+    float w1 = 0.f, e = 1.f;
+    if (d < D) {
+      e = eta[d];
+      const float s0 = P.p[S_][d], s1 = P.p[S_][D + d];
+      w1 = s0 / (s0 + s1);
+    }
+    w1s[t] = w1;
+    etas_[t] = e;
+    ietas[t] = 1.f / e;
+    GAs[t] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- [D,K] arrays: u, u_eta, u_eta_a and gA' ---------------------------
+  constexpr int LW = KP < 64 ? KP : 64;  // lanes sharing one d inside a wave
+  for (int e = t; e < KP * FTD; e += 256) {
+    const int dl = e / KP, k = e % KP;
+    const int d = d0 + dl;
+    float ga_u = 0.f, gut = 0.f;
+    if (d < D && k < K) {
+      const size_t i = (size_t)d * K + k;
+      const float u = P.p[U_][i], ue = P.p[UETA_][i], ua = P.p[UETAA_][i];
+      const float dA = gAp[(size_t)d * KP + k] * ietas[dl];
+      ga_u = u * dA;
+      const float sc = utau_s[k] * dec_s[k];
+      float lp, gy, gs;
+      halfnormal(u, ue * sc, lp, gy, gs);
+      part[U_] += (double)lp;
+      G.p[U_][i] = w1s[dl] * dA + pw * gy;
+      gut = pw * gs * ue * dec_s[k];
+      float lp2, gy2, ga2;
+      sqrt_ig(ue, ua, lp2, gy2, ga2);
+      part[UETA_] += (double)lp2;
+      G.p[UETA_][i] = pw * (gs * sc + gy2);
+      float lp3, ga3;
+      ig_half(ua, 1.f, 0.f, lp3, ga3);
+      part[UETAA_] += (double)lp3;
+      G.p[UETAA_][i] = pw * (ga2 + ga3);
+    }
+    // GA_d = sum_k u*dA : fold over the LW lanes that share d
+#pragma unroll
+    for (int m = 1; m < LW; m <<= 1) ga_u += __shfl_xor(ga_u, m);
+    if ((k % LW) == 0 && d < D) atomicAdd(&GAs[dl], ga_u);
+    if (k < K) atomicAdd(&gutau_s[k], gut);
+  }
+  // ---- v / dv through the transpose tile ---------------------------------
+  for (int e = t; e < KP * FTD; e += 256) {
+    const int dl = e / KP, k = e % KP;
+    const int d = d0 + dl;
+    tile[k][dl] = (d < D) ? (gVp[(size_t)d * KP + k] - zsum_s[k]) * etas_[dl] : 0.f;
+  }
+  __syncthreads();
+  for (int e = t; e < KP * FTD; e += 256) {
+    const int k = e / FTD, dl = e % FTD;
+    const int d = d0 + dl;
+    if (k < K && d < D) {
+      const size_t i = (size_t)k * D + d;
+      const float v = P.p[V_][i];
+      float lp, gy, gs;
+      halfnormal(v, 0.1f, lp, gy, gs);
+      part[V_] += (double)lp;
+      G.p[V_][i] = tile[k][dl] + pw * gy;
+    }
+  }
+  // ---- [.,D] vectors: w, s, s_eta, s_tau, s_eta_a, s_tau_a ---------------
+  if (t < FTD && d0 + t < D) {
+    const int d = d0 + t;
+    const float e = etas_[t];
+    const float s0 = P.p[S_][d], s1 = P.p[S_][D + d], w = P.p[W_][d];
+    const float T = s0 + s1, iT2 = 1.f / (T * T);
+    const float w2 = s1 / T;
+    const float dphi = gph[d] - (float)Bglob;
+    const float GA = GAs[t], Gphi = e * w * dphi;
+    float lp, gy, gs;
+    halfnormal(w, 1.f, lp, gy, gs);
+    part[W_] += (double)lp;
+    G.p[W_][d] = e * w2 * dphi + pw * gy;
+    const float se0 = P.p[SETA_][d], se1 = P.p[SETA_][D + d], stau = P.p[STAU_][d];
+    float lp0, gy0, gs0, lp1, gy1, gs1;
+    halfnormal(s0, se0 * stau, lp0, gy0, gs0);
+    halfnormal(s1, se1 * stau, lp1, gy1, gs1);
+    part[S_] += (double)lp0 + (double)lp1;
+    G.p[S_][d] = (GA - Gphi) * s1 * iT2 + pw * gy0;
+    G.p[S_][D + d] = (Gphi - GA) * s0 * iT2 + pw * gy1;
+    const float sa0 = P.p[SETAA_][d], sa1 = P.p[SETAA_][D + d], sta = P.p[STAUA_][d];
+    float a_lp, a_gy, a_ga, b_lp, b_gy, b_ga, c_lp, c_ga;
+    sqrt_ig(se0, sa0, a_lp, a_gy, a_ga);
+    sqrt_ig(se1, sa1, b_lp, b_gy, b_ga);
+    part[SETA_] += (double)a_lp + (double)b_lp;
+    G.p[SETA_][d] = pw * (gs0 * stau + a_gy);
+    G.p[SETA_][D + d] = pw * (gs1 * stau + b_gy);
+    ig_half(sa0, 1.f, 0.f, c_lp, c_ga);
+    part[SETAA_] += (double)c_lp;
+    G.p[SETAA_][d] = pw * (a_ga + c_ga);
+    ig_half(sa1, 1.f, 0.f, c_lp, c_ga);
+    part[SETAA_] += (double)c_lp;
+    G.p[SETAA_][D + d] = pw * (b_ga + c_ga);
+    sqrt_ig(stau, sta, a_lp, a_gy, a_ga);
+    part[STAU_] += (double)a_lp;
+    G.p[STAU_][d] = pw * (gs0 * se0 + gs1 * se1 + a_gy);
+    const float beta = 1.f / (s_tau_scale * s_tau_scale);
+    ig_half(sta, beta, 0.5f * logf(beta), c_lp, c_ga);
+    part[STAUA_] += (double)c_lp;
+    G.p[STAUA_][d] = pw * (a_ga + c_ga);
+  }
+  __syncthreads();
+  // ---- [1,K] vectors: u_tau, u_tau_a (block 0 adds their own prior) ------
+  if (t < K) {
+    float g = gutau_s[t];
+    if (blockIdx.x == 0) {
+      const float ut = P.p[UTAU_][t], uta = P.p[UTAUA_][t];
+      float lp, gy, ga, lp2, ga2;
+      sqrt_ig(ut, uta, lp, gy, ga);
+      part[UTAU_] += (double)lp;
+      g += pw * gy;
+      const float beta = 1.f / (u_tau_scale * u_tau_scale);
+      ig_half(uta, beta, 0.5f * logf(beta), lp2, ga2);
+      part[UTAUA_] += (double)lp2;
+      G.p[UTAUA_][t] = pw * (ga + ga2);
+    }
+    atomicAdd(&G.p[UTAU_][t], g);  // zeroed by the host before launch
+  }
+  // ---- energy parts ------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const double s = block_sum(part[i], red);
+    if (t == 0 && s != 0.0) atomicAdd(&parts[i], s);
+  }
+  if (blockIdx.x == 0 && t == 0) {
+    const double llx = unpack(tail, 0), zsq = unpack(tail, 1);
+    double sum_r = Bglob * dprep[KP];
+    for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * dprep[k];
+    atomicAdd(&parts[13], llx - lgamma_sum - sum_r);
+    atomicAdd(&parts[12], Bglob * (double)K * kHalfLog2OverPi - 0.5 * zsq);
+    if (nnf_out) *nnf_out = unpack(tail, 2);
+  }
+}
+
+__global__ void pack_kernel(int KP, const double* __restrict__ dacc, float* __restrict__ tail) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < kDaccHead + KP) {
+    const double v = dacc[i];
+    const float hi = (float)v;
+    tail[2 * i] = hi;
+    tail[2 * i + 1] = (float)(v - (double)hi);
+  }
+}
+
+void launch_pack(const PackArgs& a, hipStream_t st) {
+  const int n = kDaccHead + a.KP;
+  hipLaunchKernelGGL(pack_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a.KP, a.dacc, a.tail);
+}
+
+template <int KP>
+static void launch_finish_t(const FinishArgs& a, hipStream_t st) {
+  Ptrs12 P;
+  MPtrs12 G;
+  for (int i = 0; i < 12; ++i) {
+    P.p[i] = a.params[i];
+    G.p[i] = a.grads[i];
+  }
+  const int nb = (a.D + FTD - 1) / FTD;
+  hipLaunchKernelGGL(finish_kernel<KP>, dim3(nb), dim3(256), 0, st, a.D, a.K, (double)a.B_global,
+                     a.lgamma_sum, (float)a.u_tau_scale, (float)a.s_tau_scale, (float)a.decay, (float)a.prior_weight,
+                     a.acc, a.dprep, P, a.eta, G, a.parts, a.n_nonfinite);
+}
+
+void launch_finish(int KP, const FinishArgs& a, hipStream_t st) {
+  switch (KP) {
+    case 4: launch_finish_t<4>(a, st); break;
+    case 8: launch_finish_t<8>(a, st); break;
+    case 16: launch_finish_t<16>(a, st); break;
+    case 32: launch_finish_t<32>(a, st); break;
+    case 64: launch_finish_t<64>(a, st); break;
+    default: break;
+  }
+}
+
+}  // namespace spmf

@@ -1,0 +1,102 @@
+// prep.hip -- per-draw prologue of the sparse data term (gfx950).
+//
+// From one draw of (u, v, w, s) and the column scales eta it forms, in the
+// layouts the row/column passes gather from:
+//   A'[d,k] = w1_d * u[d,k] / eta_d      encoding_matrix (poisson.py:652-666)
+//                                        with g(x)=x/eta (:43) folded in
+//   V'[d,k] = eta_d * v[k,d]             decoding_matrix (:668-678) with
+//                                        f(y)=y*eta (:54) folded in, transposed
+//   phi[d]  = eta_d * w2_d * w[d]        intercept_matrix (:680-701)
+//   veta[k] = sum_d V'[d,k], phisum = sum_d phi[d]   (fp64; closed-form sum
+//                                        of the rate over all B*D cells)
+// with w1 = s0/(s0+s1), w2 = s1/(s0+s1).  Rows are padded to KP floats so a
+// gathered row is a whole number of 16-byte lanes.
+//
+// HBM-bound elementwise + a [K,D]->[D,K] transpose staged through LDS; the
+// arrays are O(D*K) (2.5 MB at D=20k,K=32), i.e. noise next to the nnz
+// passes.
+#include "common.h"
+#include "kernels.h"
+
+namespace spmf {
+
+constexpr int TD = 64;  // columns (features) per block
+
+template <int KP>
+__global__ __launch_bounds__(256) void prep_kernel(int D, int K, const float* __restrict__ u,
+                                                   const float* __restrict__ v,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ s,
+                                                   const float* __restrict__ eta,
+                                                   float* __restrict__ Ap, float* __restrict__ Vp,
+                                                   float* __restrict__ phi,
+                                                   double* __restrict__ dprep) {
+  __shared__ float tile[KP][TD + 1];
+  __shared__ float w1ie[TD], etas[TD];
+  __shared__ double red[16];
+  const int t = threadIdx.x;
+  const int d0 = blockIdx.x * TD;
+  double phi_local = 0.0;
+  if (t < TD) {
+    const int d = d0 + t;
+    float e = 1.f, a = 0.f;
+    if (d < D) {
+      e = eta[d];
+      const float s0 = s[d], s1 = s[D + d];
+      const float T = s0 + s1;
+      a = (s0 / T) / e;
+      const float p = w ? e * (s1 / T) * w[d] : 0.f;
+      phi[d] = p;
+      phi_local = (double)p;
+    }
+    w1ie[t] = a;
+    etas[t] = e;
+  }
+  // stage v[k][d0..d0+63] (coalesced along d) into LDS
+  for (int e = t; e < KP * TD; e += 256) {
+    const int k = e / TD, dl = e % TD;
+    const int d = d0 + dl;
+    tile[k][dl] = (v && k < K && d < D) ? v[(size_t)k * D + d] : 0.f;
+  }
+  __syncthreads();
+  for (int e = t; e < KP * TD; e += 256) {
+    const int dl = e / KP, k = e % KP;
+    const int d = d0 + dl;
+    if (d < D) {
+      const float uv = (k < K) ? u[(size_t)d * K + k] : 0.f;
+      Ap[(size_t)d * KP + k] = uv * w1ie[dl];
+      const float vp = tile[k][dl] * etas[dl];
+      Vp[(size_t)d * KP + k] = vp;
+      tile[k][dl] = vp;  // same thread wrote/reads this cell: no hazard
+    }
+  }
+  __syncthreads();
+  if (t < KP) {
+    double acc = 0.0;
+    for (int dl = 0; dl < TD; ++dl)
+      if (d0 + dl < D) acc += (double)tile[t][dl];
+    atomicAdd(&dprep[t], acc);
+  }
+  const double ps = block_sum(phi_local, red);
+  if (t == 0) atomicAdd(&dprep[KP], ps);
+}
+
+template <int KP>
+static void launch_prep_t(const PrepArgs& a, hipStream_t st) {
+  const int nb = (a.D + TD - 1) / TD;
+  hipLaunchKernelGGL(prep_kernel<KP>, dim3(nb), dim3(256), 0, st, a.D, a.K, a.u, a.v, a.w, a.s,
+                     a.eta, a.Ap, a.Vp, a.phi, a.dprep);
+}
+
+void launch_prep(int KP, const PrepArgs& a, hipStream_t st) {
+  switch (KP) {
+    case 4: launch_prep_t<4>(a, st); break;
+    case 8: launch_prep_t<8>(a, st); break;
+    case 16: launch_prep_t<16>(a, st); break;
+    case 32: launch_prep_t<32>(a, st); break;
+    case 64: launch_prep_t<64>(a, st); break;
+    default: break;
+  }
+}
+
+}  // namespace spmf

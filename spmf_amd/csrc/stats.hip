@@ -1,0 +1,48 @@
+// stats.hip -- one streaming pre-pass over a CSR block (gfx950):
+// compute_scales' column sums and per-column counts of x>0
+// (mederrata_spmf/poisson.py:118-135), the row sums encode() scales by
+// (:645-648) and the parameter-free per-row sums of lgamma(x+1) of the Poisson
+// log-pmf (:178-183).  HBM-bound: 8 B per stored entry read once; column
+// accumulators are fp64 atomics (D is small, contention is spread by the
+// random column pattern).
+#include "common.h"
+#include "kernels.h"
+
+namespace spmf {
+
+__global__ __launch_bounds__(256) void stats_kernel(int64_t B, const int32_t* __restrict__ row_ptr,
+                                                    const int32_t* __restrict__ col,
+                                                    const float* __restrict__ val,
+                                                    double* __restrict__ colsum,
+                                                    double* __restrict__ colnnz,
+                                                    float* __restrict__ row_sum,
+                                                    double* __restrict__ row_lgamma) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = wave; b < B; b += nwaves) {
+    const int start = row_ptr[b], end = row_ptr[b + 1];
+    double rs = 0.0, lg = 0.0;
+    for (int i = start + lane; i < end; i += 64) {
+      const float x = val[i];
+      const int c = col[i];
+      rs += (double)x;
+      if (colsum) atomicAdd(&colsum[c], (double)x);
+      if (colnnz && x > 0.f) atomicAdd(&colnnz[c], 1.0);
+      lg += lgamma((double)x + 1.0);
+    }
+    rs = wave_sum(rs);
+    lg = wave_sum(lg);
+    if (lane == 0 && row_sum) row_sum[b] = (float)rs;
+    if (lane == 0 && row_lgamma) row_lgamma[b] = lg;
+  }
+}
+
+void launch_stats(const StatsArgs& a, hipStream_t st) {
+  int64_t want = (a.B + 3) / 4;
+  int nb = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  hipLaunchKernelGGL(stats_kernel, dim3(nb), dim3(256), 0, st, a.B, a.row_ptr, a.col, a.val,
+                     a.colsum, a.colnnz, a.row_sum, a.row_lgamma);
+}
+
+}  // namespace spmf

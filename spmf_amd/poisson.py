@@ -1,0 +1,441 @@
+"""PoissonFactorization -- host-side mirror of the reference class surface
+(mederrata_spmf/poisson.py:25-718) over the HIP hot path.
+
+Only the energy path is re-implemented: ``unormalized_log_prob_parts`` and
+its gradient run as hand-written HIP kernels behind the C-ABI of
+``libspmf_hip.so`` (include/spmf_hip.h).  This module is argument plumbing:
+it keeps the reference's names, argument meaning and error behaviour, owns
+the torch tensors used as device storage and hands raw pointers to ctypes.
+There is no CPU fallback; without the library / a GPU the energy raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PART_ORDER, VAR_ORDER, SpmfError
+from .sparse import DEFAULT_PANEL_ROWS, SparseCounts
+
+
+def var_shapes(D: int, K: int) -> Dict[str, tuple]:
+    """Event shapes of the 12 latent variables (poisson.py:228-377)."""
+    return {
+        "v": (K, D), "w": (1, D), "u": (D, K),
+        "u_eta": (D, K), "u_tau": (1, K),
+        "s_eta": (2, D), "s_tau": (1, D), "s": (2, D),
+        "u_eta_a": (D, K), "u_tau_a": (1, K),
+        "s_eta_a": (2, D), "s_tau_a": (1, D),
+    }
+
+
+class PoissonFactorization:
+    """Sparse (horseshoe) poisson matrix factorization  (poisson.py:25-29).
+
+    Constructor keywords are the reference's (poisson.py:56-64), including the
+    ``horshoe_plus`` spelling.  ``device`` and ``panel_rows`` are additions.
+    """
+    bijectors = None
+    var_list = []
+    s_tau_scale = 1
+
+    def __init__(
+            self,
+            latent_dim=None, feature_dim=None,
+            u_tau_scale=0.01, s_tau_scale=1., symmetry_breaking_decay=0.99,
+            strategy=None, encoder_function=None, decoder_function=None,
+            scale_columns=True, scale_rows=True, log_transform=False,
+            horshoe_plus=True, column_norms=None, count_key='counts',
+            initialize_distributions=True,
+            dtype=torch.float64, device=None, panel_rows=DEFAULT_PANEL_ROWS,
+            **kwargs):
+        if encoder_function is not None or decoder_function is not None:
+            # poisson.py:94-97 lets callers swap g/f; the kernels only know
+            # the two built-in pairs.
+            raise NotImplementedError(
+                "custom encoder_function/decoder_function are not supported by "
+                "the HIP path (only x/eta and log(x/eta+1) are built in)")
+        if not horshoe_plus:
+            raise NotImplementedError(
+                "horshoe_plus=False (AbsHorseshoe prior, poisson.py:378-398) "
+                "is not implemented in the HIP path")
+        self.strategy = strategy
+        self.scale_rows = scale_rows
+        self.scale_columns = scale_columns
+        self.horseshoe_plus = horshoe_plus
+        self.eta_i = 1.
+        self.xi_u_global = 1.
+        if column_norms is not None:
+            self.eta_i = column_norms
+        self.count_key = count_key
+        self.dtype = dtype
+        self.symmetry_breaking_decay = symmetry_breaking_decay
+        self.log_transform = log_transform
+        self.feature_dim = feature_dim
+        self.latent_dim = self.feature_dim if latent_dim is None else latent_dim
+        self.u_tau_scale = u_tau_scale
+        self.s_tau_scale = s_tau_scale
+        self.panel_rows = panel_rows
+        self.device = torch.device(
+            device if device is not None else
+            ("cuda" if torch.cuda.is_available() else "cpu"))
+        self._ctx = None
+        self._ws = None
+        self._eta_dev = None
+        self._eta_key = None
+        self._batch_cache = {}
+        self.calibrated_expectations = {}
+        self.surrogate_distribution = None
+        self.surrogate_vars = []
+        if initialize_distributions:
+            self.create_distributions()
+        print(
+            f"Feature dim: {self.feature_dim} -> Latent dim {self.latent_dim}")
+
+    # ------------------------------------------------------------------
+    # native context
+    # ------------------------------------------------------------------
+    def _handle(self):
+        if self._ctx is None:
+            if self.device.type != "cuda":
+                raise SpmfError(
+                    "the HIP hot path needs a GPU device (no CPU fallback)")
+            lib = _lib.load()
+            flags = (_lib.FLAG_SCALE_ROWS if self.scale_rows else 0) | (
+                _lib.FLAG_LOG_TRANSFORM if self.log_transform else 0)
+            h = C.c_void_p()
+            rc = lib.spmf_ctx_create(self.device.index or 0, int(self.latent_dim),
+                                     int(self.feature_dim), flags, C.byref(h))
+            if rc != 0:
+                raise SpmfError(
+                    f"spmf_ctx_create failed (rc={rc}); latent_dim must be in "
+                    f"1..64, got K={self.latent_dim}, D={self.feature_dim}")
+            self._ctx = h
+            _lib.check(h, lib.spmf_ctx_set_prior(
+                h, float(self.u_tau_scale), float(self.s_tau_scale),
+                float(self.symmetry_breaking_decay)), "spmf_ctx_set_prior")
+        return self._ctx
+
+    def __del__(self):
+        try:
+            if self._ctx is not None:
+                _lib.load().spmf_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def _ensure_workspace(self, rows, S):
+        lib, h = _lib.load(), self._handle()
+        need = lib.spmf_workspace_bytes(h, int(rows), int(S))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            base = self._ws.data_ptr()
+            off = (-base) % 256
+            self._ws_ptr = base + off
+            _lib.check(h, lib.spmf_ctx_set_workspace(h, self._ws_ptr, self._ws.numel() - off),
+                       "spmf_ctx_set_workspace")
+
+    def _eta_device(self):
+        """eta_i as a [D] fp32 device vector (ones when unscaled)."""
+        e = self.eta_i
+        key = id(e) if not isinstance(e, (int, float)) else float(e)
+        if self._eta_key != key or self._eta_dev is None:
+            D = self.feature_dim
+            if isinstance(e, (int, float)):
+                t = torch.full((D,), float(e), dtype=torch.float32, device=self.device)
+            else:
+                if hasattr(e, "numpy") and not isinstance(e, torch.Tensor):
+                    e = e.numpy()
+                t = torch.as_tensor(np.asarray(e.cpu() if isinstance(e, torch.Tensor) else e,
+                                               dtype=np.float64)).reshape(-1)
+                if t.numel() == 1:
+                    t = t.expand(D)
+                t = t.to(torch.float32).to(self.device).contiguous()
+            self._eta_dev, self._eta_key = t, key
+        return self._eta_dev
+
+    # ------------------------------------------------------------------
+    # data plumbing
+    # ------------------------------------------------------------------
+    def _counts(self, data) -> SparseCounts:
+        x = data[self.count_key] if isinstance(data, dict) else data
+        if isinstance(x, SparseCounts):
+            sc = x
+        else:
+            ck = id(x)
+            hit = self._batch_cache.get(ck)
+            if hit is not None and hit[0] is x:
+                sc = hit[1]
+            else:
+                sc = SparseCounts.from_any(x, self.device, self.panel_rows)
+                self._batch_cache = {ck: (x, sc)}   # keep only the latest
+        if sc.n_cols != self.feature_dim:
+            raise ValueError(
+                f"counts have {sc.n_cols} features, model has {self.feature_dim}")
+        if sc.row_sum is None:
+            sc.compute_stats(self._handle())
+        sc.set_row_scale(float(self.xi_u_global), self.scale_rows)
+        return sc
+
+    def _batch(self, data):
+        """-> (SparseCounts, spmf_counts struct) for a batch dict.  A batch may
+        carry ``'panels': (p0, p1)`` to select a panel range of a resident
+        shard (minibatching without re-sorting)."""
+        sc = self._counts(data)
+        pr = data.get("panels") if isinstance(data, dict) else None
+        key = (pr, sc._xi_key)
+        cache = sc.__dict__.setdefault("_struct_cache", {})
+        if key not in cache:
+            cache[key] = sc.batch_struct(*(pr or (0, None)))
+        return sc, cache[key]
+
+    def _pack_params(self, params, names=VAR_ORDER):
+        """dict name -> tensor  =>  (S, {name: contiguous fp32 [S,*shape]})."""
+        D, K = self.feature_dim, self.latent_dim
+        shapes = var_shapes(D, K)
+        out, S = {}, None
+        for n in names:
+            if n not in params:
+                raise KeyError(f"missing parameter '{n}'")
+            t = params[n]
+            if not isinstance(t, torch.Tensor):
+                t = torch.as_tensor(np.asarray(t))
+            t = t.to(device=self.device, dtype=torch.float32)
+            if t.dim() == len(shapes[n]):
+                t = t.unsqueeze(0)
+            if tuple(t.shape[1:]) != shapes[n]:
+                raise ValueError(f"parameter '{n}' has shape {tuple(t.shape)}, "
+                                 f"expected [S,{shapes[n]}]")
+            if S is None:
+                S = t.shape[0]
+            elif t.shape[0] != S:
+                raise ValueError("all parameters must share the sample axis")
+            out[n] = t.contiguous()
+        return S, out
+
+    # ------------------------------------------------------------------
+    # the hot path
+    # ------------------------------------------------------------------
+    def energy_and_grads(self, data, params, all_reduce=None, prior_weight=1.0):
+        """All 14 energy parts (poisson.py:582-621) and d(sum of parts)/d(param)
+        for every one of the 12 variables, for S draws, on the GPU.
+
+        Returns ``(parts, grads, n_nonfinite)``: dict name -> [S] float64,
+        dict name -> [S,*shape] float32 (gradient of x + z + prior_weight *
+        prior parts), [S] float64.  ``all_reduce`` (optional
+        callable taking the packed fp32 accumulator tensor) is invoked between
+        the data pass and the finish kernel -- the single collective of the
+        row-sharded multi-GPU path; it must also return the global
+        (rows, lgamma_sum) via its return value or None for single shard.
+        """
+        if self.log_transform:
+            raise NotImplementedError(
+                "log_transform=True has no sparse closed form (SURVEY 8a row 8); "
+                "the dense HIP path is not built yet")
+        lib, h = _lib.load(), self._handle()
+        sc, cs = self._batch(data)
+        S, P = self._pack_params(params)
+        self._ensure_workspace(cs.n_rows, S)
+        eta = self._eta_device()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        pin = _lib.PtrArray(*[P[n].data_ptr() for n in VAR_ORDER])
+        grads = {n: torch.empty_like(P[n]) for n in VAR_ORDER}
+        gout = _lib.PtrArray(*[grads[n].data_ptr() for n in VAR_ORDER])
+        parts = torch.empty(S, _lib.NPARTS, dtype=torch.float64, device=self.device)
+        nnf = torch.empty(S, dtype=torch.float64, device=self.device)
+        _lib.check(h, lib.spmf_data_pass(h, C.byref(cs), S, pin, eta.data_ptr(), stream),
+                   "spmf_data_pass")
+        rows_g, lg_g = cs.n_rows, cs.lgamma_sum
+        if all_reduce is not None:
+            n = lib.spmf_acc_len(h, S)
+            acc = _wrap_f32(lib.spmf_acc_ptr(h), n, self.device, self._ws)
+            r = all_reduce(acc, cs.n_rows, cs.lgamma_sum)
+            if r is not None:
+                rows_g, lg_g = r
+        _lib.check(h, lib.spmf_finish(h, S, int(rows_g), float(lg_g), float(prior_weight), pin, eta.data_ptr(),
+                                      parts.data_ptr(), gout, nnf.data_ptr(), stream),
+                   "spmf_finish")
+        pd = {n: parts[:, i] for i, n in enumerate(PART_ORDER)}
+        return pd, grads, nnf
+
+    def unormalized_log_prob_parts(self, data, prior_weight=1., **params):
+        """Energy function (poisson.py:582-621): dict of [S] tensors keyed
+        v,w,u,...,z,x.  Raises if a stored cell has a non-finite log-pmf: the
+        sparse fast path covers the case where the clip/replace rule
+        (:606-616) is the identity."""
+        squeeze = params["u"].dim() == 2 if isinstance(params.get("u"), torch.Tensor) \
+            else np.ndim(params["u"]) == 2
+        parts, _, nnf = self.energy_and_grads(data, params)
+        if float(nnf.sum()) != 0.0:
+            raise FloatingPointError(
+                f"{int(nnf.sum())} stored cells have a non-finite Poisson log-pmf; "
+                "the non-finite replacement rule (poisson.py:606-616) needs the "
+                "dense path")
+        out = {}
+        for k, v in parts.items():
+            if k not in ("x", "z"):
+                v = v * prior_weight                       # poisson.py:591
+            out[k] = v[0] if squeeze else v
+        return out
+
+    def unormalized_log_prob(self, data=None, prior_weight=1., **params):
+        """poisson.py:575-580 -- NB: like the reference this ignores
+        ``prior_weight`` and sums the parts with weight 1 (:577)."""
+        prob_parts = self.unormalized_log_prob_parts(data, prior_weight=1., **params)
+        return sum(prob_parts.values())
+
+    def unormalized_log_prob_list(self, *x, data=None):
+        """poisson.py:703-709: positional wrapper in var_list order."""
+        return self.unormalized_log_prob(
+            data=data, **{v: t for v, t in zip(self.var_list, x)})
+
+    # ------------------------------------------------------------------
+    # small O(D*K) helpers (plain tensor algebra, not on the hot path)
+    # ------------------------------------------------------------------
+    def _expect(self, name, value):
+        if value is not None:
+            return value if isinstance(value, torch.Tensor) else torch.as_tensor(
+                np.asarray(value), device=self.device)
+        if name not in self.calibrated_expectations:
+            raise KeyError(
+                f"no calibrated expectation for '{name}': fit the model or pass it")
+        return self.calibrated_expectations[name]
+
+    def encoding_matrix(self, u=None, s=None):
+        """Output A = (alpha_ik)  (poisson.py:652-666): batch_shape x I x K"""
+        u = self._expect("u", u)
+        s = self._expect("s", s)
+        weights = s / s.sum(-2, keepdim=True)
+        return weights[..., 0, :].unsqueeze(-1) * u
+
+    def decoding_matrix(self, v=None):
+        """Output B = (beta_ki)  (poisson.py:668-678)"""
+        return self._expect("v", v)
+
+    def intercept_matrix(self, w=None, s=None):
+        """export phi  (poisson.py:680-701): batch_shape x 1 x I"""
+        w = self._expect("w", w)
+        s = self._expect("s", s)
+        weights = s / s.sum(-2, keepdim=True)
+        eta = self._eta_device().to(w.dtype)
+        return eta * weights[..., 1, :].unsqueeze(-2) * w
+
+    def encode(self, x, u=None, s=None):
+        """Returns theta given x (poisson.py:623-650), [B,K] (or [S,B,K])."""
+        u = self._expect("u", u).to(self.device, torch.float32)
+        s = self._expect("s", s).to(self.device, torch.float32)
+        lib, h = _lib.load(), self._handle()
+        sc, cs = self._batch(x if isinstance(x, dict) else {self.count_key: x})
+        single = u.dim() == 2
+        if single:
+            u, s = u.unsqueeze(0), s.unsqueeze(0)
+        self._ensure_workspace(cs.n_rows, 1)
+        eta = self._eta_device()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        out = torch.empty(u.shape[0], cs.n_rows, self.latent_dim,
+                          dtype=torch.float32, device=self.device)
+        for i in range(u.shape[0]):
+            ui, si = u[i].contiguous(), s[i].contiguous()
+            _lib.check(h, lib.spmf_encode(h, C.byref(cs), ui.data_ptr(), si.data_ptr(),
+                                          eta.data_ptr(), out[i].data_ptr(), stream),
+                       "spmf_encode")
+        return out[0] if single else out
+
+    # ------------------------------------------------------------------
+    # compute_scales (poisson.py:113-154)
+    # ------------------------------------------------------------------
+    def compute_scales(self, data_factory, compute_normalization=True, n=None):
+        if self.scale_columns and compute_normalization:
+            print("Looping through the entire dataset once to get some stats")
+            D = self.feature_dim
+            colsum = torch.zeros(D, dtype=torch.float64, device=self.device)
+            colnnz = torch.zeros(D, dtype=torch.float64, device=self.device)
+            N = 0
+            h = self._handle()
+            for batch in iter(data_factory()):
+                x = batch[self.count_key] if isinstance(batch, dict) else batch
+                sc = SparseCounts.from_any(x, self.device, self.panel_rows)
+                sc.compute_stats(h, colsum, colnnz)
+                N += sc.n_rows
+            colmeans_nonzero = colsum / colnnz          # NaN for empty columns
+            # poisson.py:139-140 sums NaNs into xi for an empty column; the
+            # build defines xi over the non-empty columns.
+            rowmean_nonzero = torch.nansum(colmeans_nonzero)
+            self.eta_i = torch.where(colmeans_nonzero > 1, colmeans_nonzero,
+                                     torch.ones_like(colmeans_nonzero)).reshape(1, D)
+            if self.scale_rows:
+                self.xi_u_global = float(rowmean_nonzero)
+            else:
+                self.xi_u_global = 1.
+
+    # ------------------------------------------------------------------
+    # distributions / driver hooks live in vi.py
+    # ------------------------------------------------------------------
+    def create_distributions(self):
+        """poisson.py:212-573: bijectors, var_list and the surrogate posterior
+        (initial values :403-539).  The prior itself lives in the finish
+        kernel."""
+        from .vi import Surrogate
+        self.bijectors = {n: "softplus" for n in VAR_ORDER}
+        self.surrogate_distribution = Surrogate(self)
+        self.surrogate_vars = self.surrogate_distribution.variables
+        self.var_list = list(VAR_ORDER)
+        self.set_calibration_expectations()
+
+    def set_calibration_expectations(self, samples=32):
+        self.calibrated_expectations = \
+            self.surrogate_distribution.expectations(samples)
+
+    def reconstitute(self, state):
+        """poisson.py:711-717: rebuild, then assign surrogate variables BY
+        POSITION (the ordering is part of the pickle format)."""
+        self.create_distributions()
+        for j, value in enumerate(state['surrogate_vars']):
+            self.surrogate_distribution.trainable_variables[j].copy_(
+                torch.as_tensor(np.asarray(value)).to(
+                    self.surrogate_distribution.trainable_variables[j]))
+
+    # fit / calibrate_advi / save / waic are attached in vi.py
+    def fit(self, *args, **kwargs):
+        from .vi import fit
+        return fit(self, *args, **kwargs)
+
+    def calibrate_advi(self, *args, **kwargs):
+        from .vi import calibrate_advi
+        return calibrate_advi(self, *args, **kwargs)
+
+    def save(self, filename):
+        from .vi import save_model
+        return save_model(self, filename)
+
+
+def _wrap_f32(ptr, n, device, owner):
+    """View n floats at device address ``ptr`` (inside ``owner``'s storage) as
+    a torch tensor without copying."""
+    base = owner.data_ptr()
+    off = ptr - base
+    assert off >= 0 and off % 4 == 0
+    return owner[off:off + 4 * n].view(torch.float32)
+
+
+class PoissonMatrixFactorization(PoissonFactorization):
+    """Legacy name/constructor used by bin/factorize_csv.py:114-119, the scRNA
+    script and every notebook: first positional argument is the (batched)
+    dataset; feature_dim is inferred from it; unknown legacy keywords
+    (scale_rates, with_s, encoder, decoder, ...) are swallowed."""
+
+    def __init__(self, data=None, latent_dim=None, **kwargs):
+        for legacy in ("scale_rates", "with_s", "encoder", "decoder",
+                       "fn", "fn_inverse", "auxiliary_horseshoe"):
+            kwargs.pop(legacy, None)
+        feature_dim = kwargs.pop("feature_dim", None)
+        self.data = data
+        if feature_dim is None and data is not None:
+            first = next(iter(data() if callable(data) else data))
+            x = first[kwargs.get("count_key", "counts")] if isinstance(first, dict) else first
+            feature_dim = x.n_cols if isinstance(x, SparseCounts) else x.shape[-1]
+        super().__init__(latent_dim=latent_dim, feature_dim=feature_dim, **kwargs)

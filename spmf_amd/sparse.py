@@ -1,0 +1,191 @@
+"""Device-resident sparse count matrix for the HIP path.
+
+The reference feeds dense ``[B, D]`` tensors under ``data[count_key]``
+(mederrata_spmf/poisson.py:170,182; tests/spmf_test.py:17-22).  For the
+linear decoder the energy only needs the stored entries, so
+the HIP path keeps one shard of the matrix as
+
+  * row-major CSR   ``row_ptr[N+1] int32, col_idx[nnz] int32, val[nnz] f32``
+  * panel-CSC       for each panel of ``panel_rows`` consecutive rows a CSC of
+                    that panel: ``pc_ptr[n_panels*(D+1)]``, ``pc_row``, ``pc_val``
+  * per-row         ``row_sum`` (f32), ``row_lgamma`` = sum lgamma(x+1) (f64)
+
+A *batch* is a contiguous range of panels, so minibatching never re-sorts.
+torch is storage + one-time layout plumbing (sort/cumsum at build time); the
+per-row statistics come from the HIP pre-pass kernel ``spmf_counts_stats``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DEFAULT_PANEL_ROWS = 8192
+
+
+def _as_csr_arrays(x):
+    """Accept scipy CSR, (indptr, indices, data), dense ndarray / tensor."""
+    try:
+        import scipy.sparse as sp
+        if sp.issparse(x):
+            x = x.tocsr()
+            x.sum_duplicates()
+            return (np.asarray(x.indptr), np.asarray(x.indices),
+                    np.asarray(x.data), x.shape)
+    except ImportError:  # pragma: no cover
+        pass
+    if isinstance(x, (tuple, list)) and len(x) == 4:
+        return x
+    return None
+
+
+class SparseCounts:
+    """One row shard of the count matrix in the layout the kernels read."""
+
+    def __init__(self, row_ptr, col_idx, val, n_rows, n_cols,
+                 panel_rows=DEFAULT_PANEL_ROWS):
+        dev = val.device
+        self.device = dev
+        self.n_rows = int(n_rows)
+        self.n_cols = int(n_cols)
+        self.row_ptr = row_ptr.to(torch.int32).contiguous()
+        self.col_idx = col_idx.to(torch.int32).contiguous()
+        self.val = val.to(torch.float32).contiguous()
+        self.nnz = int(self.val.numel())
+        if self.nnz >= 2 ** 31:
+            raise ValueError("nnz per shard must fit int32")
+        self.panel_rows = int(max(1, min(panel_rows, max(self.n_rows, 1))))
+        self.n_panels = max(1, -(-self.n_rows // self.panel_rows))
+        self._build_panel_csc()
+        self.row_sum = None
+        self.row_lgamma = None
+        self.row_scale = None      # xi_b, set by PoissonFactorization
+        self._xi_key = None
+        self._keep = []
+
+    # ---- construction ----------------------------------------------------
+    @classmethod
+    def from_any(cls, x, device=None, panel_rows=DEFAULT_PANEL_ROWS):
+        if isinstance(x, SparseCounts):
+            return x
+        device = torch.device(device if device is not None else
+                              ("cuda" if torch.cuda.is_available() else "cpu"))
+        csr = _as_csr_arrays(x)
+        if csr is not None:
+            indptr, indices, data, shape = csr
+            return cls(torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(device),
+                       torch.as_tensor(np.asarray(indices, dtype=np.int64)).to(device),
+                       torch.as_tensor(np.asarray(data, dtype=np.float32)).to(device),
+                       shape[0], shape[1], panel_rows)
+        return cls.from_dense(x, device, panel_rows)
+
+    @classmethod
+    def from_dense(cls, x, device=None, panel_rows=DEFAULT_PANEL_ROWS):
+        device = torch.device(device if device is not None else
+                              ("cuda" if torch.cuda.is_available() else "cpu"))
+        if hasattr(x, "numpy") and not isinstance(x, torch.Tensor):
+            x = x.numpy()
+        t = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x)
+        t = t.to(device)
+        if t.dim() != 2:
+            raise ValueError("counts must be [rows, features]")
+        N, D = t.shape
+        mask = t != 0
+        counts = mask.sum(1)
+        row_ptr = torch.zeros(N + 1, dtype=torch.int64, device=device)
+        row_ptr[1:] = torch.cumsum(counts, 0)
+        nz = mask.nonzero(as_tuple=False)      # row-major order
+        col = nz[:, 1]
+        val = t[mask].to(torch.float32)
+        return cls(row_ptr, col, val, N, D, panel_rows)
+
+    def _build_panel_csc(self):
+        dev, N, D, P = self.device, self.n_rows, self.n_cols, self.panel_rows
+        nP = self.n_panels
+        lens = (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int64), lens)
+        key = (rows // P) * D + self.col_idx.to(torch.int64)
+        # stable: ties keep CSR (ascending row) order -> deterministic lists
+        order = torch.sort(key, stable=True).indices
+        self.pc_row = rows[order].to(torch.int32).contiguous()
+        self.pc_val = self.val[order].contiguous()
+        cnt = torch.bincount(key, minlength=nP * D)
+        excl = torch.zeros(nP * D + 1, dtype=torch.int64, device=dev)
+        excl[1:] = torch.cumsum(cnt, 0)
+        ptr = torch.empty(nP, D + 1, dtype=torch.int64, device=dev)
+        ptr[:, :D] = excl[:-1].view(nP, D)
+        ptr[:, D] = excl[D::D]
+        self.pc_ptr = ptr.to(torch.int32).contiguous().view(-1)
+
+    # ---- statistics (HIP pre-pass) ---------------------------------------
+    def compute_stats(self, ctx_handle, colsum=None, colnnz=None):
+        """row_sum / row_lgamma via spmf_counts_stats; optionally accumulate
+        compute_scales' column sums (poisson.py:118-135) into colsum/colnnz
+        (float64 device tensors of length D)."""
+        lib = _lib.load()
+        if self.device.type != "cuda":
+            raise _lib.SpmfError("SparseCounts statistics need the HIP device")
+        self.row_sum = torch.empty(self.n_rows, dtype=torch.float32, device=self.device)
+        self.row_lgamma = torch.empty(self.n_rows, dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.spmf_counts_stats(
+            ctx_handle, self.n_rows, self.row_ptr.data_ptr(), self.col_idx.data_ptr(),
+            self.val.data_ptr(),
+            colsum.data_ptr() if colsum is not None else None,
+            colnnz.data_ptr() if colnnz is not None else None,
+            self.row_sum.data_ptr(), self.row_lgamma.data_ptr(), stream)
+        _lib.check(ctx_handle, rc, "spmf_counts_stats")
+
+    def set_row_scale(self, xi_u_global, scale_rows):
+        """xi_b = rowsum_b / xi_u_global (poisson.py:644-649)."""
+        key = (float(xi_u_global), bool(scale_rows))
+        if key == self._xi_key:
+            return
+        if scale_rows:
+            self.row_scale = (self.row_sum / float(xi_u_global)).contiguous()
+        else:
+            self.row_scale = None
+        self._xi_key = key
+
+    # ---- batches ---------------------------------------------------------
+    def n_batches(self, batch_rows):
+        ppb = max(1, batch_rows // self.panel_rows)
+        return -(-self.n_panels // ppb)
+
+    def batch_struct(self, p0=0, p1=None):
+        """spmf_counts descriptor of panels [p0, p1)."""
+        p1 = self.n_panels if p1 is None else min(p1, self.n_panels)
+        r0 = p0 * self.panel_rows
+        r1 = min(p1 * self.panel_rows, self.n_rows)
+        cs = _lib.CountsStruct()
+        cs.n_rows = r1 - r0
+        lo = int(self.row_ptr[r0]) if self.nnz else 0
+        hi = int(self.row_ptr[r1]) if self.nnz else 0
+        cs.nnz = hi - lo
+        cs.n_cols = self.n_cols
+        cs.n_panels = p1 - p0
+        cs.panel_rows = self.panel_rows
+        cs.row_base = r0
+        cs.row_ptr = self.row_ptr.data_ptr() + 4 * r0
+        cs.col_idx = self.col_idx.data_ptr()
+        cs.val = self.val.data_ptr()
+        cs.row_scale = (self.row_scale.data_ptr() + 4 * r0
+                        if self.row_scale is not None else None)
+        cs.pc_ptr = self.pc_ptr.data_ptr() + 4 * p0 * (self.n_cols + 1)
+        cs.pc_row = self.pc_row.data_ptr()
+        cs.pc_val = self.pc_val.data_ptr()
+        cs.lgamma_sum = (float(self.row_lgamma[r0:r1].sum())
+                         if self.row_lgamma is not None else 0.0)
+        return cs
+
+    def to_dense(self):
+        out = torch.zeros(self.n_rows, self.n_cols, dtype=torch.float32, device=self.device)
+        lens = (self.row_ptr[1:] - self.row_ptr[:-1]).to(torch.int64)
+        rows = torch.repeat_interleave(
+            torch.arange(self.n_rows, device=self.device), lens)
+        out[rows, self.col_idx.to(torch.int64)] = self.val
+        return out

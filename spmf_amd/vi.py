@@ -1,0 +1,292 @@
+"""Minimal VI driver -- the build's counterpart of the out-of-tree caller of
+the hot path (bayesianquilts' BayesianModel.fit / legacy calibrate_advi;
+call sites tests/spmf_test.py:35-43 and bin/factorize_csv.py:121-124).
+
+[UNVERIFIED-3P] bayesianquilts is an un-vendored, un-pinned dependency, so
+its exact loss scaling / plateau logic cannot be mirrored; this module
+DEFINES:
+
+    loss = - mean_S [ LL_x + logp_z + (B/N) (logp_prior - log q) ] / B
+
+with the raw parts available from ``PoissonFactorization.energy_and_grads``.
+The surrogate is the reference's (poisson.py:403-539): Softplus(Normal) for
+u, v, w, s and Softplus(InverseGamma) for the scale hierarchy; positive
+distribution parameters are softplus(raw) trainables.
+
+Sampling, log q and the reparameterisation chain are plain torch autograd
+(driver plumbing); the energy and its gradient wrt the sampled parameters
+are the HIP hot path.
+"""
+from __future__ import annotations
+
+import math
+import os
+import uuid
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from ._lib import VAR_ORDER
+
+_sp = torch.nn.functional.softplus
+
+
+def softplus_inverse(y):
+    y = np.asarray(y, dtype=np.float64)
+    return y + np.log(-np.expm1(-y))
+
+
+def _initial_state(D, K, u_tau_scale, s_tau_scale):
+    """(kind, constrained initial parameters) per variable, poisson.py:403-539."""
+    from .poisson import var_shapes
+    sh = var_shapes(D, K)
+    one = lambda n: np.ones(sh[n])
+    return {
+        "v": ("normal", -6.0 * one("v"), 5e-4 * one("v")),
+        "w": ("normal", -6.0 * one("w"), 5e-4 * one("w")),
+        "u": ("normal", -6.0 * one("u"), 5e-4 * one("u")),
+        "u_eta": ("invgamma", 3.0 * one("u_eta"), one("u_eta")),
+        "u_tau": ("invgamma", 3.0 * one("u_tau"), one("u_tau")),
+        "s_eta": ("invgamma", one("s_eta"), one("s_eta")),
+        "s_tau": ("invgamma", one("s_tau"), one("s_tau")),
+        "s": ("normal", one("s") * np.array([[-2.0], [-1.0]]), 1e-3 * one("s")),
+        "u_eta_a": ("invgamma", 2.0 * one("u_eta_a"), one("u_eta_a")),
+        "u_tau_a": ("invgamma", 2.0 * one("u_tau_a"), one("u_tau_a") / u_tau_scale ** 2),
+        "s_eta_a": ("invgamma", 2.0 * one("s_eta_a"), one("s_eta_a")),
+        "s_tau_a": ("invgamma", 2.0 * one("s_tau_a"), one("s_tau_a") / s_tau_scale ** 2),
+    }
+
+
+class Surrogate:
+    """Mean-field surrogate posterior, poisson.py:403-569.  Trainables are kept
+    in the reference's order (two per variable, VAR_ORDER) because
+    ``reconstitute`` assigns them by position (poisson.py:711-717)."""
+
+    def __init__(self, model):
+        D, K = model.feature_dim, model.latent_dim
+        dev = model.device
+        self.device = dev
+        self.kinds: Dict[str, str] = {}
+        self.trainable_variables: List[torch.Tensor] = []
+        self._index = {}
+        init = _initial_state(D, K, model.u_tau_scale, model.s_tau_scale)
+        for n in VAR_ORDER:
+            kind, a, b = init[n]
+            self.kinds[n] = kind
+            if kind == "normal":
+                t0, t1 = a, softplus_inverse(b)                 # loc, raw scale
+            else:
+                t0, t1 = softplus_inverse(a), softplus_inverse(b)  # raw conc, raw scale
+            self._index[n] = len(self.trainable_variables)
+            for t in (t0, t1):
+                self.trainable_variables.append(
+                    torch.tensor(t, dtype=torch.float32, device=dev, requires_grad=True))
+
+    @property
+    def variables(self):
+        return self.trainable_variables
+
+    def params_of(self, n):
+        i = self._index[n]
+        return self.trainable_variables[i], self.trainable_variables[i + 1]
+
+    def rsample(self, S, generator=None):
+        """-> (theta: name -> [S,*shape] with autograd graph, logq [S])."""
+        theta, logq = {}, 0.0
+        for n in VAR_ORDER:
+            t0, t1 = self.params_of(n)
+            shape = (S,) + tuple(t0.shape)
+            if self.kinds[n] == "normal":
+                sigma = _sp(t1)
+                eps = torch.randn(shape, device=self.device, dtype=torch.float32,
+                                  generator=generator)
+                y = t0 + sigma * eps
+                lq = -0.5 * eps ** 2 - torch.log(sigma) - 0.5 * math.log(2 * math.pi)
+            else:
+                a, b = _sp(t0), _sp(t1)
+                g = torch._standard_gamma(a.expand(shape).contiguous()) \
+                    if generator is None else \
+                    torch.distributions.Gamma(a.expand(shape), 1.0).rsample()
+                # implicit reparameterisation gradient d g / d a
+                g = _GammaReparam.apply(g.detach(), a.expand(shape))
+                g = g.clamp_min(1e-30)
+                y = b / g
+                lq = (a * torch.log(b) - torch.lgamma(a) - (a + 1.0) * torch.log(y) - b / y)
+            th = _sp(y)
+            lq = lq - torch.nn.functional.logsigmoid(y)
+            theta[n] = th
+            logq = logq + lq.sum((-1, -2))
+        return theta, logq
+
+    @torch.no_grad()
+    def sample(self, n=1):
+        th, _ = self.rsample(n)
+        return {k: v.detach() for k, v in th.items()}
+
+    @torch.no_grad()
+    def expectations(self, samples=32):
+        th, _ = self.rsample(samples)
+        return {k: v.mean(0) for k, v in th.items()}
+
+
+class _GammaReparam(torch.autograd.Function):
+    """g ~ Gamma(a, 1) with d g/d a from torch._standard_gamma_grad."""
+
+    @staticmethod
+    def forward(ctx, g, a):
+        ctx.save_for_backward(g, a)
+        return g
+
+    @staticmethod
+    def backward(ctx, grad):
+        g, a = ctx.saved_tensors
+        return None, grad * torch._standard_gamma_grad(a.contiguous(), g.contiguous())
+
+
+class Adam:
+    """tf.keras-style Adam on a list of tensors (beta1 .9, beta2 .999, eps 1e-7)."""
+
+    def __init__(self, params, lr, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.params, self.lr, self.b1, self.b2, self.eps = params, lr, beta1, beta2, eps
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, grads):
+        self.t += 1
+        c1 = 1.0 - self.b1 ** self.t
+        c2 = 1.0 - self.b2 ** self.t
+        for p, g, m, v in zip(self.params, grads, self.m, self.v):
+            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            p.addcdiv_(m / c1, (v / c2).sqrt_().add_(self.eps), value=-self.lr)
+
+
+def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None, generator=None):
+    """One stochastic ELBO evaluation + gradient wrt the surrogate trainables.
+    Returns (loss float tensor, grads list) -- no optimiser update."""
+    sur = model.surrogate_distribution
+    theta, logq = sur.rsample(sample_size, generator)
+    det = {k: v.detach() for k, v in theta.items()}
+    sc, cs = model._batch(batch)
+    B = cs.n_rows
+    c = float(B) / float(dataset_rows)
+    parts, g, nnf = model.energy_and_grads(batch, det, all_reduce=all_reduce, prior_weight=c)
+    prior = sum(parts[n] for n in VAR_ORDER)
+    energy = parts["x"] + parts["z"] + c * prior           # [S] float64
+    loss = -(energy - c * logq.detach().double()).mean() / B
+    # surrogate for autograd: d loss / d trainables
+    lin = sum((g[n] * theta[n]).sum() for n in VAR_ORDER)
+    sur_loss = -(lin - c * logq.sum()) / (sample_size * B)
+    grads = torch.autograd.grad(sur_loss, sur.trainable_variables)
+    return loss, list(grads), nnf
+
+
+def _clip(grads, clip_value):
+    if clip_value is None:
+        return grads
+    return [g.clamp(-clip_value, clip_value) for g in grads]
+
+
+def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=8,
+        sample_batches=1, num_steps=100, num_epochs=None, rel_tol=1e-6, abs_tol=1e-10,
+        learning_rate=0.01, clip_value=10.0, max_decay_steps=25, lr_decay_factor=0.99,
+        check_every=1, set_expectations=True, all_reduce=None, verbose=True, **kwargs):
+    """Counterpart of BayesianModel.fit (tests/spmf_test.py:35-43 kwargs).
+    One epoch = one pass over ``batched_data_factory()``; stops on rel_tol /
+    abs_tol of the epoch-mean loss; on a plateau decays the learning rate and
+    restores the best trainables (behaviour evidenced by
+    notebooks/factorizing_random_noise.ipynb:122-420)."""
+    sur = model.surrogate_distribution
+    opt = Adam(sur.trainable_variables, learning_rate)
+    epochs = num_epochs if num_epochs is not None else num_steps
+    losses, best, best_state, decays = [], math.inf, None, 0
+    for ep in range(epochs):
+        tot, nb = 0.0, 0
+        for batch in iter(batched_data_factory()):
+            loss, grads, nnf = elbo_step(model, batch, dataset_size, sample_size, all_reduce)
+            lv = float(loss)
+            if not math.isfinite(lv) or float(nnf.sum()) > 0:
+                if verbose:
+                    print("Batch loss NaN, skipping")
+                continue
+            opt.step(_clip(grads, clip_value))
+            tot += lv
+            nb += 1
+        if nb == 0:
+            break
+        ep_loss = tot / nb
+        losses.append(ep_loss)
+        if verbose and ep % check_every == 0:
+            print(f"Epoch: {ep} average-batch loss: {ep_loss}")
+        if ep_loss < best:
+            if best - ep_loss < abs_tol or (math.isfinite(best) and
+                                            (best - ep_loss) / abs(best) < rel_tol):
+                best = ep_loss
+                break
+            best = ep_loss
+            best_state = [p.detach().clone() for p in sur.trainable_variables]
+        else:
+            decays += 1
+            opt.lr *= lr_decay_factor
+            if verbose:
+                print(f"We are in a loss plateau learning rate: {opt.lr}")
+            if best_state is not None:
+                with torch.no_grad():
+                    for p, b in zip(sur.trainable_variables, best_state):
+                        p.copy_(b)
+                if verbose:
+                    print("Restoring from a checkpoint")
+            if decays >= max_decay_steps:
+                if verbose:
+                    print(f"We have reset {decays} times so quitting")
+                break
+    if set_expectations:
+        model.set_calibration_expectations()
+    return losses
+
+
+def calibrate_advi(model, num_steps=100, num_epochs=None, learning_rate=0.1, abs_tol=1e-10,
+                   rel_tol=1e-8, clip_value=5.0, max_decay_steps=25, lr_decay_factor=0.99,
+                   check_every=1, set_expectations=True, sample_size=4, data=None, **kwargs):
+    """Legacy driver entry (bin/factorize_csv.py:121-124): iterates
+    ``model.data`` (the batched dataset given to PoissonMatrixFactorization)."""
+    data = data if data is not None else getattr(model, "data", None)
+    if data is None:
+        raise ValueError("calibrate_advi needs the dataset the model was built with")
+    factory = data if callable(data) else (lambda: data)
+    n = 0
+    for b in iter(factory()):
+        x = b[model.count_key] if isinstance(b, dict) else b
+        n += x.n_rows if hasattr(x, "n_rows") else x.shape[0]
+    return fit(model, factory, dataset_size=n, sample_size=sample_size,
+               num_steps=num_steps, num_epochs=num_epochs, rel_tol=rel_tol, abs_tol=abs_tol,
+               learning_rate=learning_rate, clip_value=clip_value,
+               max_decay_steps=max_decay_steps, lr_decay_factor=lr_decay_factor,
+               check_every=check_every, set_expectations=set_expectations, **kwargs)
+
+
+def save_model(model, filename):
+    """``factor.save(filename)`` (bin/factorize_csv.py:139): pickle of the
+    ordered surrogate variables + constructor state, restorable with
+    ``reconstitute`` (poisson.py:711-717)."""
+    import pickle
+    eta = model.eta_i
+    if isinstance(eta, torch.Tensor):
+        eta = eta.detach().cpu().numpy()
+    state = {
+        "surrogate_vars": [p.detach().cpu().numpy()
+                           for p in model.surrogate_distribution.trainable_variables],
+        "var_list": list(model.var_list),
+        "latent_dim": model.latent_dim, "feature_dim": model.feature_dim,
+        "u_tau_scale": model.u_tau_scale, "s_tau_scale": model.s_tau_scale,
+        "symmetry_breaking_decay": model.symmetry_breaking_decay,
+        "scale_columns": model.scale_columns, "scale_rows": model.scale_rows,
+        "log_transform": model.log_transform, "eta_i": eta,
+        "xi_u_global": float(model.xi_u_global), "count_key": model.count_key,
+    }
+    with open(filename, "wb") as f:
+        pickle.dump(state, f)
+    return state

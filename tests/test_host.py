@@ -1,0 +1,115 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol the header
+declares, the ctypes struct matches, and the host-side layout builder
+(SparseCounts) produces a correct CSR + panel-CSC.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    from spmf_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from spmf_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "spmf_hip.h")).read()
+    declared = set(re.findall(r"\b(spmf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.spmf_version() == 1
+
+
+def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
+    h = C.c_void_p()
+    assert lib.spmf_ctx_create(0, 100, 10, 0, C.byref(h)) == -1      # K > 64
+    assert lib.spmf_ctx_create(0, 16, 1000, 1, C.byref(h)) == 0
+    assert lib.spmf_padded_k(h) == 16
+    assert lib.spmf_ctx_set_prior(h, -1.0, 1.0, 0.99) == -1
+    assert b"must be > 0" in lib.spmf_last_error(h)
+    n1 = lib.spmf_workspace_bytes(h, 1000, 1)
+    n2 = lib.spmf_workspace_bytes(h, 2000, 1)
+    assert n2 - n1 == 2 * 1000 * 16 * 4
+    # acc_len = 2*D*KP + D + 2*(4+KP)
+    assert lib.spmf_acc_len(h, 3) == 3 * (2 * 1000 * 16 + 1000 + 2 * (4 + 16))
+    lib.spmf_ctx_destroy(h)
+    h3 = C.c_void_p()
+    assert lib.spmf_ctx_create(0, 3, 10, 0, C.byref(h3)) == 0
+    assert lib.spmf_padded_k(h3) == 4
+    lib.spmf_ctx_destroy(h3)
+
+
+def test_counts_struct_layout_matches_header():
+    from spmf_amd._lib import CountsStruct
+    # 2*int64 + 4*int32 + 7 pointers + double
+    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8
+    assert CountsStruct.row_ptr.offset == 32
+    assert CountsStruct.lgamma_sum.offset == 88
+
+
+@pytest.mark.parametrize("N,D,P,density", [(50, 13, 16, 0.3), (64, 7, 64, 0.9), (10, 5, 3, 0.0),
+                                           (33, 20, 1000, 0.2)])
+def test_sparse_counts_layout(N, D, P, density):
+    from spmf_amd.sparse import SparseCounts
+    rng = np.random.default_rng(N + D)
+    x = ((rng.random((N, D)) < density) * (1 + rng.poisson(2.0, size=(N, D)))).astype(np.float32)
+    if N > 3:
+        x[2] = 0
+    sc = SparseCounts.from_dense(x, "cpu", P)
+    ref = sp.csr_matrix(x)
+    np.testing.assert_array_equal(sc.row_ptr.numpy(), ref.indptr)
+    np.testing.assert_array_equal(sc.col_idx.numpy(), ref.indices)
+    np.testing.assert_array_equal(sc.val.numpy(), ref.data)
+    np.testing.assert_array_equal(sc.to_dense().numpy(), x)
+    # scipy CSR input gives the same layout
+    sc2 = SparseCounts.from_any(ref, "cpu", P)
+    np.testing.assert_array_equal(sc2.pc_row.numpy(), sc.pc_row.numpy())
+    # panel-CSC: every (panel, column) list holds that panel's rows, ascending
+    nP = sc.n_panels
+    assert nP == max(1, -(-N // sc.panel_rows))
+    ptr = sc.pc_ptr.numpy().reshape(nP, D + 1)
+    assert ptr[0, 0] == 0 and ptr[-1, -1] == sc.nnz
+    seen = np.zeros_like(x)
+    for p in range(nP):
+        for d in range(D):
+            rows = sc.pc_row.numpy()[ptr[p, d]:ptr[p, d + 1]]
+            vals = sc.pc_val.numpy()[ptr[p, d]:ptr[p, d + 1]]
+            assert np.all(np.diff(rows) > 0)
+            assert np.all(rows // sc.panel_rows == p)
+            np.testing.assert_array_equal(x[rows, d], vals)
+            seen[rows, d] = vals
+        if p + 1 < nP:
+            assert ptr[p, D] == ptr[p + 1, 0]
+    np.testing.assert_array_equal(seen, x)
+
+
+def test_energy_fails_loudly_without_gpu():
+    from spmf_amd import PoissonFactorization
+    from spmf_amd._lib import SpmfError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = PoissonFactorization(latent_dim=2, feature_dim=4, initialize_distributions=False)
+    with pytest.raises(SpmfError):
+        m.energy_and_grads({"counts": np.ones((3, 4))}, {})
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "spmf_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f
