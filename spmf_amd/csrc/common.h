@@ -7,7 +7,7 @@
 
 namespace spmf {
 
-constexpr double kHalfLog2OverPi = 0.22579135264472743236;  // 0.5*log(2/pi)
+constexpr double kHalfLog2OverPi = -0.22579135264472743236;  // 0.5*log(2/pi)
 constexpr double kLgammaHalf = 0.57236494292470008707;      // lgamma(0.5)
 constexpr double kLog2 = 0.69314718055994530942;
 
