@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- ELBO steps/s + achieved HBM GB/s of the spmf hot path on MI355X.
+
+One *step* = one evaluation of all 14 energy parts plus the gradient wrt all
+12 latent variables for one batch and S Monte-Carlo draws: the
+prep, row-pass, column-pass and finish kernels behind the C-ABI, plus -- with
+more than one rank -- the single RCCL sum-all-reduce of the packed gradient
+accumulators over the row shards.  Inputs are resident in HBM before the
+timed region starts.
+
+Default workload = BASELINE.json configs[2] ("C3"): 1M x 20k linear-structure
+counts, nnz ~ 1e8, K = 32, S = 1, full batch, row-sharded over the ranks
+(strong scaling: the matrix is fixed, so steps/s should rise with N).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 measured copy)
+
+WORKLOADS = {
+    # name: (rows, cols, density, K, description)
+    "c3": (1_000_000, 20_000, 0.005, 32,
+           "C3: 1M x 20k linear-structure Poisson counts, nnz~1e8, K=32"),
+    "c2": (100_000, 5_000, 0.01, 16,
+           "C2: 100k x 5k, 1% nnz, K=16"),
+    "small": (50_000, 2_000, 0.01, 32, "smoke-sized: 50k x 2k, 1% nnz, K=32"),
+}
+
+
+def algorithmic_bytes(nnz, B, D, K, S):
+    """SURVEY 8d two-pass model, canonical fp32 values + int32 indices."""
+    row = 8 * nnz + 4 * (B + 1) + S * (8 * B * K + 8 * D * K + 8 * D)
+    col = 8 * nnz + 4 * (D + 1) + S * (8 * B * K + 8 * D * K + 8 * D)
+    return row, col, row + col
+
+
+def cpu_baseline(sc, model, params, K, max_rows=40_000):
+    """The CPU restatement (oracle/sparse_exact.py, kind "port") timed on the
+    host cores on a bounded row sample of the same workload."""
+    import numpy as np
+    import scipy.sparse as sp
+    from oracle import sparse_exact as SE
+    n = min(sc.n_rows, max_rows)
+    hi = int(sc.row_ptr[n])
+    X = sp.csr_matrix((sc.val[:hi].cpu().numpy().astype(np.float64),
+                       sc.col_idx[:hi].cpu().numpy(),
+                       sc.row_ptr[:n + 1].cpu().numpy()), shape=(n, sc.n_cols))
+    one = {k: v[0].double().cpu().numpy() for k, v in params.items()}
+    eta = model._eta_device().double().cpu().numpy()
+    decay = model.symmetry_breaking_decay ** np.arange(K)
+
+    def step():
+        SE.data_term(X, eta, float(model.xi_u_global), model.scale_rows,
+                     one["u"], one["v"], one["w"], one["s"])
+        SE.prior_term(one, model.u_tau_scale, model.s_tau_scale, decay)
+    step()
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t0 < 8.0 and reps < 50):
+        step()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return n, hi, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--samples", type=int, default=1, help="Monte-Carlo draws S per step")
+    ap.add_argument("--rows", type=int, default=None, help="override total rows")
+    ap.add_argument("--panel-rows", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from spmf_amd import PoissonFactorization, _lib, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         "torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    rows, D, density, K, desc = WORKLOADS[args.workload]
+    if args.rows:
+        rows = args.rows
+    S = args.samples
+    # strong scaling: contiguous shards of whole generator chunks
+    chunk = synth.CHUNK_ROWS
+    nchunks = -(-rows // chunk)
+    c0 = nchunks * rank // world
+    c1 = nchunks * (rank + 1) // world
+    my_rows = min(rows, c1 * chunk) - c0 * chunk
+    sc = synth.linear_structure(my_rows, D, density, dev, first_chunk=c0,
+                                panel_rows=args.panel_rows)
+
+    model = PoissonFactorization(latent_dim=K, feature_dim=D,
+                                 u_tau_scale=1.0 / (rows * D) ** 0.5, device=dev,
+                                 panel_rows=args.panel_rows)
+    # compute_scales (poisson.py:113-154) over all shards: one pre-pass + all-reduce
+    colsum = torch.zeros(D, dtype=torch.float64, device=dev)
+    colnnz = torch.zeros(D, dtype=torch.float64, device=dev)
+    sc.compute_stats(model._handle(), colsum, colnnz)
+    tot = torch.tensor([float(sc.n_rows), float(sc.row_lgamma.sum()), float(sc.nnz)],
+                       dtype=torch.float64, device=dev)
+    if world > 1:
+        for t in (colsum, colnnz, tot):
+            dist.all_reduce(t)
+    cm = colsum / colnnz
+    model.eta_i = torch.where(cm > 1, cm, torch.ones_like(cm)).reshape(1, D)
+    model.xi_u_global = float(torch.nansum(cm))
+    rows_g, lgam_g, nnz_g = int(tot[0]), float(tot[1]), int(tot[2])
+
+    # parameters: S draws from the surrogate at its initial values (poisson.py:403-539)
+    gen_seed = 20241218
+    torch.manual_seed(gen_seed)
+    params = model.surrogate_distribution.sample(S)
+    if world > 1:
+        for n in _lib.VAR_ORDER:            # replicate rank 0's draw
+            dist.broadcast(params[n], 0)
+    batch = {"counts": sc}
+
+    hook = None
+    if world > 1:
+        def hook(acc, r, lg):
+            dist.all_reduce(acc)
+            return rows_g, lgam_g
+
+    lib, h = _lib.load(), model._handle()
+
+    def step():
+        return model.energy_and_grads(batch, params, all_reduce=hook)
+
+    for _ in range(args.warmup):
+        parts, grads, nnf = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib.spmf_ctx_enable_timing(h, 1)       # hipEvents between kernels, no syncs
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        parts, grads, nnf = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    import ctypes as C
+    ms5 = (C.c_float * 5)()
+    _lib.check(h, lib.spmf_last_timing(h, ms5), "spmf_last_timing")
+    lib.spmf_ctx_enable_timing(h, 0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0])
+
+    if rank == 0:
+        ms_step = 1e3 * dt / args.steps
+        value = args.steps / dt
+        # roofline of the dominant kernel of THIS rank's shard
+        b_row, b_col, b_tot = algorithmic_bytes(sc.nnz, sc.n_rows, D, K, S)
+        kern = {"prep": ms5[0], "row_pass": ms5[1], "col_pass": ms5[2], "finish": ms5[3]}
+        dom = "col_pass" if ms5[2] >= ms5[1] else "row_pass"
+        dom_bytes = (b_col if dom == "col_pass" else b_row) / S   # timing taps cover one draw
+        achieved = dom_bytes / (kern[dom] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        _, _, b_tot_g = algorithmic_bytes(nnz_g, rows_g, D, K, S)
+        out = {
+            "metric": "elbo_steps_per_sec", "value": value, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc + f", S={S}, full batch, row-sharded x{world}",
+                       "rows": rows_g, "cols": D, "nnz": nnz_g, "latent_dim": K,
+                       "samples": S, "parallelism": f"row-shard dp{world}",
+                       "panel_rows": args.panel_rows},
+            "achieved_hbm_gbps_step": b_tot_g / world / (ms_step * 1e-3) / 1e9,
+            "frac_hbm_roofline_step": b_tot_g / world / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_step": b_tot_g,
+            "kernel_ms": {k: round(float(v), 4) for k, v in kern.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic},
+            "n_nonfinite": float(nnf.sum()),
+            "elbo_x": float(parts["x"][0]),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            n_s, nnz_s, t_s = cpu_baseline(sc, model, params, K)
+            out["cpu_baseline"] = {
+                "value": 1.0 / (t_s * rows_g / n_s), "unit": "steps/s", "cores": 1,
+                "kind": "port",
+                "sample": f"first {n_s} rows ({nnz_s} nnz) of the same matrix, fp64 "
+                          f"scipy.sparse port (oracle/sparse_exact.py), {t_s:.3f} s per "
+                          f"sample step, scaled by rows to the full workload; "
+                          f"host has {os.cpu_count()} cores, port is single-threaded"}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

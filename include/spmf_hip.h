@@ -157,9 +157,11 @@ int spmf_padded_k(const spmf_ctx* ctx);
 const float* spmf_z_ptr(const spmf_ctx* ctx);
 const float* spmf_gz_ptr(const spmf_ctx* ctx);
 
-/* Per-kernel device time of the last spmf_data_pass/spmf_finish when
- * profiling was enabled (hipEvents on `stream`; synchronises): ms[5] =
- * prep, row pass, column pass, finish, total.  For bench.py's roofline. */
+/* Per-kernel device time, averaged over the (up to 64) most recent
+ * spmf_data_pass + spmf_finish pairs issued since timing was enabled
+ * (hipEvents recorded on `stream` between the kernels of the last draw; the
+ * query synchronises, the hot path does not): ms[5] = prep, row pass, column
+ * pass, finish, sum.  For bench.py's roofline. */
 int spmf_ctx_enable_timing(spmf_ctx* ctx, int on);
 int spmf_last_timing(spmf_ctx* ctx, float* ms5);
 

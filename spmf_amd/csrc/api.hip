@@ -29,7 +29,11 @@ struct spmf_ctx {
   float *Ap = nullptr, *Vp = nullptr, *phi = nullptr, *z = nullptr, *gzs = nullptr;
   // timing taps
   int timing = 0;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kSets = 64;  // ring of event sets: no sync inside a timed loop
+  hipEvent_t evs[kSets][6] = {};
+  hipEvent_t* ev = evs[0];
+  int ev_set = -1;      // set used by the call in flight
+  int ev_count = 0;     // complete sets recorded since enable
   int ev_valid = 0;
   std::string err;
 };
@@ -101,8 +105,9 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
 
 void spmf_ctx_destroy(spmf_ctx* c) {
   if (!c) return;
-  for (auto& e : c->ev)
-    if (e) (void)hipEventDestroy(e);
+  for (auto& set : c->evs)
+    for (auto& e : set)
+      if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -161,19 +166,34 @@ const float* spmf_gz_ptr(const spmf_ctx* c) { return c ? c->gzs : nullptr; }
 
 int spmf_ctx_enable_timing(spmf_ctx* c, int on) {
   if (!c) return SPMF_E_ARG;
-  if (on && !c->ev[0])
-    for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
+  if (on && !c->evs[0][0])
+    for (auto& set : c->evs)
+      for (auto& e : set) HIPCHK(c, hipEventCreate(&e));
   c->timing = on;
   c->ev_valid = 0;
+  c->ev_set = -1;
+  c->ev_count = 0;
   return SPMF_OK;
 }
 
 int spmf_last_timing(spmf_ctx* c, float* ms5) {
   if (!c || !ms5) return SPMF_E_ARG;
-  if (!c->timing || c->ev_valid != 3) return fail(c, SPMF_E_ARG, "no timing recorded (enable timing, run data_pass + finish)");
-  HIPCHK(c, hipEventSynchronize(c->ev[5]));
-  for (int i = 0; i < 3; ++i) HIPCHK(c, hipEventElapsedTime(&ms5[i], c->ev[i], c->ev[i + 1]));
-  HIPCHK(c, hipEventElapsedTime(&ms5[3], c->ev[4], c->ev[5]));
+  if (!c->timing || c->ev_count < 1) return fail(c, SPMF_E_ARG, "no timing recorded (enable timing, run data_pass + finish)");
+  // average over the (up to kSets) most recent complete steps
+  const int n = c->ev_count < spmf_ctx::kSets ? c->ev_count : spmf_ctx::kSets;
+  double acc[4] = {0, 0, 0, 0};
+  for (int k = 0; k < n; ++k) {
+    hipEvent_t* e = c->evs[((c->ev_set - k) % spmf_ctx::kSets + spmf_ctx::kSets) % spmf_ctx::kSets];
+    HIPCHK(c, hipEventSynchronize(e[5]));
+    float t;
+    for (int i = 0; i < 3; ++i) {
+      HIPCHK(c, hipEventElapsedTime(&t, e[i], e[i + 1]));
+      acc[i] += t;
+    }
+    HIPCHK(c, hipEventElapsedTime(&t, e[4], e[5]));
+    acc[3] += t;
+  }
+  for (int i = 0; i < 4; ++i) ms5[i] = (float)(acc[i] / n);
   ms5[4] = ms5[0] + ms5[1] + ms5[2] + ms5[3];
   return SPMF_OK;
 }
@@ -211,6 +231,11 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
   const size_t al_ = acc_len(D, KP);
   // zero acc | dacc | dprep (contiguous in the carve)
   HIPCHK(c, hipMemsetAsync(c->acc, 0, (size_t)((char*)c->Ap - (char*)c->acc), st));
+  if (c->timing) {
+    c->ev_set = (c->ev_set + 1) % spmf_ctx::kSets;
+    c->ev = c->evs[c->ev_set];
+    c->ev_valid = 0;
+  }
   for (int s = 0; s < S; ++s) {
     const bool tm = c->timing && s == S - 1;
     float* acc = c->acc + (size_t)s * al_;
@@ -263,7 +288,10 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
     launch_finish(KP, fa, st);
     if (tm) {
       HIPCHK(c, hipEventRecord(c->ev[5], st));
-      c->ev_valid |= 2;
+      if (c->ev_valid == 1) {
+        c->ev_valid = 3;
+        c->ev_count++;
+      }
     }
   }
   HIPCHK(c, hipGetLastError());

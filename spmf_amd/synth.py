@@ -1,0 +1,80 @@
+"""Synthetic count matrices of the shapes BASELINE.json names.
+
+Generated on the device with torch (data plumbing, not the hot path) in
+fixed 125k-row chunks seeded by chunk id, so the global matrix is the same
+however many ranks share it.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .sparse import SparseCounts
+
+CHUNK_ROWS = 125_000
+
+
+def linear_structure_chunk(chunk_id, rows, D, density, device, seed=20241218 + 3,
+                           n_factors=8):
+    """CSR pieces of one row chunk of the C3 workload: the generator of
+    notebooks/factorize_linear_structure.ipynb:53-66 (Poisson(1) noise, every
+    third column Poisson(Z.V) with Z=|N(0,1)|, V=|N(1.5,.5)|) thinned by a
+    Bernoulli(p) mask so that the stored density is ~`density`."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed * 1000 + chunk_id)
+    gv = torch.Generator(device=device)
+    gv.manual_seed(seed)                       # V is shared by every chunk
+    nf = (D + 2) // 3
+    V = (1.5 + 0.5 * torch.randn(n_factors, nf, device=device, generator=gv)).abs()
+    Z = torch.randn(rows, n_factors, device=device, generator=g).abs()
+    # retention of a candidate cell: P(Poisson>0) ~ (2/3)*0.632 + (1/3)*~1
+    p_cand = min(1.0, density / 0.755)
+    lam = torch.full((rows,), D * p_cand, device=device)
+    n_cand = torch.poisson(lam, generator=g).clamp_(max=D).to(torch.int64)
+    r = torch.repeat_interleave(torch.arange(rows, device=device), n_cand)
+    c = torch.randint(0, D, (int(r.numel()),), device=device, generator=g)
+    key = torch.unique(r * D + c)              # sorted, duplicate free
+    r, c = key // D, key % D
+    is_f = (c % 3) == 0
+    rate = torch.ones(key.numel(), device=device)
+    fi = is_f.nonzero(as_tuple=True)[0]
+    rate[fi] = (Z[r[fi]] * V[:, c[fi] // 3].T).sum(1)
+    x = torch.poisson(rate, generator=g)
+    keep = x > 0
+    r, c, x = r[keep], c[keep], x[keep]
+    cnt = torch.bincount(r, minlength=rows)
+    return cnt, c.to(torch.int32), x.to(torch.float32)
+
+
+def linear_structure(rows, D, density, device, first_chunk=0, panel_rows=8192,
+                     chunk_rows=CHUNK_ROWS):
+    """SparseCounts of `rows` rows starting at global chunk `first_chunk`."""
+    cnts, cols, vals = [], [], []
+    done, cid = 0, first_chunk
+    while done < rows:
+        n = min(chunk_rows, rows - done)
+        cnt, c, x = linear_structure_chunk(cid, n, D, density, device)
+        cnts.append(cnt); cols.append(c); vals.append(x)
+        done += n
+        cid += 1
+    cnt = torch.cat(cnts)
+    row_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    row_ptr[1:] = torch.cumsum(cnt, 0)
+    return SparseCounts(row_ptr, torch.cat(cols), torch.cat(vals), rows, D, panel_rows)
+
+
+def bernoulli_poisson(rows, D, density, device, seed, mean=2.0, panel_rows=8192):
+    """C2-style: Bernoulli(density) mask x (1 + Poisson(mean)) values."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lam = torch.full((rows,), D * density, device=device)
+    n = torch.poisson(lam, generator=g).clamp_(max=D).to(torch.int64)
+    r = torch.repeat_interleave(torch.arange(rows, device=device), n)
+    c = torch.randint(0, D, (int(r.numel()),), device=device, generator=g)
+    key = torch.unique(r * D + c)
+    r, c = key // D, key % D
+    x = 1.0 + torch.poisson(torch.full((key.numel(),), mean, device=device), generator=g)
+    cnt = torch.bincount(r, minlength=rows)
+    row_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    row_ptr[1:] = torch.cumsum(cnt, 0)
+    return SparseCounts(row_ptr, c.to(torch.int32), x.to(torch.float32), rows, D, panel_rows)
