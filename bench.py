@@ -113,9 +113,11 @@ def main():
     sc = synth.linear_structure(my_rows, D, density, dev, first_chunk=c0,
                                 panel_rows=args.panel_rows)
 
-    model = PoissonFactorization(latent_dim=K, feature_dim=D,
-                                 u_tau_scale=1.0 / (rows * D) ** 0.5, device=dev,
-                                 panel_rows=args.panel_rows)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # the class prints like the reference
+        model = PoissonFactorization(latent_dim=K, feature_dim=D,
+                                     u_tau_scale=1.0 / (rows * D) ** 0.5, device=dev,
+                                     panel_rows=args.panel_rows)
     # compute_scales (poisson.py:113-154) over all shards: one pre-pass + all-reduce
     colsum = torch.zeros(D, dtype=torch.float64, device=dev)
     colnnz = torch.zeros(D, dtype=torch.float64, device=dev)

@@ -10,18 +10,30 @@
 // The minus-one part of (x/r - 1) over ALL rows (stored or not) is closed
 // form (sum_b z_b and B) and is applied by the finish kernel.
 //
-// Work item = (row panel p, column d), one wavefront each.  Panels are
-// `panel_rows` consecutive rows so that the z / xi*gz rows a panel gathers
-// (2 * panel_rows * KP * 4 B) stay L2 resident; consecutive workgroup ids go
-// to panels p = 8t + (blockIdx % 8), so with the observed round-robin
-// workgroup->XCD placement each XCD's L2 holds one panel at a time.  That is
-// a speed heuristic only: results do not depend on placement.
+// Mapping: a gathered row (z_b or xi_b*gz_b) is KP floats = LPN=KP/4 lanes x
+// float4, so a wave holds NG=64/LPN lane groups; EACH GROUP OWNS ONE COLUMN of
+// one row panel and keeps that column's gV'/gA'/gphi slices in registers, so
+// there is no cross-lane reduction besides the DPP fold of the dot product.
+// A group streams its (panel, column) list LPN entries per fetch (one per
+// lane, a 4*LPN-B contiguous read), two fetches ahead of use, and broadcasts
+// an entry inside the group with ds_bpermute; gathers are issued four entries
+// (eight 16-B loads per lane) at a time.
 //
-// Per-(p,d) partial sums are folded across the wave with xor shuffles and
-// leave as ONE float-atomic wave instruction covering two whole 128-B rows
-// (the shape MI355X runs atomics at full rate).  Float atomics make the
-// low-order bits of the gradient run-to-run dependent; parity tolerance is
-// 1e-5 relative (north_star).
+// L2 residency is what makes the 2 x 4*KP-B-per-entry gathers affordable
+// (measured: served from Infinity Cache instead, the pass runs at ~8.6 TB/s
+// of gather traffic = 3 ms on the C3 shape).  Panels are `panel_rows`
+// consecutive rows (2*panel_rows*KP*4 B of z / xi*gz, 2 MB at the default),
+// a wave handles ONE panel, and workgroup ids are ordered panel-major with
+// p = 8t + blockIdx%8, so with the observed round-robin workgroup->XCD
+// placement each XCD's resident workgroups share one panel.  Speed heuristic
+// only: results do not depend on placement.
+//
+// A wave leaves through an LDS transpose and 8 float-atomic wave instructions,
+// each covering two whole 128-B gradient rows (the shape MI355X runs atomics
+// at full rate).  Atomic traffic is nnz/len * (2KP+1)*4 B with len = mean
+// entries per (panel, column) list (~41 at the default) -- 0.63 GB on C3.
+// Float atomics make the low-order bits of the gradient run-to-run dependent;
+// parity tolerance is 1e-5 relative (north_star).
 #include "common.h"
 #include "kernels.h"
 
@@ -35,80 +47,107 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     const float* __restrict__ gzs, float* __restrict__ gAp, float* __restrict__ gVp,
     float* __restrict__ gphi) {
   constexpr int LPN = KP / 4;
-  constexpr int NPI = 64 / LPN;
+  constexpr int NG = 64 / LPN;                  // columns per wave
+  constexpr int GRP = LPN < 4 ? LPN : 4;        // entries gathered back to back
+  __shared__ __attribute__((aligned(16))) float stage[4][NG][2 * KP];
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPN, grp = lane / LPN;
   const int wid = threadIdx.x >> 6;
-  // block id -> (panel, column chunk); blockIdx % 8 selects the panel residue
+  // block id -> (panel, block of 4*NG columns); blockIdx % 8 = panel residue
   const int64_t L = blockIdx.x;
   const int x = (int)(L & 7);
   const int64_t q = L >> 3;
-  const int nch = (D + 3) >> 2;
-  const int t = (int)(q / nch), cch = (int)(q % nch);
+  const int ncbb = (D + 4 * NG - 1) / (4 * NG);
+  const int t = (int)(q / ncbb), cbb = (int)(q % ncbb);
   const int p = 8 * t + x;
-  const int d = cch * 4 + wid;
-  if (p >= n_panels || d >= D) return;
-  const int64_t pb = (int64_t)p * (D + 1) + d;
-  const int start = pc_ptr[pb], end = pc_ptr[pb + 1];
-  if (start >= end) return;
+  if (p >= n_panels) return;                    // block-uniform
+  const int d0 = (cbb * 4 + wid) * NG;
+  const int d = d0 + grp;
+  const bool colok = d < D;
 
+  int cur = 0, end = 0;
+  if (colok) {
+    const int64_t pb = (int64_t)p * (D + 1) + d;
+    cur = pc_ptr[pb];
+    end = pc_ptr[pb + 1];
+  }
   const float4* z4 = reinterpret_cast<const float4*>(z);
   const float4* g4 = reinterpret_cast<const float4*>(gzs);
-  const float4 vp = reinterpret_cast<const float4*>(Vp)[(size_t)d * LPN + sub];
-  const float ph = phi[d];
+  const float4 vp = colok ? reinterpret_cast<const float4*>(Vp)[(size_t)d * LPN + sub]
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float ph = colok ? phi[d] : 1.f;
   float4 gV = make_float4(0.f, 0.f, 0.f, 0.f), gA = gV;
   float gph = 0.f;
-  for (int base = start; base < end; base += 64) {
-    const int idx = base + lane;
-    const bool valid = idx < end;
-    const int rr = valid ? pc_row[idx] - row_base : 0;
-    const float xx = valid ? pc_val[idx] : 0.f;
-    const int nchunk = min(64, end - base);
-    const int nit = (nchunk + NPI - 1) / NPI;
-    for (int it = 0; it < nit; ++it) {
-      const int src = it * NPI + grp;
-      const int b = __shfl(rr, src);
-      const float xv = __shfl(xx, src);
-      const float4 zz = z4[(size_t)b * LPN + sub];
-      const float4 gg = g4[(size_t)b * LPN + sub];
-      float dot = dot4(zz, vp);
+
+  auto fetch = [&](int& rr_, float& xx_, int& cnt_) {
+    cnt_ = min(LPN, end - cur);                 // 0 once the list is exhausted
+    const int e = cur + sub;
+    rr_ = sub < cnt_ ? pc_row[e] - row_base : 0;
+    xx_ = sub < cnt_ ? pc_val[e] : 0.f;
+    cur += cnt_;
+  };
+
+  int rr0, cnt0, rr1, cnt1;
+  float xx0, xx1;
+  fetch(rr0, xx0, cnt0);
+  fetch(rr1, xx1, cnt1);
+  while (__any(cnt0 > 0)) {
+    int rr2, cnt2;
+    float xx2;
+    fetch(rr2, xx2, cnt2);                      // two fetches ahead of use
 #pragma unroll
-      for (int m = 1; m < LPN; m <<= 1) dot += __shfl_xor(dot, m);
-      const float r = dot + ph;
-      const float cb = (xv > 0.f && r > 0.f && r < INFINITY) ? xv / r : 0.f;
-      gV = fma4(cb, zz, gV);
-      gA = fma4(xv, gg, gA);
-      gph += cb;
+    for (int g0 = 0; g0 < LPN; g0 += GRP) {
+      if (__any(cnt0 > g0)) {                   // wave-uniform
+        float4 zz[GRP], gg[GRP];
+        float xv[GRP];
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const int src = grp * LPN + g0 + j;
+          const int b = __shfl(rr0, src);
+          xv[j] = __shfl(xx0, src);
+          zz[j] = z4[(size_t)b * LPN + sub];
+          gg[j] = g4[(size_t)b * LPN + sub];
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const float r = group_sum<LPN>(dot4(zz[j], vp)) + ph;
+          const float cbv =
+              (xv[j] > 0.f && r > 0.f && r < INFINITY) ? __fdividef(xv[j], r) : 0.f;
+          gV = fma4(cbv, zz[j], gV);
+          gA = fma4(xv[j], gg[j], gA);
+          gph += cbv;
+        }
+      }
     }
+    rr0 = rr1; xx0 = xx1; cnt0 = cnt1;
+    rr1 = rr2; xx1 = xx2; cnt1 = cnt2;
   }
+  // ---- transpose through LDS so each atomic instruction covers whole rows --
+  float4* st4 = reinterpret_cast<float4*>(&stage[wid][grp][0]);
+  st4[sub] = gV;
+  st4[LPN + sub] = gA;
+  __builtin_amdgcn_wave_barrier();
+  const float* flat = &stage[wid][0][0];
 #pragma unroll
-  for (int m = LPN; m < 64; m <<= 1) {
-    gV = add4(gV, shfl_xor4(gV, m));
-    gA = add4(gA, shfl_xor4(gA, m));
-    gph += __shfl_xor(gph, m);
-  }
-  // every lane now holds the full sums of its k-slice; spread the 2*KP adds
-  // over the wave: group g adds component (q&3) of (q>>2 ? gA : gV), q = g.
-  constexpr int NG = NPI < 8 ? NPI : 8;
-  if (grp < NG) {
-#pragma unroll
-    for (int q0 = 0; q0 < 8; q0 += NG) {
-      const int qq = q0 + grp;
-      const float4 src = (qq & 4) ? gA : gV;
-      const int j = qq & 3;
-      const float v = j == 0 ? src.x : (j == 1 ? src.y : (j == 2 ? src.z : src.w));
-      float* dst = ((qq & 4) ? gAp : gVp) + (size_t)d * KP + sub * 4 + j;
+  for (int i = 0; i < (NG * 2 * KP) / 64; ++i) {
+    const int e = i * 64 + lane;
+    const int c = e / (2 * KP), rem = e % (2 * KP);
+    const int dd = d0 + c;
+    const float v = flat[e];
+    if (dd < D && v != 0.f) {
+      float* dst = (rem >= KP ? gAp + (size_t)dd * KP + (rem - KP) : gVp + (size_t)dd * KP + rem);
       atomicAdd(dst, v);
     }
   }
-  if (lane == 0) atomicAdd(&gphi[d], gph);
+  if (colok && sub == 0 && gph != 0.f) atomicAdd(&gphi[d], gph);
 }
 
 template <int KP>
 static void launch_col_t(const ColArgs& a, hipStream_t st) {
-  const int64_t nch = (a.D + 3) / 4;
+  constexpr int NG = 64 / (KP / 4);
+  const int64_t ncbb = (a.D + 4 * NG - 1) / (4 * NG);
   const int64_t nt = (a.n_panels + 7) / 8;
-  const int64_t nb = nt * nch * 8;
+  const int64_t nb = nt * ncbb * 8;
   hipLaunchKernelGGL(col_pass_kernel<KP>, dim3((unsigned)nb), dim3(256), 0, st, a.D, a.n_panels,
                      a.row_base, a.pc_ptr, a.pc_row, a.pc_val, a.Vp, a.phi, a.z, a.gzs, a.gAp,
                      a.gVp, a.gphi);

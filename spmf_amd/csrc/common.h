@@ -40,6 +40,44 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
+// ---- DPP cross-lane adds (no LDS traffic, fold into v_add_f32_dpp) --------
+// ctrl: quad_perm[1,0,3,2]=0xB1 (xor 1), quad_perm[2,3,0,1]=0x4E (xor 2),
+// row_half_mirror=0x141 (i <-> 7-i), row_mirror=0x140 (i <-> 15-i),
+// row_ror:8=0x128.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+  return v + __int_as_float(t);
+}
+// Sum over the aligned group of N lanes (N = 1,2,4,8,16); every lane of the
+// group ends up with the total.
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (N >= 2) v = dpp_add<0xB1>(v);
+  if constexpr (N >= 4) v = dpp_add<0x4E>(v);
+  if constexpr (N >= 8) v = dpp_add<0x141>(v);
+  if constexpr (N >= 16) v = dpp_add<0x140>(v);
+  return v;
+}
+// Sum over the 64/LPN groups of a wave for lanes holding the same `sub`
+// (lane = grp*LPN + sub): xor butterflies over the lane bits >= log2(LPN).
+template <int LPN>
+__device__ __forceinline__ float across_groups_sum(float v) {
+  // inside a 16-lane DPP row: rotate-and-add by LPN, 2*LPN, ... , 8
+  if constexpr (LPN <= 1) v = dpp_add<0x121>(v);  // row_ror:1
+  if constexpr (LPN <= 2) v = dpp_add<0x122>(v);  // row_ror:2
+  if constexpr (LPN <= 4) v = dpp_add<0x124>(v);  // row_ror:4
+  if constexpr (LPN <= 8) v = dpp_add<0x128>(v);  // row_ror:8
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+template <int LPN>
+__device__ __forceinline__ float4 across_groups_sum4(float4 v) {
+  return make_float4(across_groups_sum<LPN>(v.x), across_groups_sum<LPN>(v.y),
+                     across_groups_sum<LPN>(v.z), across_groups_sum<LPN>(v.w));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

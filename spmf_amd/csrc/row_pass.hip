@@ -13,20 +13,107 @@
 //
 // Lane layout: a gathered factor row is KP floats = LPN=KP/4 lanes x float4,
 // so one wave instruction serves NPI=64/LPN stored entries; the LPN lanes of
-// an entry reduce their partial dot products with xor shuffles.  The
-// transcendental part (log, divide) runs once per 64 entries with one entry
-// per lane: lane (grp,sub) keeps the dot product of iteration `sub`.
-// col/val are read as one coalesced 256-B wave load per 64 entries and
-// distributed by ds_bpermute.
+// an entry fold their partial dot products with DPP adds.  The transcendental
+// part (log, divide) runs once per 64 entries with one entry per lane: lane
+// (grp,sub) keeps the dot product of iteration `sub`.  col/val are read as
+// one coalesced 256-B wave load per 64 entries and distributed by
+// ds_bpermute.  Gathers are issued in straight-line groups of up to four
+// (padded entries read row 0 with weight 0) so several L2 round trips are in
+// flight per wave; rows of <= 128 entries keep col/val in registers for both
+// sweeps.
 //
-// Roofline: HBM traffic is 8 B per stored entry per sweep (second sweep hits
-// L2) + 8*KP B per row written; the factor-row gathers (2 x 4*KP B per
+// Roofline: HBM traffic is 8 B per stored entry (+ an L2-served re-read for
+// long rows) + 8*KP B per row written; the factor-row gathers (2 x 4*KP B per
 // entry) are served by L2/Infinity Cache because A' and V' (D*KP*4 B each)
 // stay resident.  Algorithmic bytes: DESIGN.md section 4.
 #include "common.h"
 #include "kernels.h"
 
 namespace spmf {
+
+namespace {
+
+template <int KP>
+struct RowCtx {
+  static constexpr int LPN = KP / 4;
+  static constexpr int NPI = 64 / LPN;
+  static constexpr int GRP = LPN < 4 ? LPN : 4;  // gathers issued back to back
+  const float4* Ap4;
+  const float4* Vp4;
+  const float* phi;
+  int lane, sub, grp;
+
+  // z partial: zacc += sum over the chunk of x * A'_d
+  __device__ __forceinline__ void sweep1(int c, float x, int nchunk, float4& zacc) const {
+#pragma unroll
+    for (int g0 = 0; g0 < LPN; g0 += GRP) {
+      if (g0 * NPI < nchunk) {  // wave-uniform
+        float4 a[GRP];
+        float xv[GRP];
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const int src = (g0 + j) * NPI + grp;
+          const int d = __shfl(c, src);
+          xv[j] = __shfl(x, src);
+          a[j] = Ap4[(size_t)d * LPN + sub];
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) zacc = fma4(xv[j], a[j], zacc);
+      }
+    }
+  }
+
+  // rates, log-likelihood and gz partial over one chunk
+  __device__ __forceinline__ void sweep2(int c, float x, int nchunk, const float4& z,
+                                         float4& gz, float& ll, double& nnf) const {
+    float4 vv[LPN];
+    float rmine = 0.f;
+#pragma unroll
+    for (int g0 = 0; g0 < LPN; g0 += GRP) {
+      if (g0 * NPI < nchunk) {
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const int d = __shfl(c, (g0 + j) * NPI + grp);
+          vv[g0 + j] = Vp4[(size_t)d * LPN + sub];
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const float dot = group_sum<LPN>(dot4(z, vv[g0 + j]));
+          if (sub == g0 + j) rmine = dot;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) vv[g0 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // one entry per lane: lane (grp,sub) owns slot sub*NPI+grp
+    const int slot = sub * NPI + grp;
+    const float xs = __shfl(x, slot);
+    const int cs = __shfl(c, slot);
+    float cc = 0.f;
+    if (slot < nchunk && xs > 0.f) {
+      const float r = rmine + phi[cs];
+      if (r > 0.f && r < INFINITY) {
+        ll = fmaf(xs, logf(r), ll);
+        cc = __fdividef(xs, r);
+      } else {
+        nnf += 1.0;
+      }
+    }
+#pragma unroll
+    for (int g0 = 0; g0 < LPN; g0 += GRP) {
+      if (g0 * NPI < nchunk) {
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const float cb = __shfl(cc, grp * LPN + g0 + j);
+          gz = fma4(cb, vv[g0 + j], gz);
+        }
+      }
+    }
+  }
+};
+
+}  // namespace
 
 template <int KP>
 __global__ __launch_bounds__(256) void row_pass_kernel(
@@ -35,14 +122,17 @@ __global__ __launch_bounds__(256) void row_pass_kernel(
     const float* __restrict__ Ap, const float* __restrict__ Vp, const float* __restrict__ phi,
     const double* __restrict__ dprep, float* __restrict__ z, float* __restrict__ gzs,
     double* __restrict__ dacc, int encode_only) {
-  constexpr int LPN = KP / 4;    // lanes per stored entry
-  constexpr int NPI = 64 / LPN;  // entries per wave iteration
-  const int lane = threadIdx.x & 63;
-  const int sub = lane % LPN, grp = lane / LPN;
+  constexpr int LPN = KP / 4;
+  RowCtx<KP> cx;
+  cx.Ap4 = reinterpret_cast<const float4*>(Ap);
+  cx.Vp4 = reinterpret_cast<const float4*>(Vp);
+  cx.phi = phi;
+  cx.lane = threadIdx.x & 63;
+  cx.sub = cx.lane % LPN;
+  cx.grp = cx.lane / LPN;
+  const int lane = cx.lane, sub = cx.sub, grp = cx.grp;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const float4* Ap4 = reinterpret_cast<const float4*>(Ap);
-  const float4* Vp4 = reinterpret_cast<const float4*>(Vp);
 
   float4 veta4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (!encode_only)
@@ -53,82 +143,50 @@ __global__ __launch_bounds__(256) void row_pass_kernel(
 
   for (int64_t b = wave; b < B; b += nwaves) {
     const int start = row_ptr[b], end = row_ptr[b + 1];
+    const int n = end - start;
     const float xi = row_scale ? row_scale[b] : 1.f;
-    // ---- sweep 1: z_b ---------------------------------------------------
     float4 zacc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = start; base < end; base += 64) {
-      const int idx = base + lane;
-      const bool valid = idx < end;
-      const int c = valid ? col[idx] : 0;
-      const float x = valid ? val[idx] : 0.f;
-      const int nchunk = min(64, end - base);
-      const int nit = (nchunk + NPI - 1) / NPI;
-      for (int it = 0; it < nit; ++it) {
-        const int src = it * NPI + grp;
-        const int d = __shfl(c, src);
-        const float xv = __shfl(x, src);
-        zacc = fma4(xv, Ap4[(size_t)d * LPN + sub], zacc);
+    float4 gz = make_float4(0.f, 0.f, 0.f, 0.f);
+    float llrow = 0.f;
+    if (n <= 128) {
+      // ---- short row: col/val stay in registers for both sweeps ----------
+      const int i0 = start + lane, i1 = start + 64 + lane;
+      const int c0 = i0 < end ? __builtin_nontemporal_load(&col[i0]) : 0;
+      const float x0 = i0 < end ? __builtin_nontemporal_load(&val[i0]) : 0.f;
+      const int c1 = i1 < end ? __builtin_nontemporal_load(&col[i1]) : 0;
+      const float x1 = i1 < end ? __builtin_nontemporal_load(&val[i1]) : 0.f;
+      const int n0 = min(n, 64), n1 = n - 64;
+      cx.sweep1(c0, x0, n0, zacc);
+      if (n1 > 0) cx.sweep1(c1, x1, n1, zacc);
+      zacc = across_groups_sum4<LPN>(zacc);
+      zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
+      if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
+      if (encode_only) continue;
+      cx.sweep2(c0, x0, n0, zacc, gz, llrow, nnf_acc);
+      if (n1 > 0) cx.sweep2(c1, x1, n1, zacc, gz, llrow, nnf_acc);
+    } else {
+      // ---- long row: stream the row twice (second read is L2 served) -----
+      for (int base = start; base < end; base += 64) {
+        const int idx = base + lane;
+        const int c = idx < end ? col[idx] : 0;
+        const float x = idx < end ? val[idx] : 0.f;
+        cx.sweep1(c, x, min(64, end - base), zacc);
+      }
+      zacc = across_groups_sum4<LPN>(zacc);
+      zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
+      if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
+      if (encode_only) continue;
+      for (int base = start; base < end; base += 64) {
+        const int idx = base + lane;
+        const int c = idx < end ? col[idx] : 0;
+        const float x = idx < end ? val[idx] : 0.f;
+        cx.sweep2(c, x, min(64, end - base), zacc, gz, llrow, nnf_acc);
       }
     }
-#pragma unroll
-    for (int m = LPN; m < 64; m <<= 1) zacc = add4(zacc, shfl_xor4(zacc, m));
-    zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
-    if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
-    if (encode_only) continue;
+    gz = across_groups_sum4<LPN>(gz);
     if (grp == 0) {
       zsq_acc += (double)dot4(zacc, zacc);
       zsum = add4(zsum, zacc);
-    }
-    // ---- sweep 2: rates, log-likelihood, gz_b ---------------------------
-    float4 gz = make_float4(0.f, 0.f, 0.f, 0.f);
-    float llrow = 0.f;
-    for (int base = start; base < end; base += 64) {
-      const int idx = base + lane;
-      const bool valid = idx < end;
-      const int c = valid ? col[idx] : 0;
-      const float x = valid ? val[idx] : 0.f;
-      const int nchunk = min(64, end - base);
-      const int nit = (nchunk + NPI - 1) / NPI;
-      float4 vv[LPN];
-      float rmine = 0.f;
-#pragma unroll
-      for (int it = 0; it < LPN; ++it) {
-        vv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (it < nit) {  // wave-uniform
-          const int d = __shfl(c, it * NPI + grp);
-          vv[it] = Vp4[(size_t)d * LPN + sub];
-          float dot = dot4(zacc, vv[it]);
-#pragma unroll
-          for (int m = 1; m < LPN; m <<= 1) dot += __shfl_xor(dot, m);
-          if (sub == it) rmine = dot;
-        }
-      }
-      // one entry per lane: lane (grp,sub) owns slot sub*NPI+grp
-      const int slot = sub * NPI + grp;
-      const float xs = __shfl(x, slot);
-      const int cs = __shfl(c, slot);
-      const bool sv = slot < nchunk;
-      float cc = 0.f;
-      if (sv && xs > 0.f) {
-        const float r = rmine + phi[cs];
-        if (r > 0.f && r < INFINITY) {
-          llrow = fmaf(xs, logf(r), llrow);
-          cc = xs / r;
-        } else {
-          nnf_acc += 1.0;
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < LPN; ++it) {
-        if (it < nit) {
-          const float cb = __shfl(cc, grp * LPN + it);
-          gz = fma4(cb, vv[it], gz);
-        }
-      }
-    }
-#pragma unroll
-    for (int m = LPN; m < 64; m <<= 1) gz = add4(gz, shfl_xor4(gz, m));
-    if (grp == 0) {
       float4 o;
       o.x = xi * (gz.x - veta4.x - zacc.x);
       o.y = xi * (gz.y - veta4.y - zacc.y);
