@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Train PMF on a CSV-formatted count matrix -- same flags, defaults and
+output files as the reference CLI (bin/factorize_csv.py:19-204), running on
+the MI355X hot path.
+
+Outputs next to the input file (reference :128-200):
+  <f>_<K>D_encoding_lt_<b>_rn_<b>.csv        rows of A^T            (:128-134)
+  <f>_<K>D_model_lt_<b>_rn_<b>.pkl           factor.save            (:137-139)
+  <f>_<K>D_representation_lt_<b>_rn_<b>.csv  index, z (x normalization) (:187-200)
+The PDF figure (:143-185) needs matplotlib + arviz and is skipped when they
+are not installed.
+"""
+import argparse
+import csv
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from mederrata_spmf import PoissonMatrixFactorization  # noqa: E402
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(
+        description='Train PMF on CSV-formatted count matrix')
+    parser.add_argument(
+        '-f', '--csv-file', nargs='?', type=str,
+        help="Enter the CSV file")
+    parser.add_argument(
+        '-e', '--epoch', nargs='?', type=int, default=300,
+        help='Enter Epoch value: Default: 300')
+    parser.add_argument(
+        '-d', '--dimension', nargs='?', type=int, default=2,
+        help='Enter embedding dimension. Default: 2')
+    parser.add_argument(
+        '-b', '--batch-size', nargs='?', type=int, default=5000,
+        help='Enter batch size. Default: 5000')
+    parser.add_argument(
+        '-lr', '--learning-rate', nargs='?', type=float, default=0.01,
+        help='Enter float. Default: 0.01')
+    parser.add_argument(
+        '-c', '--clip-value', nargs='?', type=float, default=3.,
+        help='Gradient clip value. Default: 3.0')
+    parser.add_argument(
+        '-lt', '--log-transform',
+        help='Log-transform?', action='store_true')
+    parser.add_argument(
+        '-rn', '--row-normalize',
+        help='Row normalize based on counts?', action='store_true')
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
+    if args.csv_file is None:
+        sys.exit("You need to specify a csv file")
+    elif not os.path.exists(args.csv_file):
+        sys.exit("File doesn't exist")
+    _FILENAME = args.csv_file
+    _BATCH_SIZE = args.batch_size
+    _LOG_TRANSFORM = args.log_transform
+    _EPOCH_NUMBER = args.epoch
+    _DIMENSION = args.dimension
+    _LEARNING_RATE = args.learning_rate
+    _ROW_NORMALIZE = args.row_normalize
+    _CLIP_VALUE = args.clip_value
+
+    X = np.loadtxt(_FILENAME, delimiter=",", dtype=np.float64, ndmin=2)
+    N, columns = X.shape
+    colmeans = X.sum(0, keepdims=True) / N            # reference :90-98
+    rowmean = colmeans.sum()                          # :99
+
+    def batches(drop_remainder):
+        out = []
+        for lo in range(0, N, _BATCH_SIZE):
+            hi = min(N, lo + _BATCH_SIZE)
+            if drop_remainder and hi - lo < _BATCH_SIZE:
+                break                                  # :110 drop_remainder=True
+            b = {'indices': np.arange(lo, hi), 'counts': X[lo:hi]}
+            if _ROW_NORMALIZE:                         # :101-108
+                b['normalization'] = np.maximum(X[lo:hi].sum(1), 1.) / rowmean
+            out.append(b)
+        return out
+
+    csv_data_batched = batches(drop_remainder=True)
+    if not csv_data_batched:
+        sys.exit("Batch size larger than the dataset (drop_remainder=True leaves nothing)")
+
+    factor = PoissonMatrixFactorization(
+        csv_data_batched, latent_dim=_DIMENSION, strategy=None,
+        scale_columns=True, log_transform=_LOG_TRANSFORM,
+        column_norms=colmeans,
+        u_tau_scale=1.0 / np.sqrt(columns * N),
+        dtype=np.float64)
+
+    factor.calibrate_advi(
+        num_steps=_EPOCH_NUMBER,
+        rel_tol=1e-4, clip_value=_CLIP_VALUE,
+        learning_rate=_LEARNING_RATE)
+
+    print("Saving the encoding matrix")
+    filename = f"{_FILENAME}_{_DIMENSION}D_encoding"
+    filename += f"_lt_{_LOG_TRANSFORM}_rn_{_ROW_NORMALIZE}.csv"
+    with open(filename, "w") as f:
+        writer = csv.writer(f)
+        encoding = factor.encoding_matrix().cpu().numpy().T
+        for row in range(encoding.shape[0]):
+            writer.writerow(encoding[row, :])
+
+    print("Saving the trained model object")
+    filename = f"{_FILENAME}_{_DIMENSION}D_model"
+    filename += f"_lt_{_LOG_TRANSFORM}_rn_{_ROW_NORMALIZE}.pkl"
+    factor.save(filename)
+
+    try:
+        import matplotlib  # noqa: F401
+        import arviz  # noqa: F401
+        have_plot = True
+    except ImportError:
+        have_plot = False
+    if not have_plot:
+        print("Skipping the figure with the encodings (matplotlib/arviz not installed)")
+
+    print("Generating representations")
+    filename = f"{_FILENAME}_{_DIMENSION}D_representation"
+    filename += f"_lt_{_LOG_TRANSFORM}_rn_{_ROW_NORMALIZE}.csv"
+    with open(filename, 'w') as f:
+        writer = csv.writer(f)
+        for record in batches(drop_remainder=False):
+            # the reference reads record['data'] (:195) although the key is
+            # 'counts' (:86): a latent bug; the counts key is used here.
+            z = factor.encode(record['counts']).cpu().numpy()
+            if _ROW_NORMALIZE:
+                z *= record['normalization'][:, np.newaxis]
+            ind = record['indices']
+            for row in range(z.shape[0]):
+                writer.writerow(np.concatenate([[ind[row]], z[row, :]]))
+
+
+if __name__ == "__main__":
+    main()

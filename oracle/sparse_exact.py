@@ -127,3 +127,76 @@ def prior_term(p, u_tau_scale, s_tau_scale, decay):
         lp, ga = ig_half(P[nm + "_a"], beta)
         out[nm + "_a"] = lp.sum(); g[nm + "_a"] += ga
     return out, g
+
+
+# --------------------------------------------------------------------------
+# Packed-accumulator view (mirrors the HIP data pass / finish split so the
+# row-sharded all-reduce path can be tested on CPU with gloo).
+# Layout (include/spmf_hip.h, spmf_data_pass):
+#   acc = [ gA'(D*KP) | gV'(D*KP) | gphi(D) | tail ],  KP = K padded to 4,8,..
+#   tail = (hi,lo) float pairs of [sum x log r, sum z^2, nonfinite, 0, zsum[KP]]
+# --------------------------------------------------------------------------
+def padded_k(K):
+    kp = 4
+    while kp < K:
+        kp <<= 1
+    return kp
+
+
+def shard_accumulators(X, eta, xi_global, scale_rows, u, v, w, s):
+    """fp32 packed accumulators of ONE row shard, one sample."""
+    X = X.tocsr().astype(np.float64)
+    B, D = X.shape
+    K = u.shape[1]
+    KP = padded_k(K)
+    eta = np.broadcast_to(np.asarray(eta, dtype=np.float64).reshape(-1), (D,))
+    T = s[0] + s[1]
+    Ap = (s[0] / T)[:, None] * u / eta[:, None]
+    Vp = (v * eta[None, :]).T
+    phi = eta * (s[1] / T) * w.reshape(D)
+    rowsum = np.asarray(X.sum(1)).reshape(B)
+    xi = rowsum / xi_global if scale_rows else np.ones(B)
+    z = (X @ Ap) * xi[:, None]
+    rows = np.repeat(np.arange(B), np.diff(X.indptr))
+    r = np.einsum("nk,nk->n", z[rows], Vp[X.indices]) + phi[X.indices]
+    c = X.data / r
+    C = sp.csr_matrix((c, X.indices, X.indptr), shape=(B, D))
+    veta = Vp.sum(0)
+    gz = C @ Vp - veta[None, :] - z
+    gVp = np.zeros((D, KP)); gVp[:, :K] = C.T @ z
+    gAp = np.zeros((D, KP)); gAp[:, :K] = X.T @ (gz * xi[:, None])
+    gphi = np.asarray(C.sum(0)).reshape(D)
+    zsum = np.zeros(KP); zsum[:K] = z.sum(0)
+    scal = np.concatenate([[(X.data * np.log(r)).sum(), (z * z).sum(), 0.0, 0.0], zsum])
+    hi = scal.astype(np.float32)
+    lo = (scal - hi.astype(np.float64)).astype(np.float32)
+    tail = np.stack([hi, lo], 1).reshape(-1)
+    return np.concatenate([gAp.reshape(-1), gVp.reshape(-1), gphi, tail]).astype(np.float32)
+
+
+def finish_from_acc(acc, B_global, lgamma_sum, eta, u, v, w, s):
+    """Numpy restatement of the finish kernel's data-term chain: packed
+    accumulators (after the all-reduce) -> parts x, z and d/d(u,v,w,s)."""
+    D, K = u.shape
+    KP = padded_k(K)
+    eta = np.broadcast_to(np.asarray(eta, dtype=np.float64).reshape(-1), (D,))
+    acc = acc.astype(np.float64)
+    gAp = acc[:D * KP].reshape(D, KP)[:, :K]
+    gVp = acc[D * KP:2 * D * KP].reshape(D, KP)[:, :K]
+    gphi_acc = acc[2 * D * KP:2 * D * KP + D]
+    tail = acc[2 * D * KP + D:].reshape(-1, 2).sum(1)
+    llx, zsq, zsum = tail[0], tail[1], tail[4:4 + K]
+    T = s[0] + s[1]
+    w1, w2 = s[0] / T, s[1] / T
+    Vp = (v * eta[None, :]).T
+    phi = eta * w2 * w.reshape(D)
+    part_x = llx - lgamma_sum - (zsum @ Vp.sum(0) + B_global * phi.sum())
+    part_z = B_global * K * HALF_LOG_2_OVER_PI - 0.5 * zsq
+    gA = gAp / eta[:, None]
+    gu = w1[:, None] * gA
+    gv = ((gVp - zsum[None, :]) * eta[:, None]).T
+    dphi = gphi_acc - B_global
+    gw = (eta * w2 * dphi)[None, :]
+    GA, Gphi = (u * gA).sum(1), eta * w.reshape(D) * dphi
+    gs = np.stack([(GA - Gphi) * s[1] / T ** 2, (Gphi - GA) * s[0] / T ** 2])
+    return {"x": part_x, "z": part_z, "grads": {"u": gu, "v": gv, "w": gw, "s": gs}}

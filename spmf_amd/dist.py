@@ -1,0 +1,63 @@
+"""Row-sharded data parallelism for the hot path.
+
+The energy's data term and z-prior are sums over rows (poisson.py:604,
+617-618); priors depend only on replicated parameters.  So: contiguous row
+shards of the count matrix, one process per GPU, and ONE sum all-reduce per
+step over the packed fp32 accumulators the data pass leaves in the workspace
+(``[gA' | gV' | gphi | fp64 scalars as (hi,lo) pairs]``), after which every
+rank runs the finish kernel redundantly.  The reference has no counterpart
+(only the ``strategy`` pass-through, poisson.py:60,72).
+
+``torch.distributed`` is transport only: backend "nccl" is RCCL over xGMI on
+the GPU box, "gloo" drives the CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total_rows: int, world: int, rank: int, granule: int = 1):
+    """Contiguous [r0, r1) of this rank; shard edges fall on multiples of
+    ``granule`` rows (generator chunks / panels) and cover every row once."""
+    units = -(-total_rows // granule)
+    u0 = units * rank // world
+    u1 = units * (rank + 1) // world
+    return min(total_rows, u0 * granule), min(total_rows, u1 * granule)
+
+
+class ShardReducer:
+    """Holds the global batch constants and performs the per-step all-reduce."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rows_global = None
+        self.lgamma_global = None
+
+    def reduce_stats(self, colsum, colnnz, rows, lgamma_sum):
+        """compute_scales' one-time reduction (poisson.py:118-135 across
+        shards): sums colsum/colnnz in place, returns global (rows, lgamma)."""
+        tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64,
+                           device=colsum.device)
+        if self.world > 1:
+            for t in (colsum, colnnz, tot):
+                dist.all_reduce(t, group=self.group)
+        self.rows_global = int(round(float(tot[0])))
+        self.lgamma_global = float(tot[1])
+        return self.rows_global, self.lgamma_global
+
+    def set_batch_totals(self, rows_global, lgamma_global):
+        self.rows_global, self.lgamma_global = int(rows_global), float(lgamma_global)
+
+    def __call__(self, acc, rows, lgamma_sum):
+        """all_reduce hook of PoissonFactorization.energy_and_grads."""
+        if self.world > 1:
+            dist.all_reduce(acc, group=self.group)
+        if self.rows_global is None:
+            tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64,
+                               device=acc.device)
+            if self.world > 1:
+                dist.all_reduce(tot, group=self.group)
+            return int(round(float(tot[0]))), float(tot[1])
+        return self.rows_global, self.lgamma_global

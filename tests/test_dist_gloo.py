@@ -1,0 +1,99 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank owns a row shard, produces
+the packed accumulators (here by the numpy restatement, since the HIP data
+pass needs a GPU), the product's ShardReducer all-reduces them, and the
+finished energy/gradients must equal the unsharded fp64 oracle."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import spmf_oracle as O
+from oracle import sparse_exact as SE
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    rng = np.random.default_rng(77)
+    B, D, K = 90, 31, 5
+    x = ((rng.random((B, D)) < 0.25) * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(B * D))
+    cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = 3.7
+    params = O.random_params(cfg, 1, 78)
+    return cfg, x, params
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spmf_amd.dist import ShardReducer, shard_bounds
+    cfg, x, params = _problem()
+    r0, r1 = shard_bounds(x.shape[0], world, rank, granule=16)
+    one = {k: v[0] for k, v in params.items()}
+    eta = cfg.eta_i.numpy().reshape(-1)
+    xs = sp.csr_matrix(x[r0:r1])
+    acc = torch.from_numpy(SE.shard_accumulators(xs, eta, cfg.xi_u_global, True,
+                                                 one["u"], one["v"], one["w"], one["s"]))
+    from scipy.special import gammaln
+    lg = float(gammaln(xs.data + 1.0).sum())
+    red = ShardReducer()
+    colsum = torch.from_numpy(np.asarray(xs.sum(0)).reshape(-1).copy())
+    colnnz = torch.from_numpy(np.asarray((xs > 0).sum(0)).reshape(-1).astype(np.float64))
+    rows_g, lg_g = red.reduce_stats(colsum, colnnz, r1 - r0, lg)
+    rg2, lg2 = red(acc, r1 - r0, lg)
+    assert (rg2, lg2) == (rows_g, lg_g)
+    out = SE.finish_from_acc(acc.numpy(), rows_g, lg_g, eta, one["u"], one["v"], one["w"], one["s"])
+    if rank == 0:
+        q.put((r0, r1, rows_g, colsum.numpy(), out["x"], out["z"],
+               {k: v for k, v in out["grads"].items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_rows_once():
+    from spmf_amd.dist import shard_bounds
+    for total, world, g in [(1000, 8, 125), (90, 2, 16), (7, 4, 1), (1_000_000, 8, 125_000),
+                            (100, 3, 64)]:
+        edges = [shard_bounds(total, world, r, g) for r in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == total
+        for a, b in zip(edges[:-1], edges[1:]):
+            assert a[1] == b[0]
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo_allreduce_matches_unsharded_oracle():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=100)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0, r1, rows_g, colsum, px, pz, grads = res
+    cfg, x, params = _problem()
+    assert rows_g == x.shape[0] and (r0, r1) == (0, 48)
+    np.testing.assert_allclose(colsum, x.sum(0), rtol=1e-12)
+    parts, _, groups = O.energy_and_grads(cfg, x, params)
+    # accumulators travel as fp32 (that is the wire format): 1e-5 tolerance
+    np.testing.assert_allclose(px, parts["x"][0].item(), rtol=1e-5)
+    np.testing.assert_allclose(pz, parts["z"][0].item(), rtol=1e-5)
+    for k, g in grads.items():
+        ref = groups["data"][k][0].numpy()
+        assert np.abs(g - ref).max() <= 1e-5 * np.abs(ref).max(), k
