@@ -4,6 +4,7 @@
 // synchronisation on the hot path (timing taps excepted, off by default).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -18,6 +19,7 @@ struct spmf_ctx {
   int device = 0, K = 0, D = 0, KP = 0;
   unsigned flags = 0;
   double u_tau_scale = 0.01, s_tau_scale = 1.0, decay = 0.99;  // poisson.py:59
+  int panels_per_wave = 1;
   // workspace carve
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -99,6 +101,7 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   c->D = D;
   c->KP = padded_k(K);
   c->flags = flags;
+  if (const char* e = getenv("SPMF_PANELS_PER_WAVE")) c->panels_per_wave = atoi(e);
   *out = c;
   return SPMF_OK;
 }
@@ -251,7 +254,7 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
     if (ct->n_rows > 0 && ct->nnz > 0) {
-      ColArgs ca{D, ct->n_panels, ct->row_base, ct->pc_ptr, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, acc + (size_t)D * KP, acc + (size_t)2 * D * KP};
+      ColArgs ca{D, ct->n_panels, ct->row_base, c->panels_per_wave, ct->pc_ptr, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, acc + (size_t)D * KP, acc + (size_t)2 * D * KP};
       launch_col_pass(KP, ca, st);
     }
     PackArgs pk{KP, dacc, acc + (size_t)2 * D * KP + D};

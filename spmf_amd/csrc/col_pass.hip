@@ -39,7 +39,11 @@
 
 namespace spmf {
 
-template <int KP>
+#ifndef COL_GRP
+#define COL_GRP 4
+#endif
+
+template <int KP, int TP>
 __global__ __launch_bounds__(256) void col_pass_kernel(
     int D, int n_panels, int row_base, const int32_t* __restrict__ pc_ptr,
     const int32_t* __restrict__ pc_row, const float* __restrict__ pc_val,
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     float* __restrict__ gphi) {
   constexpr int LPN = KP / 4;
   constexpr int NG = 64 / LPN;                  // columns per wave
-  constexpr int GRP = LPN < 4 ? LPN : 4;        // entries gathered back to back
+  constexpr int GRP = LPN < COL_GRP ? LPN : COL_GRP;  // entries gathered back to back
   __shared__ __attribute__((aligned(16))) float stage[4][NG][2 * KP];
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPN, grp = lane / LPN;
@@ -59,20 +63,24 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
   const int64_t q = L >> 3;
   const int ncbb = (D + 4 * NG - 1) / (4 * NG);
   const int t = (int)(q / ncbb), cbb = (int)(q % ncbb);
-  const int p = 8 * t + x;
-  if (p >= n_panels) return;                    // block-uniform
+  // super-panel = TP consecutive panels walked in order by the same wave
+  const int p0 = (8 * t + x) * TP;
+  if (p0 >= n_panels) return;                   // block-uniform
   const int d0 = (cbb * 4 + wid) * NG;
   const int d = d0 + grp;
   const bool colok = d < D;
 
-  int cur = 0, end = 0;
-  if (colok) {
-    const int64_t pb = (int64_t)p * (D + 1) + d;
-    cur = pc_ptr[pb];
-    end = pc_ptr[pb + 1];
+  int seg_s[TP], seg_e[TP];
+#pragma unroll
+  for (int i = 0; i < TP; ++i) {
+    seg_s[i] = seg_e[i] = 0;
+    if (colok && p0 + i < n_panels) {
+      const int64_t pb = (int64_t)(p0 + i) * (D + 1) + d;
+      seg_s[i] = pc_ptr[pb];
+      seg_e[i] = pc_ptr[pb + 1];
+    }
   }
-  const float4* z4 = reinterpret_cast<const float4*>(z);
-  const float4* g4 = reinterpret_cast<const float4*>(gzs);
+  int cur = seg_s[0], end = seg_e[0], seg = 1;
   const float4 vp = colok ? reinterpret_cast<const float4*>(Vp)[(size_t)d * LPN + sub]
                           : make_float4(0.f, 0.f, 0.f, 0.f);
   const float ph = colok ? phi[d] : 1.f;
@@ -80,7 +88,14 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
   float gph = 0.f;
 
   auto fetch = [&](int& rr_, float& xx_, int& cnt_) {
-    cnt_ = min(LPN, end - cur);                 // 0 once the list is exhausted
+#pragma unroll
+    for (int i = 1; i < TP; ++i)                // next non-empty list of the super-panel
+      if (cur == end && seg == i) {
+        cur = seg_s[i];
+        end = seg_e[i];
+        seg = i + 1;
+      }
+    cnt_ = min(LPN, end - cur);                 // 0 once the lists are exhausted
     const int e = cur + sub;
     rr_ = sub < cnt_ ? pc_row[e] - row_base : 0;
     xx_ = sub < cnt_ ? pc_val[e] : 0.f;
@@ -105,14 +120,14 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
           const int src = grp * LPN + g0 + j;
           const int b = __shfl(rr0, src);
           xv[j] = __shfl(xx0, src);
-          zz[j] = z4[(size_t)b * LPN + sub];
-          gg[j] = g4[(size_t)b * LPN + sub];
+          zz[j] = gather4<LPN>(z, b, sub);
+          gg[j] = gather4<LPN>(gzs, b, sub);
         }
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
           const float r = group_sum<LPN>(dot4(zz[j], vp)) + ph;
-          const float cbv =
-              (xv[j] > 0.f && r > 0.f && r < INFINITY) ? __fdividef(xv[j], r) : 0.f;
+          // r <= 0 / NaN cells were counted by the row pass; +inf gives 0
+          const float cbv = r > 0.f ? xv[j] * __builtin_amdgcn_rcpf(r) : 0.f;
           gV = fma4(cbv, zz[j], gV);
           gA = fma4(xv[j], gg[j], gA);
           gph += cbv;
@@ -146,11 +161,18 @@ template <int KP>
 static void launch_col_t(const ColArgs& a, hipStream_t st) {
   constexpr int NG = 64 / (KP / 4);
   const int64_t ncbb = (a.D + 4 * NG - 1) / (4 * NG);
-  const int64_t nt = (a.n_panels + 7) / 8;
+  const int tp = a.panels_per_wave >= 4 ? 4 : (a.panels_per_wave >= 2 ? 2 : 1);
+  const int64_t nsp = (a.n_panels + tp - 1) / tp;   // super-panels
+  const int64_t nt = (nsp + 7) / 8;
   const int64_t nb = nt * ncbb * 8;
-  hipLaunchKernelGGL(col_pass_kernel<KP>, dim3((unsigned)nb), dim3(256), 0, st, a.D, a.n_panels,
-                     a.row_base, a.pc_ptr, a.pc_row, a.pc_val, a.Vp, a.phi, a.z, a.gzs, a.gAp,
-                     a.gVp, a.gphi);
+#define SPMF_COL_LAUNCH(TP_)                                                                  \
+  hipLaunchKernelGGL((col_pass_kernel<KP, TP_>), dim3((unsigned)nb), dim3(256), 0, st, a.D,   \
+                     a.n_panels, a.row_base, a.pc_ptr, a.pc_row, a.pc_val, a.Vp, a.phi, a.z,  \
+                     a.gzs, a.gAp, a.gVp, a.gphi)
+  if (tp == 4) SPMF_COL_LAUNCH(4);
+  else if (tp == 2) SPMF_COL_LAUNCH(2);
+  else SPMF_COL_LAUNCH(1);
+#undef SPMF_COL_LAUNCH
 }
 
 void launch_col_pass(int KP, const ColArgs& a, hipStream_t st) {

@@ -40,6 +40,16 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
+// Gather the `sub`-th float4 of row `row` of a [rows, 4*LPN]-float table with
+// a 32-bit byte offset (tables are < 4 GiB, checked on the host): lets the
+// compiler use the saddr + 32-bit voffset form instead of 64-bit VALU
+// address arithmetic per gather.
+template <int LPN>
+__device__ __forceinline__ float4 gather4(const float* __restrict__ base, int row, int sub) {
+  const uint32_t off = ((uint32_t)row * (uint32_t)LPN + (uint32_t)sub) * 16u;
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
+}
+
 // ---- DPP cross-lane adds (no LDS traffic, fold into v_add_f32_dpp) --------
 // ctrl: quad_perm[1,0,3,2]=0xB1 (xor 1), quad_perm[2,3,0,1]=0x4E (xor 2),
 // row_half_mirror=0x141 (i <-> 7-i), row_mirror=0x140 (i <-> 15-i),

@@ -29,6 +29,7 @@ void launch_row_pass(int KP, const RowArgs& a, hipStream_t st);
 
 struct ColArgs {
   int D, n_panels, row_base;
+  int panels_per_wave;  // 1, 2 or 4 consecutive panels accumulated before the atomics
   const int32_t* pc_ptr;
   const int32_t* pc_row;
   const float* pc_val;

@@ -38,8 +38,8 @@ struct RowCtx {
   static constexpr int LPN = KP / 4;
   static constexpr int NPI = 64 / LPN;
   static constexpr int GRP = LPN < 4 ? LPN : 4;  // gathers issued back to back
-  const float4* Ap4;
-  const float4* Vp4;
+  const float* Ap;
+  const float* Vp;
   const float* phi;
   int lane, sub, grp;
 
@@ -55,7 +55,7 @@ struct RowCtx {
           const int src = (g0 + j) * NPI + grp;
           const int d = __shfl(c, src);
           xv[j] = __shfl(x, src);
-          a[j] = Ap4[(size_t)d * LPN + sub];
+          a[j] = gather4<LPN>(Ap, d, sub);
         }
 #pragma unroll
         for (int j = 0; j < GRP; ++j) zacc = fma4(xv[j], a[j], zacc);
@@ -74,7 +74,7 @@ struct RowCtx {
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
           const int d = __shfl(c, (g0 + j) * NPI + grp);
-          vv[g0 + j] = Vp4[(size_t)d * LPN + sub];
+          vv[g0 + j] = gather4<LPN>(Vp, d, sub);
         }
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
@@ -95,7 +95,7 @@ struct RowCtx {
       const float r = rmine + phi[cs];
       if (r > 0.f && r < INFINITY) {
         ll = fmaf(xs, logf(r), ll);
-        cc = __fdividef(xs, r);
+        cc = xs * __builtin_amdgcn_rcpf(r);
       } else {
         nnf += 1.0;
       }
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void row_pass_kernel(
     double* __restrict__ dacc, int encode_only) {
   constexpr int LPN = KP / 4;
   RowCtx<KP> cx;
-  cx.Ap4 = reinterpret_cast<const float4*>(Ap);
-  cx.Vp4 = reinterpret_cast<const float4*>(Vp);
+  cx.Ap = Ap;
+  cx.Vp = Vp;
   cx.phi = phi;
   cx.lane = threadIdx.x & 63;
   cx.sub = cx.lane % LPN;
