@@ -97,7 +97,9 @@ def main():
                          "torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # launched by torch.distributed.run (also with one rank: exercises RCCL)
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if distributed:
         dist.init_process_group("nccl", device_id=dev)
 
     rows, D, density, K, desc = WORKLOADS[args.workload]
@@ -124,7 +126,7 @@ def main():
     sc.compute_stats(model._handle(), colsum, colnnz)
     tot = torch.tensor([float(sc.n_rows), float(sc.row_lgamma.sum()), float(sc.nnz)],
                        dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         for t in (colsum, colnnz, tot):
             dist.all_reduce(t)
     cm = colsum / colnnz
@@ -136,16 +138,16 @@ def main():
     gen_seed = 20241218
     torch.manual_seed(gen_seed)
     params = model.surrogate_distribution.sample(S)
-    if world > 1:
+    if distributed:
         for n in _lib.VAR_ORDER:            # replicate rank 0's draw
             dist.broadcast(params[n], 0)
     batch = {"counts": sc}
 
     hook = None
-    if world > 1:
-        def hook(acc, r, lg):
-            dist.all_reduce(acc)
-            return rows_g, lgam_g
+    if distributed:
+        from spmf_amd.dist import ShardReducer
+        hook = ShardReducer()
+        hook.set_batch_totals(rows_g, lgam_g)
 
     lib, h = _lib.load(), model._handle()
 
@@ -155,7 +157,7 @@ def main():
     for _ in range(args.warmup):
         parts, grads, nnf = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     lib.spmf_ctx_enable_timing(h, 1)       # hipEvents between kernels, no syncs
     torch.cuda.synchronize()
@@ -163,7 +165,7 @@ def main():
     for _ in range(args.steps):
         parts, grads, nnf = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -172,7 +174,7 @@ def main():
     _lib.check(h, lib.spmf_last_timing(h, ms5), "spmf_last_timing")
     lib.spmf_ctx_enable_timing(h, 0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
 
@@ -224,7 +226,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -31,7 +31,8 @@ class ShardReducer:
 
     def __init__(self, group=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized()      # also with one rank (exercises the transport)
+        self.world = dist.get_world_size(group) if self.active else 1
         self.rows_global = None
         self.lgamma_global = None
 
@@ -40,7 +41,7 @@ class ShardReducer:
         shards): sums colsum/colnnz in place, returns global (rows, lgamma)."""
         tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64,
                            device=colsum.device)
-        if self.world > 1:
+        if self.active:
             for t in (colsum, colnnz, tot):
                 dist.all_reduce(t, group=self.group)
         self.rows_global = int(round(float(tot[0])))
@@ -52,12 +53,12 @@ class ShardReducer:
 
     def __call__(self, acc, rows, lgamma_sum):
         """all_reduce hook of PoissonFactorization.energy_and_grads."""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(acc, group=self.group)
         if self.rows_global is None:
             tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64,
                                device=acc.device)
-            if self.world > 1:
+            if self.active:
                 dist.all_reduce(tot, group=self.group)
             return int(round(float(tot[0]))), float(tot[1])
         return self.rows_global, self.lgamma_global
