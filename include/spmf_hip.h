@@ -56,7 +56,7 @@ extern "C" {
 
 /* flags for spmf_ctx_create */
 #define SPMF_FLAG_SCALE_ROWS 1u     /* poisson.py:61,644-649 */
-#define SPMF_FLAG_LOG_TRANSFORM 2u  /* poisson.py:41-42,52-53 (dense path only) */
+#define SPMF_FLAG_LOG_TRANSFORM 2u  /* poisson.py:41-42,52-53: sparse stored-cell terms + dense f32-MFMA exp sums */
 
 typedef struct spmf_ctx spmf_ctx;
 
@@ -81,6 +81,10 @@ typedef struct spmf_counts {
   const int32_t* pc_row;    /* base pointer: row id (row_base + batch row) */
   const float* pc_val;      /* base pointer */
   double lgamma_sum;        /* sum over the batch of lgamma(x+1) (parameter free) */
+  /* log_transform only (poisson.py:41-42): g(x) = log(x/eta + 1) per stored
+   * entry, in CSR and in panel-CSC order (base pointers); NULL otherwise. */
+  const float* gval;
+  const float* pc_gval;
 } spmf_counts;
 
 int spmf_version(void);

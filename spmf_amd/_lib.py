@@ -37,6 +37,7 @@ class CountsStruct(C.Structure):
         ("row_scale", C.c_void_p),
         ("pc_ptr", C.c_void_p), ("pc_row", C.c_void_p), ("pc_val", C.c_void_p),
         ("lgamma_sum", C.c_double),
+        ("gval", C.c_void_p), ("pc_gval", C.c_void_p),
     ]
 
 

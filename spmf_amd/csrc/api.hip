@@ -28,7 +28,7 @@ struct spmf_ctx {
   float* acc = nullptr;
   double* dacc = nullptr;
   double* dprep = nullptr;
-  float *Ap = nullptr, *Vp = nullptr, *phi = nullptr, *z = nullptr, *gzs = nullptr;
+  float *Ap = nullptr, *Vp = nullptr, *phi = nullptr, *z = nullptr, *gzs = nullptr, *gzd = nullptr;
   // timing taps
   int timing = 0;
   static constexpr int kSets = 64;  // ring of event sets: no sync inside a timed loop
@@ -69,7 +69,7 @@ static size_t var_size(const spmf_ctx* c, int i) {
 }
 
 struct Carve {
-  size_t acc, dacc, dprep, Ap, Vp, phi, z, gzs, total;
+  size_t acc, dacc, dprep, Ap, Vp, phi, z, gzs, gzd, total;
 };
 static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   Carve k;
@@ -83,6 +83,7 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.phi = o;   o += al(D * sizeof(float));
   k.z = o;     o += al((size_t)rows * KP * sizeof(float));
   k.gzs = o;   o += al((size_t)rows * KP * sizeof(float));
+  k.gzd = o;   if (c->flags & SPMF_FLAG_LOG_TRANSFORM) o += al((size_t)rows * KP * sizeof(float));
   k.total = o;
   return k;
 }
@@ -100,6 +101,8 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   c->K = K;
   c->D = D;
   c->KP = padded_k(K);
+  // the dense exp kernels of the log_transform decoder work on 32-feature MFMA tiles
+  if ((flags & SPMF_FLAG_LOG_TRANSFORM) && c->KP < 32) c->KP = 32;
   c->flags = flags;
   if (const char* e = getenv("SPMF_PANELS_PER_WAVE")) c->panels_per_wave = atoi(e);
   *out = c;
@@ -157,6 +160,7 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   c->phi = (float*)(c->ws + k.phi);
   c->z = (float*)(c->ws + k.z);
   c->gzs = (float*)(c->ws + k.gzs);
+  c->gzd = (float*)(c->ws + k.gzd);
   c->ws_rows = rows;
   c->ws_S = S;
   return SPMF_OK;
@@ -221,8 +225,9 @@ int spmf_counts_stats(spmf_ctx* c, int64_t n_rows, const int32_t* row_ptr, const
 
 int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, void* stream) {
   if (!c || !params || !eta || S < 1) return fail(c, SPMF_E_ARG, "data_pass: bad arguments");
-  if (c->flags & SPMF_FLAG_LOG_TRANSFORM) return fail(c, SPMF_E_UNSUPPORTED, "log_transform has no sparse closed form; use the dense path");
+  const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0;
   int rc = check_counts(c, ct);
+  if (!rc && logt && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG, "counts: log_transform needs gval / pc_gval");
   if (rc) return rc;
   if (ct->n_rows > 0 && ct->nnz > 0 && (!ct->pc_ptr || !ct->pc_row || !ct->pc_val || ct->n_panels < 1)) return fail(c, SPMF_E_ARG, "counts: panel-CSC arrays missing");
   for (int i : {0, 1, 2, 7})
@@ -245,16 +250,32 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
     double* dacc = c->dacc + (size_t)s * (kDaccHead + KP);
     double* dprep = c->dprep + (size_t)s * (KP + 1);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
-    PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep};
+    PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt};
     launch_prep(KP, pa, st);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
-    if (ct->n_rows > 0) {
-      RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 0};
+    const float* rscale = (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr;
+    float* gVp = acc + (size_t)D * KP;
+    if (ct->n_rows > 0 && !logt) {
+      RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 0, 0, nullptr};
       launch_row_pass(KP, ra, st);
+    } else if (ct->n_rows > 0) {
+      // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
+      // cores, then the stored-cell terms (sweep 2) with the dense row term.
+      RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, ct->gval, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 1, 1, nullptr};
+      launch_row_pass(KP, r1, st);
+      ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0};
+      launch_expdot(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E
+      int chunks = (int)((ct->n_rows / 128 + 511) / 512);
+      if (chunks < 1) chunks = 1;
+      if (chunks > 64) chunks = 64;
+      ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, chunks, 1};
+      launch_expdot(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+      RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 2, 1, c->gzd};
+      launch_row_pass(KP, r2, st);
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
     if (ct->n_rows > 0 && ct->nnz > 0) {
-      ColArgs ca{D, ct->n_panels, ct->row_base, c->panels_per_wave, ct->pc_ptr, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, acc + (size_t)D * KP, acc + (size_t)2 * D * KP};
+      ColArgs ca{D, ct->n_panels, ct->row_base, c->panels_per_wave, ct->pc_ptr, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, gVp, acc + (size_t)2 * D * KP, logt, ct->pc_gval};
       launch_col_pass(KP, ca, st);
     }
     PackArgs pk{KP, dacc, acc + (size_t)2 * D * KP + D};
@@ -286,7 +307,7 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
       P[i] = params[i] + s * var_size(c, i);
       G[i] = grads[i] + s * var_size(c, i);
     }
-    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr};
+    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0};
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
     launch_finish(KP, fa, st);
     if (tm) {
@@ -309,17 +330,18 @@ int spmf_elbo_fwd_bwd(spmf_ctx* c, const spmf_counts* ct, int S, double prior_we
 
 int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* s, const float* eta, float* z_out, void* stream) {
   if (!c || !u || !s || !eta || !z_out) return fail(c, SPMF_E_ARG, "encode: bad arguments");
-  if (c->flags & SPMF_FLAG_LOG_TRANSFORM) return fail(c, SPMF_E_UNSUPPORTED, "encode: log_transform needs g(x) values; not in the sparse path yet");
+  const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0;
   int rc = check_counts(c, ct);
+  if (!rc && logt && ct->nnz > 0 && !ct->gval) rc = fail(c, SPMF_E_ARG, "encode: log_transform needs counts.gval");
   if (rc) return rc;
   if (ct->n_rows == 0) return SPMF_OK;
   rc = bind_ws(c, ct->n_rows, 1);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(c, hipMemsetAsync(c->dprep, 0, (c->KP + 1) * sizeof(double), st));
-  PrepArgs pa{c->D, c->K, u, nullptr, nullptr, s, eta, c->Ap, c->Vp, c->phi, c->dprep};
+  PrepArgs pa{c->D, c->K, u, nullptr, nullptr, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt};
   launch_prep(c->KP, pa, st);
-  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1};
+  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr};
   launch_row_pass(c->KP, ra, st);
   HIPCHK(c, hipMemcpy2DAsync(z_out, (size_t)c->K * sizeof(float), c->z, (size_t)c->KP * sizeof(float), (size_t)c->K * sizeof(float), (size_t)ct->n_rows, hipMemcpyDeviceToDevice, st));
   HIPCHK(c, hipGetLastError());

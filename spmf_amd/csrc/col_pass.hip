@@ -43,13 +43,13 @@ namespace spmf {
 #define COL_GRP 4
 #endif
 
-template <int KP, int TP>
+template <int KP, int TP, bool LOGT>
 __global__ __launch_bounds__(256) void col_pass_kernel(
     int D, int n_panels, int row_base, const int32_t* __restrict__ pc_ptr,
     const int32_t* __restrict__ pc_row, const float* __restrict__ pc_val,
     const float* __restrict__ Vp, const float* __restrict__ phi, const float* __restrict__ z,
     const float* __restrict__ gzs, float* __restrict__ gAp, float* __restrict__ gVp,
-    float* __restrict__ gphi) {
+    float* __restrict__ gphi, const float* __restrict__ pc_gval) {
   constexpr int LPN = KP / 4;
   constexpr int NG = 64 / LPN;                  // columns per wave
   constexpr int GRP = LPN < COL_GRP ? LPN : COL_GRP;  // entries gathered back to back
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
   float4 gV = make_float4(0.f, 0.f, 0.f, 0.f), gA = gV;
   float gph = 0.f;
 
-  auto fetch = [&](int& rr_, float& xx_, int& cnt_) {
+  auto fetch = [&](int& rr_, float& xx_, float& gx_, int& cnt_) {
 #pragma unroll
     for (int i = 1; i < TP; ++i)                // next non-empty list of the super-panel
       if (cur == end && seg == i) {
@@ -99,43 +99,47 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     const int e = cur + sub;
     rr_ = sub < cnt_ ? pc_row[e] - row_base : 0;
     xx_ = sub < cnt_ ? pc_val[e] : 0.f;
+    gx_ = (LOGT && sub < cnt_) ? pc_gval[e] : 0.f;   // g(x) = log(x/eta+1), data side
     cur += cnt_;
   };
 
   int rr0, cnt0, rr1, cnt1;
-  float xx0, xx1;
-  fetch(rr0, xx0, cnt0);
-  fetch(rr1, xx1, cnt1);
+  float xx0, xx1, gx0, gx1;
+  fetch(rr0, xx0, gx0, cnt0);
+  fetch(rr1, xx1, gx1, cnt1);
   while (__any(cnt0 > 0)) {
     int rr2, cnt2;
-    float xx2;
-    fetch(rr2, xx2, cnt2);                      // two fetches ahead of use
+    float xx2, gx2;
+    fetch(rr2, xx2, gx2, cnt2);                 // two fetches ahead of use
 #pragma unroll
     for (int g0 = 0; g0 < LPN; g0 += GRP) {
       if (__any(cnt0 > g0)) {                   // wave-uniform
         float4 zz[GRP], gg[GRP];
-        float xv[GRP];
+        float xv[GRP], gv[GRP];
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
           const int src = grp * LPN + g0 + j;
           const int b = __shfl(rr0, src);
           xv[j] = __shfl(xx0, src);
+          gv[j] = LOGT ? __shfl(gx0, src) : xv[j];
           zz[j] = gather4<LPN>(z, b, sub);
           gg[j] = gather4<LPN>(gzs, b, sub);
         }
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
-          const float r = group_sum<LPN>(dot4(zz[j], vp)) + ph;
+          const float y = group_sum<LPN>(dot4(zz[j], vp));
+          const float ey = LOGT ? expf(y) : 1.f;
+          const float r = (LOGT ? ey - 1.f : y) + ph;
           // r <= 0 / NaN cells were counted by the row pass; +inf gives 0
-          const float cbv = r > 0.f ? xv[j] * __builtin_amdgcn_rcpf(r) : 0.f;
-          gV = fma4(cbv, zz[j], gV);
-          gA = fma4(xv[j], gg[j], gA);
-          gph += cbv;
+          const float xr = r > 0.f ? xv[j] * __builtin_amdgcn_rcpf(r) : 0.f;
+          gV = fma4(LOGT ? xr * ey : xr, zz[j], gV);
+          gA = fma4(gv[j], gg[j], gA);
+          gph += xr;
         }
       }
     }
-    rr0 = rr1; xx0 = xx1; cnt0 = cnt1;
-    rr1 = rr2; xx1 = xx2; cnt1 = cnt2;
+    rr0 = rr1; xx0 = xx1; gx0 = gx1; cnt0 = cnt1;
+    rr1 = rr2; xx1 = xx2; gx1 = gx2; cnt1 = cnt2;
   }
   // ---- transpose through LDS so each atomic instruction covers whole rows --
   float4* st4 = reinterpret_cast<float4*>(&stage[wid][grp][0]);
@@ -161,17 +165,18 @@ template <int KP>
 static void launch_col_t(const ColArgs& a, hipStream_t st) {
   constexpr int NG = 64 / (KP / 4);
   const int64_t ncbb = (a.D + 4 * NG - 1) / (4 * NG);
-  const int tp = a.panels_per_wave >= 4 ? 4 : (a.panels_per_wave >= 2 ? 2 : 1);
+  const int tp = a.logt ? 1 : (a.panels_per_wave >= 4 ? 4 : (a.panels_per_wave >= 2 ? 2 : 1));
   const int64_t nsp = (a.n_panels + tp - 1) / tp;   // super-panels
   const int64_t nt = (nsp + 7) / 8;
   const int64_t nb = nt * ncbb * 8;
-#define SPMF_COL_LAUNCH(TP_)                                                                  \
-  hipLaunchKernelGGL((col_pass_kernel<KP, TP_>), dim3((unsigned)nb), dim3(256), 0, st, a.D,   \
-                     a.n_panels, a.row_base, a.pc_ptr, a.pc_row, a.pc_val, a.Vp, a.phi, a.z,  \
-                     a.gzs, a.gAp, a.gVp, a.gphi)
-  if (tp == 4) SPMF_COL_LAUNCH(4);
-  else if (tp == 2) SPMF_COL_LAUNCH(2);
-  else SPMF_COL_LAUNCH(1);
+#define SPMF_COL_LAUNCH(TP_, LT_)                                                              \
+  hipLaunchKernelGGL((col_pass_kernel<KP, TP_, LT_>), dim3((unsigned)nb), dim3(256), 0, st,    \
+                     a.D, a.n_panels, a.row_base, a.pc_ptr, a.pc_row, a.pc_val, a.Vp, a.phi,   \
+                     a.z, a.gzs, a.gAp, a.gVp, a.gphi, a.pc_gval)
+  if (a.logt) SPMF_COL_LAUNCH(1, true);
+  else if (tp == 4) SPMF_COL_LAUNCH(4, false);
+  else if (tp == 2) SPMF_COL_LAUNCH(2, false);
+  else SPMF_COL_LAUNCH(1, false);
 #undef SPMF_COL_LAUNCH
 }
 

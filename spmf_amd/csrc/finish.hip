@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
                                                      const double* __restrict__ dprep, Ptrs12 P,
                                                      const float* __restrict__ eta, MPtrs12 G,
                                                      double* __restrict__ parts,
-                                                     double* __restrict__ nnf_out) {
+                                                     double* __restrict__ nnf_out, int logt) {
   __shared__ float tile[KP][FTD + 1];
   __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
   __shared__ float zsum_s[KP], utau_s[KP], dec_s[KP], gutau_s[KP];
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   for (int i = 0; i < SPMF_NPARTS_LOCAL; ++i) part[i] = 0.0;
 
   if (t < KP) {
-    zsum_s[t] = (float)unpack(tail, kDaccHead + t);
+    // log_transform: the dense kernel already subtracted sum_b E_bd z_b from gV'
+    zsum_s[t] = logt ? 0.f : (float)unpack(tail, kDaccHead + t);
     utau_s[t] = t < K ? P.p[UTAU_][t] : 1.f;
     dec_s[t] = powf(decay, (float)t);
     gutau_s[t] = 0.f;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     }
     w1s[t] = w1;
     etas_[t] = e;
-    ietas[t] = 1.f / e;
+    ietas[t] = logt ? 1.f : 1.f / e;   // A' = w1*u/eta (linear) or w1*u (log_transform)
     GAs[t] = 0.f;
   }
   __syncthreads();
@@ -224,8 +225,12 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   }
   if (blockIdx.x == 0 && t == 0) {
     const double llx = unpack(tail, 0), zsq = unpack(tail, 1);
+    // sum of the rate over ALL cells: closed form (linear) or the dense exp sum
     double sum_r = Bglob * dprep[KP];
-    for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * dprep[k];
+    if (logt)
+      sum_r += unpack(tail, 3) - Bglob * (double)D;
+    else
+      for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * dprep[k];
     atomicAdd(&parts[13], llx - lgamma_sum - sum_r);
     atomicAdd(&parts[12], Bglob * (double)K * kHalfLog2OverPi - 0.5 * zsq);
     if (nnf_out) *nnf_out = unpack(tail, 2);
@@ -258,7 +263,7 @@ static void launch_finish_t(const FinishArgs& a, hipStream_t st) {
   const int nb = (a.D + FTD - 1) / FTD;
   hipLaunchKernelGGL(finish_kernel<KP>, dim3(nb), dim3(256), 0, st, a.D, a.K, (double)a.B_global,
                      a.lgamma_sum, (float)a.u_tau_scale, (float)a.s_tau_scale, (float)a.decay, (float)a.prior_weight,
-                     a.acc, a.dprep, P, a.eta, G, a.parts, a.n_nonfinite);
+                     a.acc, a.dprep, P, a.eta, G, a.parts, a.n_nonfinite, a.logt);
 }
 
 void launch_finish(int KP, const FinishArgs& a, hipStream_t st) {

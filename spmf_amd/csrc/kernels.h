@@ -10,6 +10,7 @@ struct PrepArgs {
   const float *u, *v, *w, *s, *eta;
   float *Ap, *Vp, *phi;
   double* dprep;  // [KP+1]: veta[KP], phisum   (zeroed by the caller)
+  int logt;       // log_transform: A' = w1*u (g(x) is data side), V' = eta*v^T
 };
 void launch_prep(int KP, const PrepArgs& a, hipStream_t st);
 
@@ -23,7 +24,9 @@ struct RowArgs {
   const double* dprep;
   float *z, *gzs;
   double* dacc;  // [kDaccHead+KP] (zeroed by the caller)
-  int encode_only;
+  int mode;            // 0 full (linear decoder), 1 sweep 1 only (encode), 2 sweep 2 only
+  int logt;            // log_transform rate r = exp(<z,V'>) - 1 + phi
+  const float* gzd;    // mode 2: per-row dense term sum_d E_bd V'_d  [B,KP]
 };
 void launch_row_pass(int KP, const RowArgs& a, hipStream_t st);
 
@@ -35,7 +38,20 @@ struct ColArgs {
   const float* pc_val;
   const float *Vp, *phi, *z, *gzs;
   float *gAp, *gVp, *gphi;  // accumulated with float atomics (zeroed by the caller)
+  int logt;
+  const float* pc_gval;     // log_transform: g(x) per panel-CSC entry
 };
+
+struct ExpdotArgs {
+  int NP, NQ;
+  const float *P, *Q;  // [NP,KD], [NQ,KD]
+  float* out;          // [NP,KD]
+  float sign;
+  double* esum;        // may be null
+  int q_chunks;        // gridDim.y; >1 needs atomic_out
+  int atomic_out;
+};
+void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st);
 void launch_col_pass(int KP, const ColArgs& a, hipStream_t st);
 
 struct PackArgs {
@@ -57,6 +73,7 @@ struct FinishArgs {
   float* const* grads;  // 12 device pointers (this draw)
   double* parts;        // [14] (zeroed by the caller)
   double* n_nonfinite;  // [1] or null
+  int logt;
 };
 void launch_finish(int KP, const FinishArgs& a, hipStream_t st);
 

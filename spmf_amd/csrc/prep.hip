@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void prep_kernel(int D, int K, const float* __
                                                    const float* __restrict__ eta,
                                                    float* __restrict__ Ap, float* __restrict__ Vp,
                                                    float* __restrict__ phi,
-                                                   double* __restrict__ dprep) {
+                                                   double* __restrict__ dprep, int logt) {
   __shared__ float tile[KP][TD + 1];
   __shared__ float w1ie[TD], etas[TD];
   __shared__ double red[16];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void prep_kernel(int D, int K, const float* __
       e = eta[d];
       const float s0 = s[d], s1 = s[D + d];
       const float T = s0 + s1;
-      a = (s0 / T) / e;
+      a = logt ? (s0 / T) : (s0 / T) / e;
       const float p = w ? e * (s1 / T) * w[d] : 0.f;
       phi[d] = p;
       phi_local = (double)p;
@@ -85,7 +85,7 @@ template <int KP>
 static void launch_prep_t(const PrepArgs& a, hipStream_t st) {
   const int nb = (a.D + TD - 1) / TD;
   hipLaunchKernelGGL(prep_kernel<KP>, dim3(nb), dim3(256), 0, st, a.D, a.K, a.u, a.v, a.w, a.s,
-                     a.eta, a.Ap, a.Vp, a.phi, a.dprep);
+                     a.eta, a.Ap, a.Vp, a.phi, a.dprep, a.logt);
 }
 
 void launch_prep(int KP, const PrepArgs& a, hipStream_t st) {

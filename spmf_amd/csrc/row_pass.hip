@@ -33,7 +33,7 @@ namespace spmf {
 
 namespace {
 
-template <int KP>
+template <int KP, bool LOGT>
 struct RowCtx {
   static constexpr int LPN = KP / 4;
   static constexpr int NPI = 64 / LPN;
@@ -92,10 +92,12 @@ struct RowCtx {
     const int cs = __shfl(c, slot);
     float cc = 0.f;
     if (slot < nchunk && xs > 0.f) {
-      const float r = rmine + phi[cs];
+      // linear decoder: r = <z,V'> + phi; log_transform: r = exp(<z,V'>) - 1 + phi
+      const float ey = LOGT ? expf(rmine) : 1.f;
+      const float r = (LOGT ? ey - 1.f : rmine) + phi[cs];
       if (r > 0.f && r < INFINITY) {
         ll = fmaf(xs, logf(r), ll);
-        cc = xs * __builtin_amdgcn_rcpf(r);
+        cc = xs * ey * __builtin_amdgcn_rcpf(r);   // d(x log r)/d<z,V'>
       } else {
         nnf += 1.0;
       }
@@ -115,15 +117,16 @@ struct RowCtx {
 
 }  // namespace
 
-template <int KP>
+template <int KP, bool LOGT>
 __global__ __launch_bounds__(256) void row_pass_kernel(
     int64_t B, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ row_scale,
     const float* __restrict__ Ap, const float* __restrict__ Vp, const float* __restrict__ phi,
     const double* __restrict__ dprep, float* __restrict__ z, float* __restrict__ gzs,
-    double* __restrict__ dacc, int encode_only) {
+    double* __restrict__ dacc, int mode, const float* __restrict__ gzd) {
+  const bool encode_only = mode == 1;
   constexpr int LPN = KP / 4;
-  RowCtx<KP> cx;
+  RowCtx<KP, LOGT> cx;
   cx.Ap = Ap;
   cx.Vp = Vp;
   cx.phi = phi;
@@ -156,26 +159,34 @@ __global__ __launch_bounds__(256) void row_pass_kernel(
       const int c1 = i1 < end ? __builtin_nontemporal_load(&col[i1]) : 0;
       const float x1 = i1 < end ? __builtin_nontemporal_load(&val[i1]) : 0.f;
       const int n0 = min(n, 64), n1 = n - 64;
-      cx.sweep1(c0, x0, n0, zacc);
-      if (n1 > 0) cx.sweep1(c1, x1, n1, zacc);
-      zacc = across_groups_sum4<LPN>(zacc);
-      zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
-      if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
-      if (encode_only) continue;
+      if (mode != 2) {
+        cx.sweep1(c0, x0, n0, zacc);
+        if (n1 > 0) cx.sweep1(c1, x1, n1, zacc);
+        zacc = across_groups_sum4<LPN>(zacc);
+        zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
+        if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
+        if (encode_only) continue;
+      } else {
+        zacc = gather4<LPN>(z, (int)b, sub);
+      }
       cx.sweep2(c0, x0, n0, zacc, gz, llrow, nnf_acc);
       if (n1 > 0) cx.sweep2(c1, x1, n1, zacc, gz, llrow, nnf_acc);
     } else {
       // ---- long row: stream the row twice (second read is L2 served) -----
-      for (int base = start; base < end; base += 64) {
-        const int idx = base + lane;
-        const int c = idx < end ? col[idx] : 0;
-        const float x = idx < end ? val[idx] : 0.f;
-        cx.sweep1(c, x, min(64, end - base), zacc);
+      if (mode != 2) {
+        for (int base = start; base < end; base += 64) {
+          const int idx = base + lane;
+          const int c = idx < end ? col[idx] : 0;
+          const float x = idx < end ? val[idx] : 0.f;
+          cx.sweep1(c, x, min(64, end - base), zacc);
+        }
+        zacc = across_groups_sum4<LPN>(zacc);
+        zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
+        if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
+        if (encode_only) continue;
+      } else {
+        zacc = gather4<LPN>(z, (int)b, sub);
       }
-      zacc = across_groups_sum4<LPN>(zacc);
-      zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
-      if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
-      if (encode_only) continue;
       for (int base = start; base < end; base += 64) {
         const int idx = base + lane;
         const int c = idx < end ? col[idx] : 0;
@@ -187,11 +198,14 @@ __global__ __launch_bounds__(256) void row_pass_kernel(
     if (grp == 0) {
       zsq_acc += (double)dot4(zacc, zacc);
       zsum = add4(zsum, zacc);
+      // minus the derivative of sum_d r_bd over ALL columns: closed form veta
+      // (linear decoder) or the dense exp term of this row (log_transform)
+      const float4 dn = mode == 2 ? gather4<LPN>(gzd, (int)b, sub) : veta4;
       float4 o;
-      o.x = xi * (gz.x - veta4.x - zacc.x);
-      o.y = xi * (gz.y - veta4.y - zacc.y);
-      o.z = xi * (gz.z - veta4.z - zacc.z);
-      o.w = xi * (gz.w - veta4.w - zacc.w);
+      o.x = xi * (gz.x - dn.x - zacc.x);
+      o.y = xi * (gz.y - dn.y - zacc.y);
+      o.z = xi * (gz.z - dn.z - zacc.z);
+      o.w = xi * (gz.w - dn.w - zacc.w);
       reinterpret_cast<float4*>(gzs)[(size_t)b * LPN + sub] = o;
     }
     ll_acc += (double)llrow;
@@ -229,9 +243,14 @@ template <int KP>
 static void launch_row_t(const RowArgs& a, hipStream_t st) {
   int64_t want = (a.B + 3) / 4;  // 4 waves (rows in flight) per 256-thread block
   int nb = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
-  hipLaunchKernelGGL(row_pass_kernel<KP>, dim3(nb), dim3(256), 0, st, a.B, a.row_ptr, a.col,
-                     a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, a.gzs, a.dacc,
-                     a.encode_only);
+  if (a.logt)
+    hipLaunchKernelGGL((row_pass_kernel<KP, true>), dim3(nb), dim3(256), 0, st, a.B, a.row_ptr,
+                       a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, a.gzs, a.dacc,
+                       a.mode, a.gzd);
+  else
+    hipLaunchKernelGGL((row_pass_kernel<KP, false>), dim3(nb), dim3(256), 0, st, a.B, a.row_ptr,
+                       a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, a.gzs, a.dacc,
+                       a.mode, a.gzd);
 }
 
 void launch_row_pass(int KP, const RowArgs& a, hipStream_t st) {

@@ -179,6 +179,8 @@ class PoissonFactorization:
         if sc.row_sum is None:
             sc.compute_stats(self._handle())
         sc.set_row_scale(float(self.xi_u_global), self.scale_rows)
+        if self.log_transform:
+            sc.set_log_transform(self._eta_device())
         return sc
 
     def _batch(self, data):
@@ -187,7 +189,7 @@ class PoissonFactorization:
         shard (minibatching without re-sorting)."""
         sc = self._counts(data)
         pr = data.get("panels") if isinstance(data, dict) else None
-        key = (pr, sc._xi_key)
+        key = (pr, sc._xi_key, sc._g_key)
         cache = sc.__dict__.setdefault("_struct_cache", {})
         if key not in cache:
             cache[key] = sc.batch_struct(*(pr or (0, None)))
@@ -232,10 +234,6 @@ class PoissonFactorization:
         row-sharded multi-GPU path; it must also return the global
         (rows, lgamma_sum) via its return value or None for single shard.
         """
-        if self.log_transform:
-            raise NotImplementedError(
-                "log_transform=True has no sparse closed form (SURVEY 8a row 8); "
-                "the dense HIP path is not built yet")
         lib, h = _lib.load(), self._handle()
         sc, cs = self._batch(data)
         S, P = self._pack_params(params)

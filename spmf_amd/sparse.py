@@ -65,6 +65,9 @@ class SparseCounts:
         self.row_lgamma = None
         self.row_scale = None      # xi_b, set by PoissonFactorization
         self._xi_key = None
+        self.gval = None           # g(x) = log(x/eta+1) per entry (log_transform only)
+        self.pc_gval = None
+        self._g_key = None
         self._keep = []
 
     # ---- construction ----------------------------------------------------
@@ -151,6 +154,24 @@ class SparseCounts:
             self.row_scale = None
         self._xi_key = key
 
+    def set_log_transform(self, eta_dev):
+        """g(x) = log(x/eta_d + 1) per stored entry (encoder_function,
+        poisson.py:41-42), in CSR and panel-CSC order.  Data side: depends on
+        the counts and the fixed column scales only."""
+        key = (eta_dev.data_ptr(), int(eta_dev._version))
+        if self._g_key == key:
+            return
+        eta = eta_dev.to(self.device, torch.float32)
+        self.gval = torch.log1p(self.val / eta[self.col_idx.to(torch.int64)]).contiguous()
+        nP, D = self.n_panels, self.n_cols
+        ptr = self.pc_ptr.view(nP, D + 1).to(torch.int64)
+        cnt = (ptr[:, 1:] - ptr[:, :-1]).reshape(-1)
+        cols = torch.repeat_interleave(
+            torch.arange(nP * D, device=self.device, dtype=torch.int64) % D, cnt)
+        self.pc_gval = torch.log1p(self.pc_val / eta[cols]).contiguous()
+        self._g_key = key
+        self.__dict__.pop("_struct_cache", None)
+
     # ---- batches ---------------------------------------------------------
     def n_batches(self, batch_rows):
         ppb = max(1, batch_rows // self.panel_rows)
@@ -180,6 +201,8 @@ class SparseCounts:
         cs.pc_val = self.pc_val.data_ptr()
         cs.lgamma_sum = (float(self.row_lgamma[r0:r1].sum())
                          if self.row_lgamma is not None else 0.0)
+        cs.gval = self.gval.data_ptr() if self.gval is not None else None
+        cs.pc_gval = self.pc_gval.data_ptr() if self.pc_gval is not None else None
         return cs
 
     def to_dense(self):

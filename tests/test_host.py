@@ -54,8 +54,9 @@ def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
 
 def test_counts_struct_layout_matches_header():
     from spmf_amd._lib import CountsStruct
-    # 2*int64 + 4*int32 + 7 pointers + double
-    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8
+    # 2*int64 + 4*int32 + 7 pointers + double + 2 pointers
+    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8 + 16
+    assert CountsStruct.gval.offset == 96
     assert CountsStruct.row_ptr.offset == 32
     assert CountsStruct.lgamma_sum.offset == 88
 
