@@ -35,7 +35,13 @@ WORKLOADS = {
     "c2": (100_000, 5_000, 0.01, 16,
            "C2: 100k x 5k, 1% nnz, K=16"),
     "small": (50_000, 2_000, 0.01, 32, "smoke-sized: 50k x 2k, 1% nnz, K=32"),
+    # scRNA-shaped, row scaling + log_transform on (bin/factorize_scrnaseq_counts.py:93-99):
+    # the dense exp sums run on the f32 matrix cores, roofline bound = mfma
+    "c4": (500_000, 30_000, 0.03, 64,
+           "C4: 500k x 30k scRNA-shaped counts, ~3% nnz, K=64, log_transform"),
+    "c4small": (50_000, 6_000, 0.03, 64, "C4-shaped smoke: 50k x 6k, ~3% nnz, K=64, log_transform"),
 }
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 
 
 def algorithmic_bytes(nnz, B, D, K, S):
@@ -112,14 +118,21 @@ def main():
     c0 = nchunks * rank // world
     c1 = nchunks * (rank + 1) // world
     my_rows = min(rows, c1 * chunk) - c0 * chunk
-    sc = synth.linear_structure(my_rows, D, density, dev, first_chunk=c0,
-                                panel_rows=args.panel_rows)
+    logt = args.workload.startswith("c4")
+    if logt:
+        per = 25_000
+        sc = synth.scrna_like(my_rows, D, dev, 20241218 + 4, first_chunk=c0 * (chunk // per),
+                              panel_rows=args.panel_rows, chunk_rows=per,
+                              target_density=density)
+    else:
+        sc = synth.linear_structure(my_rows, D, density, dev, first_chunk=c0,
+                                    panel_rows=args.panel_rows)
 
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):   # the class prints like the reference
         model = PoissonFactorization(latent_dim=K, feature_dim=D,
                                      u_tau_scale=1.0 / (rows * D) ** 0.5, device=dev,
-                                     panel_rows=args.panel_rows)
+                                     panel_rows=args.panel_rows, log_transform=logt)
     # compute_scales (poisson.py:113-154) over all shards: one pre-pass + all-reduce
     colsum = torch.zeros(D, dtype=torch.float64, device=dev)
     colnnz = torch.zeros(D, dtype=torch.float64, device=dev)
@@ -130,8 +143,14 @@ def main():
         for t in (colsum, colnnz, tot):
             dist.all_reduce(t)
     cm = colsum / colnnz
-    model.eta_i = torch.where(cm > 1, cm, torch.ones_like(cm)).reshape(1, D)
-    model.xi_u_global = float(torch.nansum(cm))
+    if logt:
+        # bin/factorize_scrnaseq_counts.py:93-99: column_norms = plain column means
+        # (floored: a zero mean would divide by zero in g(x) = log(x/eta + 1))
+        model.eta_i = (colsum / float(tot[0])).clamp_min(1e-3).reshape(1, D)
+        model.xi_u_global = float(torch.nansum(colsum / float(tot[0])))
+    else:
+        model.eta_i = torch.where(cm > 1, cm, torch.ones_like(cm)).reshape(1, D)
+        model.xi_u_global = float(torch.nansum(cm))
     rows_g, lgam_g, nnz_g = int(tot[0]), float(tot[1]), int(tot[2])
 
     # parameters: S draws from the surrogate at its initial values (poisson.py:403-539)
@@ -170,7 +189,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     import ctypes as C
-    ms5 = (C.c_float * 5)()
+    ms5 = (C.c_float * 6)()
     _lib.check(h, lib.spmf_last_timing(h, ms5), "spmf_last_timing")
     lib.spmf_ctx_enable_timing(h, 0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -183,13 +202,24 @@ def main():
         value = args.steps / dt
         # roofline of the dominant kernel of THIS rank's shard
         b_row, b_col, b_tot = algorithmic_bytes(sc.nnz, sc.n_rows, D, K, S)
-        kern = {"prep": ms5[0], "row_pass": ms5[1], "col_pass": ms5[2], "finish": ms5[3]}
-        dom = "col_pass" if ms5[2] >= ms5[1] else "row_pass"
-        dom_bytes = (b_col if dom == "col_pass" else b_row) / S   # timing taps cover one draw
-        achieved = dom_bytes / (kern[dom] * 1e-3) / 1e9
+        kern = {"prep": ms5[0], "row_pass": ms5[1], "col_pass": ms5[2], "finish": ms5[3],
+                "dense_expdot": ms5[5]}
+        KD = max(32, K)
+        dense_flops = 2 * 4.0 * sc.n_rows * D * KD      # two launches, 2 products each
+        if logt and ms5[5] >= max(ms5[1], ms5[2]):
+            dom = "dense_expdot"
+            achieved = dense_flops / (ms5[5] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+        else:
+            dom = "col_pass" if ms5[2] >= ms5[1] else "row_pass"
+            dom_bytes = (b_col if dom == "col_pass" else b_row) / S   # taps cover one draw
+            achieved = dom_bytes / (kern[dom] * 1e-3) / 1e9
+            roof = None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if roof is None and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
             except Exception:
@@ -208,9 +238,9 @@ def main():
             "frac_hbm_roofline_step": b_tot_g / world / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_step": b_tot_g,
             "kernel_ms": {k: round(float(v), 4) for k, v in kern.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic},
+            "roofline": roof or {"bound": "hbm", "kernel": dom, "achieved": achieved,
+                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic},
             "n_nonfinite": float(nnf.sum()),
             "elbo_x": float(parts["x"][0]),
         }

@@ -164,10 +164,11 @@ const float* spmf_gz_ptr(const spmf_ctx* ctx);
 /* Per-kernel device time, averaged over the (up to 64) most recent
  * spmf_data_pass + spmf_finish pairs issued since timing was enabled
  * (hipEvents recorded on `stream` between the kernels of the last draw; the
- * query synchronises, the hot path does not): ms[5] = prep, row pass, column
- * pass, finish, sum.  For bench.py's roofline. */
+ * query synchronises, the hot path does not): ms[6] = prep, row pass (sparse
+ * launches), column pass, finish, sum of all, dense exp kernels
+ * (log_transform only, else 0).  For bench.py's roofline. */
 int spmf_ctx_enable_timing(spmf_ctx* ctx, int on);
-int spmf_last_timing(spmf_ctx* ctx, float* ms5);
+int spmf_last_timing(spmf_ctx* ctx, float* ms6);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ struct spmf_ctx {
   // timing taps
   int timing = 0;
   static constexpr int kSets = 64;  // ring of event sets: no sync inside a timed loop
-  hipEvent_t evs[kSets][6] = {};
+  hipEvent_t evs[kSets][8] = {};   // 0..3 data pass, 4..5 finish, 6..7 dense exp kernels
   hipEvent_t* ev = evs[0];
   int ev_set = -1;      // set used by the call in flight
   int ev_count = 0;     // complete sets recorded since enable
@@ -185,6 +185,7 @@ int spmf_ctx_enable_timing(spmf_ctx* c, int on) {
 
 int spmf_last_timing(spmf_ctx* c, float* ms5) {
   if (!c || !ms5) return SPMF_E_ARG;
+  const bool logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) != 0;
   if (!c->timing || c->ev_count < 1) return fail(c, SPMF_E_ARG, "no timing recorded (enable timing, run data_pass + finish)");
   // average over the (up to kSets) most recent complete steps
   const int n = c->ev_count < spmf_ctx::kSets ? c->ev_count : spmf_ctx::kSets;
@@ -202,6 +203,18 @@ int spmf_last_timing(spmf_ctx* c, float* ms5) {
   }
   for (int i = 0; i < 4; ++i) ms5[i] = (float)(acc[i] / n);
   ms5[4] = ms5[0] + ms5[1] + ms5[2] + ms5[3];
+  ms5[5] = 0.f;
+  if (logt) {   // the two dense launches sit inside the row interval: report them apart
+    double d = 0;
+    for (int k = 0; k < n; ++k) {
+      hipEvent_t* e = c->evs[((c->ev_set - k) % spmf_ctx::kSets + spmf_ctx::kSets) % spmf_ctx::kSets];
+      float t;
+      HIPCHK(c, hipEventElapsedTime(&t, e[6], e[7]));
+      d += t;
+    }
+    ms5[5] = (float)(d / n);
+    ms5[1] -= ms5[5];
+  }
   return SPMF_OK;
 }
 
@@ -263,13 +276,19 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
       // cores, then the stored-cell terms (sweep 2) with the dense row term.
       RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, ct->gval, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 1, 1, nullptr};
       launch_row_pass(KP, r1, st);
+      if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
       ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0};
       launch_expdot(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E
-      int chunks = (int)((ct->n_rows / 128 + 511) / 512);
+      // W-stationary launch has only D/128 workgroups: split the row (Q) range
+      // into chunks until ~4 workgroups per CU are in flight
+      const int nbx = (D + 127) / 128;
+      const int qtiles = (int)((ct->n_rows + 127) / 128);
+      int chunks = (1024 + nbx - 1) / nbx;
+      if (chunks > qtiles) chunks = qtiles;
       if (chunks < 1) chunks = 1;
-      if (chunks > 64) chunks = 64;
       ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, chunks, 1};
       launch_expdot(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+      if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
       RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 2, 1, c->gzd};
       launch_row_pass(KP, r2, st);
     }

@@ -78,3 +78,45 @@ def bernoulli_poisson(rows, D, density, device, seed, mean=2.0, panel_rows=8192)
     row_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
     row_ptr[1:] = torch.cumsum(cnt, 0)
     return SparseCounts(row_ptr, c.to(torch.int32), x.to(torch.float32), rows, D, panel_rows)
+
+
+def scrna_like(rows, D, device, seed, first_chunk=0, panel_rows=8192, chunk_rows=25_000,
+               target_density=0.03):
+    """C4-style scRNA-seq-shaped counts: per-gene mean ~
+    LogNormal(-3.5, 1.5), per-cell size factor ~ LogNormal(0, 0.5),
+    X ~ Poisson(size * mean), gene means rescaled so the stored density is
+    ~`target_density`.  Generated dense chunk by chunk on the device."""
+    gg = torch.Generator(device=device)
+    gg.manual_seed(seed)
+    mean = torch.exp(-3.5 + 1.5 * torch.randn(D, device=device, generator=gg))
+    # P(x>0) = 1 - exp(-size*mean); calibrate a global scale on a size-factor sample
+    sf = torch.exp(0.5 * torch.randn(2048, device=device, generator=gg))
+    lo, hi = 1e-3, 1e3
+    for _ in range(40):
+        mid = (lo * hi) ** 0.5
+        dens = (1 - torch.exp(-(sf[:, None] * mean[None, :] * mid))).mean().item()
+        if dens < target_density:
+            lo = mid
+        else:
+            hi = mid
+    mean = mean * ((lo * hi) ** 0.5)
+    cnts, cols, vals = [], [], []
+    done, cid = 0, first_chunk
+    while done < rows:
+        n = min(chunk_rows, rows - done)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1000 + 7 + cid)
+        size = torch.exp(0.5 * torch.randn(n, device=device, generator=g))
+        x = torch.poisson(size[:, None] * mean[None, :], generator=g)
+        mask = x > 0
+        cnts.append(mask.sum(1))
+        nz = mask.nonzero(as_tuple=False)
+        cols.append(nz[:, 1].to(torch.int32))
+        vals.append(x[mask].to(torch.float32))
+        del x, mask, nz
+        done += n
+        cid += 1
+    cnt = torch.cat(cnts)
+    row_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    row_ptr[1:] = torch.cumsum(cnt, 0)
+    return SparseCounts(row_ptr, torch.cat(cols), torch.cat(vals), rows, D, panel_rows)
