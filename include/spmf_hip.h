@@ -155,6 +155,23 @@ int spmf_elbo_fwd_bwd(spmf_ctx* ctx, const spmf_counts* counts, int S,
 int spmf_encode(spmf_ctx* ctx, const spmf_counts* counts, const float* u,
                 const float* s, const float* eta, float* z_out, void* stream);
 
+/* log_likelihood_components (poisson.py:156-184) for ONE draw, dense like the
+ * reference: rate[B,D] and the Poisson log-pmf ll[B,D] of every cell (fp32,
+ * row-major).  Output bound (8 B per cell); not on the hot path.  Serves the
+ * class surface and the non-finite replacement rule. */
+int spmf_dense_ll(spmf_ctx* ctx, const spmf_counts* counts, const float* u,
+                  const float* v, const float* w, const float* s,
+                  const float* eta, float* rate_out, float* ll_out, void* stream);
+
+/* Reductions of the non-finite rule (poisson.py:606-616) over a dense ll
+ * buffer of n cells; io = double[3] on the device.
+ *   pass 0: io[0] = min(io[0], min over finite cells)  (initialise io[0]=0:
+ *           the reference's where(finite, ll, 0) puts 0 into the minimum)
+ *   pass 1: io[1] += sum where(finite, clip(ll, io[0]-10, 0), io[0]-10),
+ *           io[2] += number of non-finite cells. */
+int spmf_nonfinite_reduce(spmf_ctx* ctx, int64_t n, const float* ll, int pass,
+                          double* io, void* stream);
+
 /* Test/diagnostic taps: per-row z and d/dz of the LAST draw processed by
  * spmf_data_pass, [B,KP] fp32 with KP = spmf_padded_k(). */
 int spmf_padded_k(const spmf_ctx* ctx);

@@ -66,6 +66,9 @@ SIGNATURES = {
                                     C.c_double, PtrArray, C.c_void_p, C.c_void_p, PtrArray,
                                     C.c_void_p, C.c_void_p]),
     "spmf_encode": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct)] + [C.c_void_p] * 5),
+    "spmf_dense_ll": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct)] + [C.c_void_p] * 8),
+    "spmf_nonfinite_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
     "spmf_padded_k": (C.c_int, [C.c_void_p]),
     "spmf_z_ptr": (C.c_void_p, [C.c_void_p]),
     "spmf_gz_ptr": (C.c_void_p, [C.c_void_p]),

@@ -367,4 +367,33 @@ int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float*
   return SPMF_OK;
 }
 
+int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* v, const float* w, const float* s, const float* eta, float* rate_out, float* ll_out, void* stream) {
+  if (!c || !u || !v || !w || !s || !eta || !rate_out || !ll_out) return fail(c, SPMF_E_ARG, "dense_ll: bad arguments");
+  const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0;
+  int rc = check_counts(c, ct);
+  if (!rc && logt && ct->nnz > 0 && !ct->gval) rc = fail(c, SPMF_E_ARG, "dense_ll: log_transform needs counts.gval");
+  if (rc) return rc;
+  if (ct->n_rows == 0) return SPMF_OK;
+  rc = bind_ws(c, ct->n_rows, 1);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipMemsetAsync(c->dprep, 0, (c->KP + 1) * sizeof(double), st));
+  PrepArgs pa{c->D, c->K, u, v, w, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt};
+  launch_prep(c->KP, pa, st);
+  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr};
+  launch_row_pass(c->KP, ra, st);
+  DenseLLArgs da{ct->n_rows, c->D, logt, c->z, c->Vp, c->phi, ct->row_ptr, ct->col_idx, ct->val, rate_out, ll_out};
+  launch_dense_ll(c->KP, da, st);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_nonfinite_reduce(spmf_ctx* c, int64_t n, const float* ll, int pass, double* io, void* stream) {
+  if (!c || !ll || !io || n < 0 || (pass != 0 && pass != 1)) return fail(c, SPMF_E_ARG, "nonfinite_reduce: bad arguments");
+  if (n == 0) return SPMF_OK;
+  launch_nonfinite(n, ll, pass, io, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
 }  // extern "C"

@@ -52,6 +52,19 @@ struct ExpdotArgs {
   int atomic_out;
 };
 void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st);
+
+struct DenseLLArgs {
+  int64_t B;
+  int D, logt;
+  const float *z, *Vp, *phi;
+  const int32_t* row_ptr;
+  const int32_t* col;
+  const float* val;
+  float *rate, *ll;  // [B,D] each
+};
+void launch_dense_ll(int KP, const DenseLLArgs& a, hipStream_t st);
+// pass 0: io[0] = min(io[0], finite ll); pass 1: io[1] += clipped/replaced sum, io[2] += #non-finite
+void launch_nonfinite(int64_t n, const float* ll, int pass, double* io, hipStream_t st);
 void launch_col_pass(int KP, const ColArgs& a, hipStream_t st);
 
 struct PackArgs {

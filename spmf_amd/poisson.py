@@ -268,17 +268,85 @@ class PoissonFactorization:
         squeeze = params["u"].dim() == 2 if isinstance(params.get("u"), torch.Tensor) \
             else np.ndim(params["u"]) == 2
         parts, _, nnf = self.energy_and_grads(data, params)
-        if float(nnf.sum()) != 0.0:
-            raise FloatingPointError(
-                f"{int(nnf.sum())} stored cells have a non-finite Poisson log-pmf; "
-                "the non-finite replacement rule (poisson.py:606-616) needs the "
-                "dense path")
+        if float(nnf.sum()) != 0.0 or not bool(torch.isfinite(parts["x"]).all()):
+            # some cell's log-pmf is not finite: the sparse fast path does not
+            # apply; evaluate the replacement rule (poisson.py:606-616) over
+            # the dense per-cell log-pmf (values only).
+            parts = dict(parts)
+            parts["x"] = self._nonfinite_rule_x(data, params)
         out = {}
         for k, v in parts.items():
             if k not in ("x", "z"):
                 v = v * prior_weight                       # poisson.py:591
             out[k] = v[0] if squeeze else v
         return out
+
+    # ------------------------------------------------------------------
+    # dense per-cell outputs (class surface; not the hot path)
+    # ------------------------------------------------------------------
+    def log_likelihood_components(self, s, u, v, w, data, *args, **kwargs):
+        """Returns the log likelihood without summing along axes
+        (poisson.py:156-184): {'log_likelihood': [S,B,D], 'rate': [S,B,D]}
+        (no sample axis when the parameters have none)."""
+        lib, h = _lib.load(), self._handle()
+        sc, cs = self._batch(data)
+        S, P = self._pack_params({"s": s, "u": u, "v": v, "w": w}, names=("s", "u", "v", "w"))
+        single = (u.dim() if isinstance(u, torch.Tensor) else np.ndim(u)) == 2
+        self._ensure_workspace(cs.n_rows, 1)
+        eta = self._eta_device()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        B, D = cs.n_rows, self.feature_dim
+        rate = torch.empty(S, B, D, dtype=torch.float32, device=self.device)
+        ll = torch.empty(S, B, D, dtype=torch.float32, device=self.device)
+        for i in range(S):
+            _lib.check(h, lib.spmf_dense_ll(
+                h, C.byref(cs), P["u"][i].data_ptr(), P["v"][i].data_ptr(),
+                P["w"][i].data_ptr(), P["s"][i].data_ptr(), eta.data_ptr(),
+                rate[i].data_ptr(), ll[i].data_ptr(), stream), "spmf_dense_ll")
+        if single:
+            rate, ll = rate[0], ll[0]
+        return {'log_likelihood': ll, 'rate': rate}
+
+    def predictive_distribution(self, s, u, v, w, data, *args, **kwargs):
+        """poisson.py:187-210.  The reference sums a non-existent key 'll'
+        (:206-208, KeyError whenever a sample axis is present); here the
+        summed per-row log likelihood is added under that key instead."""
+        prediction = self.log_likelihood_components(s=s, u=u, v=v, w=w, data=data)
+        if prediction['log_likelihood'].dim() > 2:
+            prediction['ll'] = prediction['log_likelihood'].sum(-1)
+        return prediction
+
+    def _nonfinite_rule_x(self, data, params):
+        """'x' part under the non-finite replacement rule (poisson.py:606-616)
+        from the dense per-cell log-pmf: global min over [S,B,D] finite cells,
+        clip to [min-10, 0], non-finite cells -> min-10.  Values only."""
+        lib, h = _lib.load(), self._handle()
+        sc, cs = self._batch(data)
+        S, P = self._pack_params(params, names=("s", "u", "v", "w"))
+        self._ensure_workspace(cs.n_rows, 1)
+        eta = self._eta_device()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        B, D = cs.n_rows, self.feature_dim
+        rate = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        ll = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        io = torch.zeros(S, 3, dtype=torch.float64, device=self.device)
+        gmin = torch.zeros(3, dtype=torch.float64, device=self.device)
+
+        def dense(i):
+            _lib.check(h, lib.spmf_dense_ll(
+                h, C.byref(cs), P["u"][i].data_ptr(), P["v"][i].data_ptr(),
+                P["w"][i].data_ptr(), P["s"][i].data_ptr(), eta.data_ptr(),
+                rate.data_ptr(), ll.data_ptr(), stream), "spmf_dense_ll")
+        for i in range(S):                       # pass 0: one min over ALL draws
+            dense(i)
+            _lib.check(h, lib.spmf_nonfinite_reduce(h, B * D, ll.data_ptr(), 0,
+                                                    gmin.data_ptr(), stream), "nonfinite")
+        for i in range(S):                       # pass 1: clipped / replaced sums
+            dense(i)
+            io[i, 0] = gmin[0]
+            _lib.check(h, lib.spmf_nonfinite_reduce(h, B * D, ll.data_ptr(), 1,
+                                                    io[i].data_ptr(), stream), "nonfinite")
+        return io[:, 1].clone()
 
     def unormalized_log_prob(self, data=None, prior_weight=1., **params):
         """poisson.py:575-580 -- NB: like the reference this ignores
