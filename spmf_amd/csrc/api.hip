@@ -20,6 +20,7 @@ struct spmf_ctx {
   unsigned flags = 0;
   double u_tau_scale = 0.01, s_tau_scale = 1.0, decay = 0.99;  // poisson.py:59
   int panels_per_wave = 1;
+  int split_row = 0;
   // workspace carve
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -76,7 +77,7 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   size_t o = 0;
   const size_t KP = c->KP, D = c->D;
   k.acc = o;   o += al((size_t)S * acc_len(c->D, c->KP) * sizeof(float));
-  k.dacc = o;  o += al((size_t)S * (kDaccHead + KP) * sizeof(double));
+  k.dacc = o;  o += al((size_t)S * kDaccRep * (kDaccHead + KP) * sizeof(double));
   k.dprep = o; o += al((size_t)S * (KP + 1) * sizeof(double));
   k.Ap = o;    o += al(D * KP * sizeof(float));
   k.Vp = o;    o += al(D * KP * sizeof(float));
@@ -105,6 +106,7 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   if ((flags & SPMF_FLAG_LOG_TRANSFORM) && c->KP < 32) c->KP = 32;
   c->flags = flags;
   if (const char* e = getenv("SPMF_PANELS_PER_WAVE")) c->panels_per_wave = atoi(e);
+  if (const char* e = getenv("SPMF_SPLIT_ROW")) c->split_row = atoi(e);
   *out = c;
   return SPMF_OK;
 }
@@ -260,7 +262,7 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
   for (int s = 0; s < S; ++s) {
     const bool tm = c->timing && s == S - 1;
     float* acc = c->acc + (size_t)s * al_;
-    double* dacc = c->dacc + (size_t)s * (kDaccHead + KP);
+    double* dacc = c->dacc + (size_t)s * kDaccRep * (kDaccHead + KP);
     double* dprep = c->dprep + (size_t)s * (KP + 1);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
     PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt};
@@ -270,6 +272,11 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
     float* gVp = acc + (size_t)D * KP;
     if (ct->n_rows > 0 && !logt) {
       RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 0, 0, nullptr};
+      if (c->split_row) {   // two launches: each keeps only one factor table hot in L2
+        ra.mode = 1;
+        launch_row_pass(KP, ra, st);
+        ra.mode = 2;
+      }
       launch_row_pass(KP, ra, st);
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix

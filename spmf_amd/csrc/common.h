@@ -15,6 +15,10 @@ constexpr double kLog2 = 0.69314718055994530942;
 //   [0] sum_nnz x*log r   [1] sum z^2   [2] non-finite stored cells
 //   [3] reserved          [4 .. 4+KP)   sum_b z_b
 constexpr int kDaccHead = 4;
+// the block sums land in one of kDaccRep replicas (blockIdx % kDaccRep) so the
+// fp64 atomics of thousands of blocks do not serialise on 4+KP addresses;
+// the pack kernel folds the replicas.
+constexpr int kDaccRep = 16;
 
 // fp32 accumulator tail: the fp64 scalars as (hi,lo) float pairs.
 __host__ __device__ inline int acc_tail_len(int KP) { return 2 * (kDaccHead + KP); }

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   __shared__ float tile[KP][FTD + 1];
   __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
   __shared__ float zsum_s[KP], utau_s[KP], dec_s[KP], gutau_s[KP];
-  __shared__ double red[16];
+  __shared__ float gred[256];
   const int t = threadIdx.x;
   const int d0 = blockIdx.x * FTD;
   const float* gAp = acc;
@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
 
   // ---- [D,K] arrays: u, u_eta, u_eta_a and gA' ---------------------------
   constexpr int LW = KP < 64 ? KP : 64;  // lanes sharing one d inside a wave
+  // 256 % KP == 0, so a thread keeps the same k in every iteration: gut_acc
+  // sums its d's in a register (LDS float atomics cost ~200 cycles each here)
+  float gut_acc = 0.f;
   for (int e = t; e < KP * FTD; e += 256) {
     const int dl = e / KP, k = e % KP;
     const int d = d0 + dl;
@@ -137,8 +140,16 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     // GA_d = sum_k u*dA : fold over the LW lanes that share d
 #pragma unroll
     for (int m = 1; m < LW; m <<= 1) ga_u += __shfl_xor(ga_u, m);
-    if ((k % LW) == 0 && d < D) atomicAdd(&GAs[dl], ga_u);
-    if (k < K) atomicAdd(&gutau_s[k], gut);
+    if ((k % LW) == 0 && d < D) GAs[dl] = ga_u;   // one writer per dl
+    gut_acc += gut;
+  }
+  // fold gut over the threads that share k: t, t+KP, t+2KP, ... (256/KP of them)
+  gred[t] = gut_acc;
+  __syncthreads();
+  if (t < KP) {
+    float g = 0.f;
+    for (int j = t; j < 256; j += KP) g += gred[j];
+    gutau_s[t] = g;
   }
   // ---- v / dv through the transpose tile ---------------------------------
   for (int e = t; e < KP * FTD; e += 256) {
@@ -218,10 +229,19 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     atomicAdd(&G.p[UTAU_][t], g);  // zeroed by the host before launch
   }
   // ---- energy parts ------------------------------------------------------
+  {
+    __shared__ double pred[12][4];
+    const int wid = t >> 6, lane = t & 63;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
-    const double s = block_sum(part[i], red);
-    if (t == 0 && s != 0.0) atomicAdd(&parts[i], s);
+    for (int i = 0; i < 12; ++i) {
+      const double s = wave_sum(part[i]);
+      if (lane == 0) pred[i][wid] = s;
+    }
+    __syncthreads();
+    if (t < 12) {
+      const double s = pred[t][0] + pred[t][1] + pred[t][2] + pred[t][3];
+      if (s != 0.0) atomicAdd(&parts[t], s);
+    }
   }
   if (blockIdx.x == 0 && t == 0) {
     const double llx = unpack(tail, 0), zsq = unpack(tail, 1);
@@ -240,7 +260,8 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
 __global__ void pack_kernel(int KP, const double* __restrict__ dacc, float* __restrict__ tail) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kDaccHead + KP) {
-    const double v = dacc[i];
+    double v = 0.0;
+    for (int r = 0; r < kDaccRep; ++r) v += dacc[(size_t)r * (kDaccHead + KP) + i];
     const float hi = (float)v;
     tail[2 * i] = hi;
     tail[2 * i + 1] = (float)(v - (double)hi);

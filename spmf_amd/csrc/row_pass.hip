@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void row_pass_kernel(
       zsum = add4(zsum, zacc);
       // minus the derivative of sum_d r_bd over ALL columns: closed form veta
       // (linear decoder) or the dense exp term of this row (log_transform)
-      const float4 dn = mode == 2 ? gather4<LPN>(gzd, (int)b, sub) : veta4;
+      const float4 dn = (mode == 2 && gzd) ? gather4<LPN>(gzd, (int)b, sub) : veta4;
       float4 o;
       o.x = xi * (gz.x - dn.x - zacc.x);
       o.y = xi * (gz.y - dn.y - zacc.y);
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void row_pass_kernel(
   const double ll_b = block_sum(ll_acc, red);
   const double zq_b = block_sum(zsq_acc, red);
   const double nf_b = block_sum(nnf_acc, red);
+  dacc += (size_t)(blockIdx.x % kDaccRep) * (kDaccHead + KP);
   if (threadIdx.x == 0) {
     atomicAdd(&dacc[0], ll_b);
     atomicAdd(&dacc[1], zq_b);
