@@ -85,6 +85,16 @@ typedef struct spmf_counts {
    * entry, in CSR and in panel-CSC order (base pointers); NULL otherwise. */
   const float* gval;
   const float* pc_gval;
+  /* Column-pass work items: every non-empty (panel, column) list cut into
+   * segments of bounded length, sorted by length inside a panel.
+   *   items[i] = {start, len, column, 0} (int32 x 4, start absolute into
+   *   pc_row/pc_val); item_ptr[p], item_ptr[p+1] bound panel p's items
+   *   (absolute item indices; pointer already offset to the batch's first
+   *   panel); max_items_per_panel sizes the launch. */
+  const int32_t* item_ptr;
+  const int32_t* items;
+  int32_t max_items_per_panel;
+  int32_t reserved_;
 } spmf_counts;
 
 int spmf_version(void);

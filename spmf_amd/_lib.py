@@ -38,6 +38,8 @@ class CountsStruct(C.Structure):
         ("pc_ptr", C.c_void_p), ("pc_row", C.c_void_p), ("pc_val", C.c_void_p),
         ("lgamma_sum", C.c_double),
         ("gval", C.c_void_p), ("pc_gval", C.c_void_p),
+        ("item_ptr", C.c_void_p), ("items", C.c_void_p),
+        ("max_items_per_panel", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

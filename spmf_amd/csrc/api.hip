@@ -19,7 +19,6 @@ struct spmf_ctx {
   int device = 0, K = 0, D = 0, KP = 0;
   unsigned flags = 0;
   double u_tau_scale = 0.01, s_tau_scale = 1.0, decay = 0.99;  // poisson.py:59
-  int panels_per_wave = 1;
   int split_row = 0;
   // workspace carve
   char* ws = nullptr;
@@ -105,7 +104,6 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   // the dense exp kernels of the log_transform decoder work on 32-feature MFMA tiles
   if ((flags & SPMF_FLAG_LOG_TRANSFORM) && c->KP < 32) c->KP = 32;
   c->flags = flags;
-  if (const char* e = getenv("SPMF_PANELS_PER_WAVE")) c->panels_per_wave = atoi(e);
   if (const char* e = getenv("SPMF_SPLIT_ROW")) c->split_row = atoi(e);
   *out = c;
   return SPMF_OK;
@@ -244,7 +242,7 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
   int rc = check_counts(c, ct);
   if (!rc && logt && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG, "counts: log_transform needs gval / pc_gval");
   if (rc) return rc;
-  if (ct->n_rows > 0 && ct->nnz > 0 && (!ct->pc_ptr || !ct->pc_row || !ct->pc_val || ct->n_panels < 1)) return fail(c, SPMF_E_ARG, "counts: panel-CSC arrays missing");
+  if (ct->n_rows > 0 && ct->nnz > 0 && (!ct->pc_row || !ct->pc_val || !ct->item_ptr || !ct->items || ct->n_panels < 1)) return fail(c, SPMF_E_ARG, "counts: panel-CSC arrays / work items missing");
   for (int i : {0, 1, 2, 7})
     if (!params[i]) return fail(c, SPMF_E_ARG, "data_pass: params v,w,u,s must be non-null");
   rc = bind_ws(c, ct->n_rows, S);
@@ -301,7 +299,7 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
     if (ct->n_rows > 0 && ct->nnz > 0) {
-      ColArgs ca{D, ct->n_panels, ct->row_base, c->panels_per_wave, ct->pc_ptr, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, gVp, acc + (size_t)2 * D * KP, logt, ct->pc_gval};
+      ColArgs ca{D, ct->n_panels, ct->row_base, ct->max_items_per_panel, ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, gVp, acc + (size_t)2 * D * KP, logt, ct->pc_gval};
       launch_col_pass(KP, ca, st);
     }
     PackArgs pk{KP, dacc, acc + (size_t)2 * D * KP + D};

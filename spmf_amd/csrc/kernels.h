@@ -32,8 +32,9 @@ void launch_row_pass(int KP, const RowArgs& a, hipStream_t st);
 
 struct ColArgs {
   int D, n_panels, row_base;
-  int panels_per_wave;  // 1, 2 or 4 consecutive panels accumulated before the atomics
-  const int32_t* pc_ptr;
+  int max_items_per_panel;
+  const int32_t* item_ptr;  // [n_panels+1]
+  const int32_t* items;     // [n_items][4] = {start, len, column, 0}
   const int32_t* pc_row;
   const float* pc_val;
   const float *Vp, *phi, *z, *gzs;

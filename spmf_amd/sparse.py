@@ -25,6 +25,7 @@ import torch
 from . import _lib
 
 DEFAULT_PANEL_ROWS = 8192
+SEGMENT_ENTRIES = 256     # longest run of one column a single lane group streams
 
 
 def _as_csr_arrays(x):
@@ -123,6 +124,37 @@ class SparseCounts:
         ptr[:, :D] = excl[:-1].view(nP, D)
         ptr[:, D] = excl[D::D]
         self.pc_ptr = ptr.to(torch.int32).contiguous().view(-1)
+        self._build_items(cnt, excl[:-1])
+
+    def _build_items(self, cnt, starts, seg=None):
+        """Column-pass work items {start, len, column, 0}: every non-empty
+        (panel, column) list cut into segments of <= seg entries; inside a
+        panel sorted by length (descending) so the lane groups of a wave get
+        items of similar length.  Deterministic (stable sorts)."""
+        dev, D, nP = self.device, self.n_cols, self.n_panels
+        seg = int(seg or SEGMENT_ENTRIES)
+        nseg = (cnt + seg - 1) // seg                       # segments per list
+        lists = torch.nonzero(nseg > 0, as_tuple=False).view(-1)
+        rep = nseg[lists]
+        lid = torch.repeat_interleave(lists, rep)           # list id of every item
+        first = torch.cumsum(rep, 0) - rep
+        k = torch.arange(lid.numel(), device=dev, dtype=torch.int64) - \
+            torch.repeat_interleave(first, rep)             # segment index inside its list
+        start = starts[lid] + k * seg
+        length = torch.minimum(cnt[lid] - k * seg, torch.full_like(k, seg))
+        panel = lid // D
+        col = lid % D
+        # sort by (panel asc, length desc); ties keep (column, segment) order
+        key = panel * (seg + 1) + (seg - length)
+        order = torch.sort(key, stable=True).indices
+        items = torch.stack([start[order], length[order], col[order],
+                             torch.zeros_like(col[order])], 1)
+        self.items = items.to(torch.int32).contiguous()
+        per_panel = torch.bincount(panel, minlength=nP)
+        ip = torch.zeros(nP + 1, dtype=torch.int64, device=dev)
+        ip[1:] = torch.cumsum(per_panel, 0)
+        self.item_ptr = ip.to(torch.int32).contiguous()
+        self.items_per_panel = per_panel
 
     # ---- statistics (HIP pre-pass) ---------------------------------------
     def compute_stats(self, ctx_handle, colsum=None, colnnz=None):
@@ -201,6 +233,10 @@ class SparseCounts:
         cs.pc_val = self.pc_val.data_ptr()
         cs.lgamma_sum = (float(self.row_lgamma[r0:r1].sum())
                          if self.row_lgamma is not None else 0.0)
+        cs.item_ptr = self.item_ptr.data_ptr() + 4 * p0
+        cs.items = self.items.data_ptr()
+        cs.max_items_per_panel = (int(self.items_per_panel[p0:p1].max())
+                                  if self.items.numel() else 0)
         cs.gval = self.gval.data_ptr() if self.gval is not None else None
         cs.pc_gval = self.pc_gval.data_ptr() if self.pc_gval is not None else None
         return cs

@@ -55,8 +55,9 @@ def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
 def test_counts_struct_layout_matches_header():
     from spmf_amd._lib import CountsStruct
     # 2*int64 + 4*int32 + 7 pointers + double + 2 pointers
-    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8 + 16
+    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8 + 16 + 16 + 8
     assert CountsStruct.gval.offset == 96
+    assert CountsStruct.max_items_per_panel.offset == 128
     assert CountsStruct.row_ptr.offset == 32
     assert CountsStruct.lgamma_sum.offset == 88
 
@@ -114,3 +115,27 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f
+
+
+@pytest.mark.parametrize("seg", [3, 256])
+def test_column_pass_work_items_cover_every_entry_once(seg, monkeypatch):
+    import spmf_amd.sparse as S
+    monkeypatch.setattr(S, "SEGMENT_ENTRIES", seg)
+    rng = np.random.default_rng(9)
+    x = ((rng.random((70, 11)) < 0.5) * (1 + rng.poisson(2.0, size=(70, 11)))).astype(np.float32)
+    x[:, 4] = 0
+    x[:, 7] = 1.0                                     # a hot column: split into segments
+    sc = S.SparseCounts.from_dense(x, "cpu", 32)
+    items, ip = sc.items.numpy(), sc.item_ptr.numpy()
+    assert ip[0] == 0 and ip[-1] == len(items) and len(ip) == sc.n_panels + 1
+    seen = np.zeros(sc.nnz, dtype=int)
+    ptr = sc.pc_ptr.numpy().reshape(sc.n_panels, -1)
+    for p in range(sc.n_panels):
+        lens = items[ip[p]:ip[p + 1], 1]
+        assert np.all(np.diff(lens) <= 0)             # sorted by length inside the panel
+        for start, ln, col, _ in items[ip[p]:ip[p + 1]]:
+            assert 0 < ln <= seg
+            assert ptr[p, col] <= start and start + ln <= ptr[p, col + 1]
+            seen[start:start + ln] += 1
+    assert np.all(seen == 1)
+    assert not np.any(items[:, 2] == 4)               # empty column has no item
