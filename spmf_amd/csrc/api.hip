@@ -19,7 +19,6 @@ struct spmf_ctx {
   int device = 0, K = 0, D = 0, KP = 0;
   unsigned flags = 0;
   double u_tau_scale = 0.01, s_tau_scale = 1.0, decay = 0.99;  // poisson.py:59
-  int split_row = 0;
   // workspace carve
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -104,7 +103,6 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   // the dense exp kernels of the log_transform decoder work on 32-feature MFMA tiles
   if ((flags & SPMF_FLAG_LOG_TRANSFORM) && c->KP < 32) c->KP = 32;
   c->flags = flags;
-  if (const char* e = getenv("SPMF_SPLIT_ROW")) c->split_row = atoi(e);
   *out = c;
   return SPMF_OK;
 }
@@ -270,11 +268,6 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
     float* gVp = acc + (size_t)D * KP;
     if (ct->n_rows > 0 && !logt) {
       RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 0, 0, nullptr};
-      if (c->split_row) {   // two launches: each keeps only one factor table hot in L2
-        ra.mode = 1;
-        launch_row_pass(KP, ra, st);
-        ra.mode = 2;
-      }
       launch_row_pass(KP, ra, st);
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix

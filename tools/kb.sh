@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_kb.sh [bench args]   -> prints ms/step and per-kernel ms
+# usage: tools/kb.sh [bench args]   -> prints ms/step and per-kernel ms
 mkdir -p gpurun_out
 python bench.py --no-cpu-baseline "$@" > gpurun_out/kb.json 2> gpurun_out/kb.err || { tail -20 gpurun_out/kb.err; exit 1; }
 python -c '

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <outdir> <bench args...> ; separate PMC passes (no trace domains mixed in)
+# usage: tools/pmc.sh <outdir> <bench args...> ; separate PMC passes (no trace domains mixed in)
 export TMPDIR=/tmp
 out=$1; shift
 mkdir -p $out
