@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
                                                      const float* __restrict__ Q,
                                                      float* __restrict__ out, float sign,
                                                      double* __restrict__ esum, int atomic_out) {
-  constexpr int PITCH = KD + 1;
+  constexpr int PITCH = KD + 4;   // 16-B aligned rows; (KD+4) % 64 = 4 keeps b128 column reads conflict free
+  constexpr int KH = KD / 2;      // lane half h covers k in [h*KH, (h+1)*KH): any k order is valid
+                                  // as long as A and B agree, and this one makes A a contiguous read
   constexpr int MT = KD / 32;  // 32-feature tiles of the second product
-  __shared__ float qs[2][QT * PITCH];
+  __shared__ __attribute__((aligned(16))) float qs[2][QT * PITCH];
   __shared__ double red[16];
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
@@ -53,10 +55,14 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
   const int tile0 = blockIdx.y * tpc;
   const int tile1 = min(ntiles, tile0 + tpc);
 
-  // P fragment: B operand of product 1, B[k=2s+h][j=c] = P[p0+c][2s+h]
-  float pb[KD / 2];
+  // P fragment: B operand of product 1, step s: B[k][j=c] = P[p0+c][h*KH + s]
+  float pb[KH];
 #pragma unroll
-  for (int s = 0; s < KD / 2; ++s) pb[s] = p < NP ? P[(size_t)p * KD + 2 * s + h] : 0.f;
+  for (int s4 = 0; s4 < KH / 4; ++s4) {
+    const float4 v = p < NP ? *reinterpret_cast<const float4*>(P + (size_t)p * KD + h * KH + 4 * s4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    pb[4 * s4 + 0] = v.x; pb[4 * s4 + 1] = v.y; pb[4 * s4 + 2] = v.z; pb[4 * s4 + 3] = v.w;
+  }
 
   f32x16 acc[MT];
 #pragma unroll
@@ -65,72 +71,111 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
   double es = 0.0;
 
-  // stage loader: 256 threads move QT*KD floats
-  constexpr int PER = QT * KD / 256;
-  float stage[PER];
-  auto gload = [&](int tile) {
-    const int q0 = tile * QT;
+  // stage loader: 256 threads move the QT*KD floats of a tile in QT/32 parts
+  // (one 32-row part per sub-tile of the compute loop: only PER registers live)
+  constexpr int PER4 = 32 * KD / 256 / 4;   // float4 per thread per 32-row part
+  float4 stage[PER4];
+  auto gload = [&](int tile, int part) {
+    const int q0 = tile * QT + part * 32;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = i * 256 + t;
+    for (int i = 0; i < PER4; ++i) {
+      const int e = (i * 256 + t) * 4;
       const int r = e / KD, k = e % KD;
-      stage[i] = (q0 + r < NQ) ? Q[(size_t)(q0 + r) * KD + k] : 0.f;
+      stage[i] = (q0 + r < NQ) ? *reinterpret_cast<const float4*>(Q + (size_t)(q0 + r) * KD + k)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](int buf, int part) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = i * 256 + t;
+    for (int i = 0; i < PER4; ++i) {
+      const int e = (i * 256 + t) * 4;
       const int r = e / KD, k = e % KD;
-      qs[buf][r * PITCH + k] = stage[i];
+      *reinterpret_cast<float4*>(&qs[buf][(part * 32 + r) * PITCH + k]) = stage[i];
     }
   };
 
   if (tile0 < tile1) {
-    gload(tile0);
-    swrite(0);
+#pragma unroll
+    for (int part = 0; part < QT / 32; ++part) {
+      gload(tile0, part);
+      swrite(0, part);
+    }
   }
   __syncthreads();
   for (int tile = tile0; tile < tile1; ++tile) {
     const int buf = (tile - tile0) & 1;
-    if (tile + 1 < tile1) gload(tile + 1);
+    const bool more = tile + 1 < tile1;     // block-uniform
+    // interior tiles need no masking (block-uniform)
+    const bool edge = (tile * QT + QT > NQ) || ((int)(blockIdx.x * 128 + 128) > NP);
     const float* qb = qs[buf];
     const int q0 = tile * QT;
-#pragma unroll 1
-    for (int sub = 0; sub < QT / 32; ++sub) {
-      if (q0 + sub * 32 >= NQ) break;  // block-uniform
-      const float* qt = qb + sub * 32 * PITCH;
-      // ---- product 1: X[q][p] = sum_k Q[q][k] P[p][k] --------------------
+    // Software pipeline over the 4 sub-tiles of the stage: product 1 of
+    // sub-tile s+1 (an MFMA chain) is issued in the same basic block as the
+    // exp() VALU work of sub-tile s, so the two pipes overlap inside one wave.
+    // Rows past NQ hold zeros in LDS and are masked in E, so no early exit.
+    auto product1 = [&](const float* qt) {
       f32x16 x;
 #pragma unroll
       for (int i = 0; i < 16; ++i) x[i] = 0.f;
 #pragma unroll
-      for (int s = 0; s < KD / 2; ++s) {
-        const float a = qt[c * PITCH + 2 * s + h];
-        x = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[s], x, 0, 0, 0);
+      for (int s4 = 0; s4 < KH / 4; ++s4) {
+        const float4 a = *reinterpret_cast<const float4*>(qt + c * PITCH + h * KH + 4 * s4);
+        x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, pb[4 * s4 + 0], x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, pb[4 * s4 + 1], x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, pb[4 * s4 + 2], x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, pb[4 * s4 + 3], x, 0, 0, 0);
       }
-      // ---- E = exp(X), masked outside [NQ) x [NP) ------------------------
-      float part = 0.f;
+      return x;
+    };
+    float es_tile = 0.f;
+    f32x16 xcur = product1(qb);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int q = q0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const float e = (q < NQ && p < NP) ? expf(x[i]) : 0.f;
-        x[i] = e;
-        part += e;
-      }
-      es += (double)part;
-      // ---- product 2: out^T[k][p] += sum_q Q[q][k] E[q][p] ---------------
+    for (int sub = 0; sub < QT / 32; ++sub) {
+      const float* qt = qb + sub * 32 * PITCH;
+      if (more) gload(tile + 1, sub);       // lands under this sub-tile's MFMAs
+      f32x16 xnext;
+      if (sub + 1 < QT / 32) xnext = product1(qt + 32 * PITCH);
+      // A operands of product 2 for the whole sub-tile, issued before the exp
+      // block so their LDS latency is not paid per MFMA pair
+      float aq[16][MT];
 #pragma unroll
       for (int tt = 0; tt < 16; ++tt) {
         const int row = (tt & 3) + 8 * (tt >> 2) + 4 * h;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float a = qt[row * PITCH + m * 32 + c];
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[tt], acc[m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) aq[tt][m] = qt[row * PITCH + m * 32 + c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- E = exp(X), masked outside [NQ) x [NP) ------------------------
+      // exp via v_exp_f32 (2^x): |rel err| ~ 1e-7 * (1 + |x|), inside the 1e-5 budget
+      float part = 0.f;
+      if (edge) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int q = q0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const float e = (q < NQ && p < NP) ? __expf(xcur[i]) : 0.f;
+          xcur[i] = e;
+          part += e;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float e = __expf(xcur[i]);
+          xcur[i] = e;
+          part += e;
         }
       }
+      es_tile += part;
+      // ---- product 2: out^T[k][p] += sum_q Q[q][k] E[q][p] ---------------
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[tt][m], xcur[tt], acc[m], 0, 0, 0);
+      }
+      if (sub + 1 < QT / 32) xcur = xnext;
+      if (more) swrite(buf ^ 1, sub);
     }
-    if (tile + 1 < tile1) swrite(buf ^ 1);
+    es += (double)es_tile;
     __syncthreads();
   }
   // ---- store: lane holds features (i&3)+8(i>>2)+4h (+32m) of row p --------
