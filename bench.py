@@ -244,7 +244,7 @@ def main():
             "n_nonfinite": float(nnf.sum()),
             "elbo_x": float(parts["x"][0]),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not logt:
             n_s, nnz_s, t_s = cpu_baseline(sc, model, params, K)
             out["cpu_baseline"] = {
                 "value": 1.0 / (t_s * rows_g / n_s), "unit": "steps/s", "cores": 1,

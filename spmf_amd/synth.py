@@ -12,6 +12,7 @@ import torch
 from .sparse import SparseCounts
 
 CHUNK_ROWS = 125_000
+MAX_GENE_MEAN = 4.0
 
 
 def linear_structure_chunk(chunk_id, rows, D, density, device, seed=20241218 + 3,
@@ -94,19 +95,25 @@ def scrna_like(rows, D, device, seed, first_chunk=0, panel_rows=8192, chunk_rows
     lo, hi = 1e-3, 1e3
     for _ in range(40):
         mid = (lo * hi) ** 0.5
-        dens = (1 - torch.exp(-(sf[:, None] * mean[None, :] * mid))).mean().item()
+        dens = (1 - torch.exp(-(sf[:, None] * (mean[None, :] * mid).clamp_max(MAX_GENE_MEAN)))
+                ).mean().item()
         if dens < target_density:
             lo = mid
         else:
             hi = mid
-    mean = mean * ((lo * hi) ** 0.5)
+    # cap the hottest genes: with raw column-mean scaling (eta = mean) the
+    # log_transform rate exp(<z, eta v>) of a gene with mean in the hundreds
+    # overflows fp32 at the surrogate's initial values (the reference is fp64)
+    mean = (mean * ((lo * hi) ** 0.5)).clamp_max(MAX_GENE_MEAN)
     cnts, cols, vals = [], [], []
     done, cid = 0, first_chunk
     while done < rows:
         n = min(chunk_rows, rows - done)
         g = torch.Generator(device=device)
         g.manual_seed(seed * 1000 + 7 + cid)
-        size = torch.exp(0.5 * torch.randn(n, device=device, generator=g))
+        # size factors clipped at 2 sigma: an un-clipped LogNormal tail row (x12 counts)
+        # drives exp(<z, eta v>) past the fp32 range at the surrogate's initial values
+        size = torch.exp((0.5 * torch.randn(n, device=device, generator=g)).clamp_(-1.0, 1.0))
         x = torch.poisson(size[:, None] * mean[None, :], generator=g)
         mask = x > 0
         cnts.append(mask.sum(1))
