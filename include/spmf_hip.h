@@ -56,6 +56,8 @@ extern "C" {
 
 /* flags for spmf_ctx_create */
 #define SPMF_FLAG_SCALE_ROWS 1u     /* poisson.py:61,644-649 */
+#define SPMF_FLAG_BERNOULLI 4u      /* BernoulliFactorization (mederrata_spmf/bernoulli.py): Bernoulli(logits=rate)
+                                     * likelihood :147-155, Normal priors on v,w :187-216; linear decoder only */
 #define SPMF_FLAG_LOG_TRANSFORM 2u  /* poisson.py:41-42,52-53: sparse stored-cell terms + dense f32-MFMA exp sums */
 
 typedef struct spmf_ctx spmf_ctx;

@@ -71,6 +71,10 @@ class OracleConfig:
     log_transform: bool = False
     eta_i: object = 1.0          # poisson.py:88-91  ([1,D] tensor or scalar 1.)
     xi_u_global: object = 1.0    # poisson.py:89
+    # 'poisson' (poisson.py) or 'bernoulli' (mederrata_spmf/bernoulli.py:32-649:
+    # Bernoulli(logits=rate) :148, Normal priors / Identity bijectors on v,w
+    # :187-216, encode without row scaling :572-589)
+    likelihood: str = "poisson"
     extra: dict = field(default_factory=dict)
 
 
@@ -99,6 +103,17 @@ def sqrt_inverse_gamma_log_prob(y, concentration, scale):
     p(y) = InvGamma(y^2; a, b) * 2y."""
     return (inverse_gamma_log_prob(y * y, concentration, scale)
             + math.log(2.0) + torch.log(y))
+
+
+def normal_log_prob(y, scale):
+    """tfd.Normal(0, scale).log_prob(y)."""
+    return -0.5 * math.log(2.0 * math.pi) - torch.log(scale) - 0.5 * (y / scale) ** 2
+
+
+def bernoulli_log_prob(x, logits):
+    """tfd.Bernoulli(logits).log_prob(x) = x*l - softplus(l)
+    (= -sigmoid_cross_entropy_with_logits)."""
+    return x * logits - torch.nn.functional.softplus(logits)
 
 
 def poisson_log_prob(x, rate):
@@ -170,7 +185,7 @@ def encode(cfg: OracleConfig, x, u, s):
     """poisson.py:623-650"""
     A = encoding_matrix(u, s)
     z = torch.matmul(encoder_function(cfg, x), A)
-    if cfg.scale_rows:
+    if cfg.scale_rows and cfg.likelihood != "bernoulli":   # bernoulli.py:572-589: no row scaling
         xi_u = x.sum(-1, keepdim=True) / _t(cfg.xi_u_global)
         z = z * xi_u
     return z
@@ -183,6 +198,8 @@ def log_likelihood_components(cfg: OracleConfig, x, s, u, v, w):
     B = decoding_matrix(v)
     theta_beta = decoder_function(cfg, torch.matmul(theta_u, B))
     rate = theta_beta + phi
+    if cfg.likelihood == "bernoulli":                          # bernoulli.py:147-155
+        return {"log_likelihood": bernoulli_log_prob(x, rate), "rate": rate}
     return {"log_likelihood": poisson_log_prob(x, rate), "rate": rate}
 
 
@@ -197,8 +214,12 @@ def prior_log_prob_parts(cfg: OracleConfig, p: Dict[str, torch.Tensor]):
     one = torch.tensor(1.0, dtype=F64)
     sm = lambda t: t.sum((-1, -2))
     out = {}
-    out["v"] = sm(halfnormal_log_prob(p["v"], torch.tensor(0.1, dtype=F64)))
-    out["w"] = sm(halfnormal_log_prob(p["w"], one))
+    if cfg.likelihood == "bernoulli":                          # bernoulli.py:187-216
+        out["v"] = sm(normal_log_prob(p["v"], torch.tensor(0.1, dtype=F64)))
+        out["w"] = sm(normal_log_prob(p["w"], one))
+    else:
+        out["v"] = sm(halfnormal_log_prob(p["v"], torch.tensor(0.1, dtype=F64)))
+        out["w"] = sm(halfnormal_log_prob(p["w"], one))
     out["u"] = sm(halfnormal_log_prob(
         p["u"], p["u_eta"] * p["u_tau"] * decay))                # :247-251
     out["s"] = sm(halfnormal_log_prob(p["s"], p["s_eta"] * p["s_tau"]))

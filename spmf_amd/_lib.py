@@ -21,6 +21,7 @@ PART_ORDER = VAR_ORDER + ("z", "x")
 
 FLAG_SCALE_ROWS = 1
 FLAG_LOG_TRANSFORM = 2
+FLAG_BERNOULLI = 4
 
 
 class SpmfError(RuntimeError):

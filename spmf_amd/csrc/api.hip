@@ -82,7 +82,7 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.phi = o;   o += al(D * sizeof(float));
   k.z = o;     o += al((size_t)rows * KP * sizeof(float));
   k.gzs = o;   o += al((size_t)rows * KP * sizeof(float));
-  k.gzd = o;   if (c->flags & SPMF_FLAG_LOG_TRANSFORM) o += al((size_t)rows * KP * sizeof(float));
+  k.gzd = o;   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI)) o += al((size_t)rows * KP * sizeof(float));
   k.total = o;
   return k;
 }
@@ -101,7 +101,11 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   c->D = D;
   c->KP = padded_k(K);
   // the dense exp kernels of the log_transform decoder work on 32-feature MFMA tiles
-  if ((flags & SPMF_FLAG_LOG_TRANSFORM) && c->KP < 32) c->KP = 32;
+  if ((flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI)) && c->KP < 32) c->KP = 32;
+  if ((flags & SPMF_FLAG_LOG_TRANSFORM) && (flags & SPMF_FLAG_BERNOULLI)) {
+    delete c;
+    return SPMF_E_UNSUPPORTED;   // Bernoulli with the exp decoder is not built
+  }
   c->flags = flags;
   *out = c;
   return SPMF_OK;
@@ -183,7 +187,7 @@ int spmf_ctx_enable_timing(spmf_ctx* c, int on) {
 
 int spmf_last_timing(spmf_ctx* c, float* ms5) {
   if (!c || !ms5) return SPMF_E_ARG;
-  const bool logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) != 0;
+  const bool logt = (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI)) != 0;
   if (!c->timing || c->ev_count < 1) return fail(c, SPMF_E_ARG, "no timing recorded (enable timing, run data_pass + finish)");
   // average over the (up to kSets) most recent complete steps
   const int n = c->ev_count < spmf_ctx::kSets ? c->ev_count : spmf_ctx::kSets;
@@ -236,9 +240,10 @@ int spmf_counts_stats(spmf_ctx* c, int64_t n_rows, const int32_t* row_ptr, const
 
 int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, void* stream) {
   if (!c || !params || !eta || S < 1) return fail(c, SPMF_E_ARG, "data_pass: bad arguments");
-  const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0;
+  // likelihood / decoder code of the kernels: 0 Poisson linear, 1 Poisson log_transform, 2 Bernoulli
+  const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : 0);
   int rc = check_counts(c, ct);
-  if (!rc && logt && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG, "counts: log_transform needs gval / pc_gval");
+  if (!rc && logt == 1 && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG, "counts: log_transform needs gval / pc_gval");
   if (rc) return rc;
   if (ct->n_rows > 0 && ct->nnz > 0 && (!ct->pc_row || !ct->pc_val || !ct->item_ptr || !ct->items || ct->n_panels < 1)) return fail(c, SPMF_E_ARG, "counts: panel-CSC arrays / work items missing");
   for (int i : {0, 1, 2, 7})
@@ -261,7 +266,7 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
     double* dacc = c->dacc + (size_t)s * kDaccRep * (kDaccHead + KP);
     double* dprep = c->dprep + (size_t)s * (KP + 1);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
-    PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt};
+    PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt == 1 ? 1 : 0};
     launch_prep(KP, pa, st);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
     const float* rscale = (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr;
@@ -272,11 +277,14 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
       // cores, then the stored-cell terms (sweep 2) with the dense row term.
-      RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, ct->gval, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 1, 1, nullptr};
+      RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, logt == 1 ? ct->gval : ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 1, logt, nullptr};
       launch_row_pass(KP, r1, st);
       if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
-      ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0};
-      launch_expdot(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E
+      const int act = logt == 2 ? 1 : 0;
+      float* gphi_acc = acc + (size_t)2 * D * KP;
+      // Z-stationary: Q rows are columns d -> bias_q = phi (Bernoulli logits)
+      ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0, act, nullptr, act ? c->phi : nullptr, nullptr};
+      launch_expdot(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E (or sum softplus)
       // W-stationary launch has only D/128 workgroups: split the row (Q) range
       // into chunks until ~4 workgroups per CU are in flight
       const int nbx = (D + 127) / 128;
@@ -284,10 +292,12 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
       int chunks = (1024 + nbx - 1) / nbx;
       if (chunks > qtiles) chunks = qtiles;
       if (chunks < 1) chunks = 1;
-      ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, chunks, 1};
+      // W-stationary: P rows are columns d -> bias_p = phi; Bernoulli also needs the
+      // column sums of sigmoid for d/dphi (subtracted from the gphi accumulators)
+      ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, chunks, 1, act, act ? c->phi : nullptr, nullptr, act ? gphi_acc : nullptr};
       launch_expdot(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
-      RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 2, 1, c->gzd};
+      RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 2, logt, c->gzd};
       launch_row_pass(KP, r2, st);
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
@@ -324,7 +334,7 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
       P[i] = params[i] + s * var_size(c, i);
       G[i] = grads[i] + s * var_size(c, i);
     }
-    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0};
+    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : 0)};
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
     launch_finish(KP, fa, st);
     if (tm) {
@@ -367,6 +377,7 @@ int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float*
 
 int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* v, const float* w, const float* s, const float* eta, float* rate_out, float* ll_out, void* stream) {
   if (!c || !u || !v || !w || !s || !eta || !rate_out || !ll_out) return fail(c, SPMF_E_ARG, "dense_ll: bad arguments");
+  if (c->flags & SPMF_FLAG_BERNOULLI) return fail(c, SPMF_E_UNSUPPORTED, "dense_ll: Bernoulli per-cell outputs are not built");
   const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0;
   int rc = check_counts(c, ct);
   if (!rc && logt && ct->nnz > 0 && !ct->gval) rc = fail(c, SPMF_E_ARG, "dense_ll: log_transform needs counts.gval");

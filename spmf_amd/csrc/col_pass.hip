@@ -51,7 +51,8 @@ namespace spmf {
 #define COL_GRP 4
 #endif
 
-template <int KP, bool LOGT>
+// LIK: 0 Poisson / linear, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
+template <int KP, int LIK>
 __global__ __launch_bounds__(256) void col_pass_kernel(
     int D, int n_panels, int row_base, int blocks_per_panel,
     const int32_t* __restrict__ item_ptr, const int4* __restrict__ items,
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     const int e = cur + sub;
     rr_ = sub < cnt_ ? pc_row[e] - row_base : 0;
     xx_ = sub < cnt_ ? pc_val[e] : 0.f;
-    gx_ = (LOGT && sub < cnt_) ? pc_gval[e] : 0.f;    // g(x) = log(x/eta+1), data side
+    gx_ = (LIK == 1 && sub < cnt_) ? pc_gval[e] : 0.f;  // g(x) = log(x/eta+1), data side
     cur += cnt_;
   };
 
@@ -116,20 +117,27 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
           const int src = grp * LPN + g0 + j;
           const int b = __shfl(rr0, src);
           xv[j] = __shfl(xx0, src);
-          gv[j] = LOGT ? __shfl(gx0, src) : xv[j];
+          gv[j] = LIK == 1 ? __shfl(gx0, src) : xv[j];
           zz[j] = gather4<LPN>(z, b, sub);
           gg[j] = gather4<LPN>(gzs, b, sub);
         }
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
-          const float y = group_sum<LPN>(dot4(zz[j], vp));
-          const float ey = LOGT ? expf(y) : 1.f;
-          const float r = (LOGT ? ey - 1.f : y) + ph;
-          // r <= 0 / NaN cells were counted by the row pass; +inf gives 0
-          const float xr = r > 0.f ? xv[j] * __builtin_amdgcn_rcpf(r) : 0.f;
-          gV = fma4(LOGT ? xr * ey : xr, zz[j], gV);
-          gA = fma4(gv[j], gg[j], gA);
-          gph += xr;
+          if (LIK == 2) {
+            // Bernoulli: d(x*logit)/dV' = x z_b, d/dphi = x: no rate needed
+            gV = fma4(xv[j], zz[j], gV);
+            gA = fma4(gv[j], gg[j], gA);
+            gph += xv[j];
+          } else {
+            const float y = group_sum<LPN>(dot4(zz[j], vp));
+            const float ey = LIK == 1 ? expf(y) : 1.f;
+            const float r = (LIK == 1 ? ey - 1.f : y) + ph;
+            // r <= 0 / NaN cells were counted by the row pass; +inf gives 0
+            const float xr = r > 0.f ? xv[j] * __builtin_amdgcn_rcpf(r) : 0.f;
+            gV = fma4(LIK == 1 ? xr * ey : xr, zz[j], gV);
+            gA = fma4(gv[j], gg[j], gA);
+            gph += xr;
+          }
         }
       }
     }
@@ -166,14 +174,14 @@ static void launch_col_t(const ColArgs& a, hipStream_t st) {
   const int64_t nt = (a.n_panels + 7) / 8;
   const int64_t nb = nt * bpp * 8;
   const int4* items = reinterpret_cast<const int4*>(a.items);
-  if (a.logt)
-    hipLaunchKernelGGL((col_pass_kernel<KP, true>), dim3((unsigned)nb), dim3(256), 0, st, a.D,
-                       a.n_panels, a.row_base, bpp, a.item_ptr, items, a.pc_row, a.pc_val,
-                       a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi);
-  else
-    hipLaunchKernelGGL((col_pass_kernel<KP, false>), dim3((unsigned)nb), dim3(256), 0, st, a.D,
-                       a.n_panels, a.row_base, bpp, a.item_ptr, items, a.pc_row, a.pc_val,
-                       a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi);
+#define SPMF_COL_LAUNCH(L_)                                                                    \
+  hipLaunchKernelGGL((col_pass_kernel<KP, L_>), dim3((unsigned)nb), dim3(256), 0, st, a.D,     \
+                     a.n_panels, a.row_base, bpp, a.item_ptr, items, a.pc_row, a.pc_val,       \
+                     a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi)
+  if (a.logt == 2) SPMF_COL_LAUNCH(2);
+  else if (a.logt == 1) SPMF_COL_LAUNCH(1);
+  else SPMF_COL_LAUNCH(0);
+#undef SPMF_COL_LAUNCH
 }
 
 void launch_col_pass(int KP, const ColArgs& a, hipStream_t st) {

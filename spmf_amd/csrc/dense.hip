@@ -33,11 +33,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int QT = 128;  // Q rows per LDS stage
 
-template <int KD>
+// ACT 0: E = exp(X)                         esum += sum E          (Poisson, log_transform)
+// ACT 1: E = sigmoid(X + bias)              esum += sum softplus(X + bias)   (Bernoulli logits,
+//        bernoulli.py:147-155; bias = phi of the column: bias_q when Q rows are columns,
+//        bias_p when P rows are columns); out2[p] += sign * sum_q E (the d/dphi column sums)
+template <int KD, int ACT>
 __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float* __restrict__ P,
                                                      const float* __restrict__ Q,
                                                      float* __restrict__ out, float sign,
-                                                     double* __restrict__ esum, int atomic_out) {
+                                                     double* __restrict__ esum, int atomic_out,
+                                                     const float* __restrict__ bias_p,
+                                                     const float* __restrict__ bias_q,
+                                                     float* __restrict__ out2) {
   constexpr int PITCH = KD + 4;   // 16-B aligned rows; (KD+4) % 64 = 4 keeps b128 column reads conflict free
   constexpr int KH = KD / 2;      // lane half h covers k in [h*KH, (h+1)*KH): any k order is valid
                                   // as long as A and B agree, and this one makes A a contiguous read
@@ -70,6 +77,8 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
   double es = 0.0;
+  float colsum = 0.f;                                   // ACT 1: sum_q E for this lane's p
+  const float bp = (ACT == 1 && bias_p && p < NP) ? bias_p[p] : 0.f;
 
   // stage loader: 256 threads move the QT*KD floats of a tile in QT/32 parts
   // (one 32-row part per sub-tile of the compute loop: only PER registers live)
@@ -105,8 +114,8 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
   for (int tile = tile0; tile < tile1; ++tile) {
     const int buf = (tile - tile0) & 1;
     const bool more = tile + 1 < tile1;     // block-uniform
-    // interior tiles need no masking (block-uniform)
-    const bool edge = (tile * QT + QT > NQ) || ((int)(blockIdx.x * 128 + 128) > NP);
+    // interior tiles need no masking (block-uniform); the sigmoid form always masks
+    const bool edge = ACT == 1 || (tile * QT + QT > NQ) || ((int)(blockIdx.x * 128 + 128) > NP);
     const float* qb = qs[buf];
     const int q0 = tile * QT;
     // Software pipeline over the 4 sub-tiles of the stage: product 1 of
@@ -148,7 +157,21 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
       // ---- E = exp(X), masked outside [NQ) x [NP) ------------------------
       // exp via v_exp_f32 (2^x): |rel err| ~ 1e-7 * (1 + |x|), inside the 1e-5 budget
       float part = 0.f;
-      if (edge) {
+      if (ACT == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int q = q0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool in = q < NQ && p < NP;
+          const float l = xcur[i] + bp + ((bias_q && in) ? bias_q[q] : 0.f);
+          const float en = __expf(-fabsf(l));             // exp(-|l|) in (0,1]
+          const float inv = __builtin_amdgcn_rcpf(1.f + en);
+          const float sg = l >= 0.f ? inv : en * inv;     // sigmoid(l)
+          const float sp = fmaxf(l, 0.f) + __logf(1.f + en);   // softplus(l)
+          xcur[i] = in ? sg : 0.f;
+          part += in ? sp : 0.f;
+          colsum += in ? sg : 0.f;
+        }
+      } else if (edge) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int q = q0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -195,6 +218,10 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
         }
       }
   }
+  if (ACT == 1 && out2) {
+    colsum += __shfl_xor(colsum, 32);                   // the two lane halves hold disjoint q rows
+    if (h == 0 && p < NP && colsum != 0.f) atomicAdd(&out2[p], sign * colsum);
+  }
   if (esum) {
     const double tot = block_sum(es, red);
     if (t == 0) atomicAdd(esum, tot);
@@ -205,12 +232,14 @@ void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st) {
   const int nbx = (a.NP + 127) / 128;
   int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
   dim3 grid(nbx, chunks);
-  if (KD == 32)
-    hipLaunchKernelGGL(expdot_kernel<32>, grid, dim3(256), 0, st, a.NP, a.NQ, a.P, a.Q, a.out,
-                       a.sign, a.esum, a.atomic_out);
-  else if (KD == 64)
-    hipLaunchKernelGGL(expdot_kernel<64>, grid, dim3(256), 0, st, a.NP, a.NQ, a.P, a.Q, a.out,
-                       a.sign, a.esum, a.atomic_out);
+#define SPMF_ED_LAUNCH(KD_, ACT_)                                                              \
+  hipLaunchKernelGGL((expdot_kernel<KD_, ACT_>), grid, dim3(256), 0, st, a.NP, a.NQ, a.P, a.Q, \
+                     a.out, a.sign, a.esum, a.atomic_out, a.bias_p, a.bias_q, a.out2)
+  if (KD == 32 && a.act == 0) SPMF_ED_LAUNCH(32, 0);
+  else if (KD == 32) SPMF_ED_LAUNCH(32, 1);
+  else if (KD == 64 && a.act == 0) SPMF_ED_LAUNCH(64, 0);
+  else if (KD == 64) SPMF_ED_LAUNCH(64, 1);
+#undef SPMF_ED_LAUNCH
 }
 
 }  // namespace spmf

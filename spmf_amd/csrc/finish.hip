@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     }
     w1s[t] = w1;
     etas_[t] = e;
-    ietas[t] = logt ? 1.f : 1.f / e;   // A' = w1*u/eta (linear) or w1*u (log_transform)
+    ietas[t] = logt == 1 ? 1.f : 1.f / e;   // A' = w1*u/eta (linear) or w1*u (log_transform)
     GAs[t] = 0.f;
   }
   __syncthreads();
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       const float v = P.p[V_][i];
       float lp, gy, gs;
       halfnormal(v, 0.1f, lp, gy, gs);
+      if (logt == 2) lp -= (float)kLog2;   // Bernoulli: v ~ Normal(0,.1) (bernoulli.py:187-200)
       part[V_] += (double)lp;
       G.p[V_][i] = tile[k][dl] + pw * gy;
     }
@@ -177,10 +178,12 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     const float s0 = P.p[S_][d], s1 = P.p[S_][D + d], w = P.p[W_][d];
     const float T = s0 + s1, iT2 = 1.f / (T * T);
     const float w2 = s1 / T;
-    const float dphi = gph[d] - (float)Bglob;
+    // Poisson: sum_b x/r - B; Bernoulli: sum_nnz x - sum_b sigmoid (dense kernel already applied)
+    const float dphi = logt == 2 ? gph[d] : gph[d] - (float)Bglob;
     const float GA = GAs[t], Gphi = e * w * dphi;
     float lp, gy, gs;
     halfnormal(w, 1.f, lp, gy, gs);
+    if (logt == 2) lp -= (float)kLog2;     // Bernoulli: w ~ Normal(0,1) (bernoulli.py:201-216)
     part[W_] += (double)lp;
     G.p[W_][d] = e * w2 * dphi + pw * gy;
     const float se0 = P.p[SETA_][d], se1 = P.p[SETA_][D + d], stau = P.p[STAU_][d];
@@ -247,11 +250,13 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     const double llx = unpack(tail, 0), zsq = unpack(tail, 1);
     // sum of the rate over ALL cells: closed form (linear) or the dense exp sum
     double sum_r = Bglob * dprep[KP];
-    if (logt)
+    if (logt == 2)
+      sum_r = unpack(tail, 3);                 // sum over all cells of softplus(logit)
+    else if (logt == 1)
       sum_r += unpack(tail, 3) - Bglob * (double)D;
     else
       for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * dprep[k];
-    atomicAdd(&parts[13], llx - lgamma_sum - sum_r);
+    atomicAdd(&parts[13], llx - (logt == 2 ? 0.0 : lgamma_sum) - sum_r);
     atomicAdd(&parts[12], Bglob * (double)K * kHalfLog2OverPi - 0.5 * zsq);
     if (nnf_out) *nnf_out = unpack(tail, 2);
   }

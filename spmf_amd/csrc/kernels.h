@@ -51,6 +51,9 @@ struct ExpdotArgs {
   double* esum;        // may be null
   int q_chunks;        // gridDim.y; >1 needs atomic_out
   int atomic_out;
+  int act;             // 0 exp (Poisson log_transform), 1 sigmoid/softplus (Bernoulli)
+  const float *bias_p, *bias_q;  // act 1: logit bias per P row / per Q row (one of them)
+  float* out2;         // act 1: out2[p] += sign * sum_q sigmoid (may be null)
 };
 void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st);
 

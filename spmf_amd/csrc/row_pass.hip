@@ -33,7 +33,8 @@ namespace spmf {
 
 namespace {
 
-template <int KP, bool LOGT>
+// LIK: 0 Poisson / linear decoder, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
+template <int KP, int LIK>
 struct RowCtx {
   static constexpr int LPN = KP / 4;
   static constexpr int NPI = 64 / LPN;
@@ -92,14 +93,25 @@ struct RowCtx {
     const int cs = __shfl(c, slot);
     float cc = 0.f;
     if (slot < nchunk && xs > 0.f) {
-      // linear decoder: r = <z,V'> + phi; log_transform: r = exp(<z,V'>) - 1 + phi
-      const float ey = LOGT ? expf(rmine) : 1.f;
-      const float r = (LOGT ? ey - 1.f : rmine) + phi[cs];
-      if (r > 0.f && r < INFINITY) {
-        ll = fmaf(xs, logf(r), ll);
-        cc = xs * ey * __builtin_amdgcn_rcpf(r);   // d(x log r)/d<z,V'>
+      if (LIK == 2) {
+        // Bernoulli(logits = <z,V'> + phi) (bernoulli.py:147-155): stored-cell part x*logit
+        const float lg = rmine + phi[cs];
+        if (lg > -INFINITY && lg < INFINITY) {
+          ll = fmaf(xs, lg, ll);
+          cc = xs;                                   // d(x*logit)/d<z,V'>
+        } else {
+          nnf += 1.0;
+        }
       } else {
-        nnf += 1.0;
+        // linear decoder: r = <z,V'> + phi; log_transform: r = exp(<z,V'>) - 1 + phi
+        const float ey = LIK == 1 ? expf(rmine) : 1.f;
+        const float r = (LIK == 1 ? ey - 1.f : rmine) + phi[cs];
+        if (r > 0.f && r < INFINITY) {
+          ll = fmaf(xs, logf(r), ll);
+          cc = xs * ey * __builtin_amdgcn_rcpf(r);   // d(x log r)/d<z,V'>
+        } else {
+          nnf += 1.0;
+        }
       }
     }
 #pragma unroll
@@ -117,7 +129,7 @@ struct RowCtx {
 
 }  // namespace
 
-template <int KP, bool LOGT>
+template <int KP, int LIK>
 __global__ __launch_bounds__(256) void row_pass_kernel(
     int64_t B, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ row_scale,
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256) void row_pass_kernel(
     double* __restrict__ dacc, int mode, const float* __restrict__ gzd) {
   const bool encode_only = mode == 1;
   constexpr int LPN = KP / 4;
-  RowCtx<KP, LOGT> cx;
+  RowCtx<KP, LIK> cx;
   cx.Ap = Ap;
   cx.Vp = Vp;
   cx.phi = phi;
@@ -244,14 +256,14 @@ template <int KP>
 static void launch_row_t(const RowArgs& a, hipStream_t st) {
   int64_t want = (a.B + 3) / 4;  // 4 waves (rows in flight) per 256-thread block
   int nb = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
-  if (a.logt)
-    hipLaunchKernelGGL((row_pass_kernel<KP, true>), dim3(nb), dim3(256), 0, st, a.B, a.row_ptr,
-                       a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, a.gzs, a.dacc,
-                       a.mode, a.gzd);
-  else
-    hipLaunchKernelGGL((row_pass_kernel<KP, false>), dim3(nb), dim3(256), 0, st, a.B, a.row_ptr,
-                       a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, a.gzs, a.dacc,
-                       a.mode, a.gzd);
+#define SPMF_ROW_LAUNCH(L_)                                                                    \
+  hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb), dim3(256), 0, st, a.B, a.row_ptr,    \
+                     a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, a.gzs, a.dacc, \
+                     a.mode, a.gzd)
+  if (a.logt == 2) SPMF_ROW_LAUNCH(2);
+  else if (a.logt == 1) SPMF_ROW_LAUNCH(1);
+  else SPMF_ROW_LAUNCH(0);
+#undef SPMF_ROW_LAUNCH
 }
 
 void launch_row_pass(int KP, const RowArgs& a, hipStream_t st) {

@@ -42,6 +42,8 @@ class PoissonFactorization:
     bijectors = None
     var_list = []
     s_tau_scale = 1
+    _likelihood_flag = 0          # extra ctx flag of a subclass (BernoulliFactorization)
+    _identity_vars = ()           # variables with an Identity bijector in the surrogate
 
     def __init__(
             self,
@@ -106,7 +108,7 @@ class PoissonFactorization:
                     "the HIP hot path needs a GPU device (no CPU fallback)")
             lib = _lib.load()
             flags = (_lib.FLAG_SCALE_ROWS if self.scale_rows else 0) | (
-                _lib.FLAG_LOG_TRANSFORM if self.log_transform else 0)
+                _lib.FLAG_LOG_TRANSFORM if self.log_transform else 0) | self._likelihood_flag
             h = C.c_void_p()
             rc = lib.spmf_ctx_create(self.device.index or 0, int(self.latent_dim),
                                      int(self.feature_dim), flags, C.byref(h))

@@ -71,10 +71,13 @@ class Surrogate:
         self.trainable_variables: List[torch.Tensor] = []
         self._index = {}
         init = _initial_state(D, K, model.u_tau_scale, model.s_tau_scale)
+        identity = set(getattr(model, "_identity_vars", ()))
         for n in VAR_ORDER:
             kind, a, b = init[n]
+            if n in identity:          # tfb.Identity(Normal): bernoulli.py:187-193,362-381
+                kind = "normal_identity"
             self.kinds[n] = kind
-            if kind == "normal":
+            if kind in ("normal", "normal_identity"):
                 t0, t1 = a, softplus_inverse(b)                 # loc, raw scale
             else:
                 t0, t1 = softplus_inverse(a), softplus_inverse(b)  # raw conc, raw scale
@@ -97,7 +100,7 @@ class Surrogate:
         for n in VAR_ORDER:
             t0, t1 = self.params_of(n)
             shape = (S,) + tuple(t0.shape)
-            if self.kinds[n] == "normal":
+            if self.kinds[n] in ("normal", "normal_identity"):
                 sigma = _sp(t1)
                 eps = torch.randn(shape, device=self.device, dtype=torch.float32,
                                   generator=generator)
@@ -113,8 +116,11 @@ class Surrogate:
                 g = g.clamp_min(1e-30)
                 y = b / g
                 lq = (a * torch.log(b) - torch.lgamma(a) - (a + 1.0) * torch.log(y) - b / y)
-            th = _sp(y)
-            lq = lq - torch.nn.functional.logsigmoid(y)
+            if self.kinds[n] == "normal_identity":
+                th = y                                          # no Jacobian
+            else:
+                th = _sp(y)
+                lq = lq - torch.nn.functional.logsigmoid(y)
             theta[n] = th
             logq = logq + lq.sum((-1, -2))
         return theta, logq

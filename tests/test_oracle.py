@@ -211,3 +211,29 @@ def test_surrogate_initial_state_shapes_and_order():
         "normal", T(st_["u"]["loc"]), T(O.softplus_inverse(st_["u"]["scale"])),
         torch.zeros(5, 3, dtype=F64))
     assert torch.all(th > 0) and th.max() < 3e-3 and torch.isfinite(lq)
+
+
+def test_bernoulli_restatement():
+    """mederrata_spmf/bernoulli.py: Bernoulli(logits) log-pmf, Normal priors on
+    v,w, encode without row scaling."""
+    rng = np.random.default_rng(4)
+    l = rng.normal(0, 3, size=40)
+    x = (rng.random(40) < 0.4).astype(np.float64)
+    from scipy.special import expit
+    np.testing.assert_allclose(
+        O.bernoulli_log_prob(T(x), T(l)).numpy(),
+        st.bernoulli.logpmf(x.astype(int), expit(l)), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(O.normal_log_prob(T(l), T(0.1)).numpy(),
+                               st.norm.logpdf(l, scale=0.1), rtol=1e-12)
+    cfg, xx, params = _problem(9, 7, 2, 1, 5)
+    cfg.likelihood = "bernoulli"
+    xb = (xx > 0).astype(np.float64)
+    params["v"] = -params["v"]            # Identity bijector: any sign
+    z = O.encode(cfg, T(xb), T(params["u"]), T(params["s"]))
+    A = O.encoding_matrix(T(params["u"]), T(params["s"]))
+    np.testing.assert_allclose(z.numpy(), (T(xb) / cfg.eta_i @ A).numpy(), rtol=1e-13)
+    parts = O.unormalized_log_prob_parts(cfg, xb, params)
+    assert abs(parts["v"].item() - st.norm.logpdf(params["v"], scale=0.1).sum()) < 1e-9
+    logits = (z @ T(params["v"])) * cfg.eta_i + O.intercept_matrix(cfg, T(params["w"]), T(params["s"]))
+    ll = st.bernoulli.logpmf(xb.astype(int), expit(logits.numpy()[0])).sum()
+    assert abs(parts["x"].item() - ll) < 1e-9
