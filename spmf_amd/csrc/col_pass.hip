@@ -68,11 +68,19 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
   const int sub = lane % LPN, grp = lane / LPN;
   const int wid = threadIdx.x >> 6;
   // block id -> (panel, block of 4*NG items); blockIdx % 8 = panel residue
+  // (batches of fewer than 8 panels use a flat mapping: the residue mapping
+  // would leave the XCDs of the missing residues with empty workgroups only)
   const int64_t L = blockIdx.x;
-  const int x = (int)(L & 7);
-  const int64_t q = L >> 3;
-  const int t = (int)(q / blocks_per_panel), ib = (int)(q % blocks_per_panel);
-  const int p = 8 * t + x;
+  int p, ib;
+  if (n_panels < 8) {
+    p = (int)(L / blocks_per_panel);
+    ib = (int)(L % blocks_per_panel);
+  } else {
+    const int x = (int)(L & 7);
+    const int64_t q = L >> 3;
+    p = 8 * (int)(q / blocks_per_panel) + x;
+    ib = (int)(q % blocks_per_panel);
+  }
   if (p >= n_panels) return;                          // block-uniform
   const int i0 = item_ptr[p] + ib * 4 * NG;
   if (i0 >= item_ptr[p + 1]) return;                  // block-uniform
@@ -172,7 +180,7 @@ static void launch_col_t(const ColArgs& a, hipStream_t st) {
   const int bpp = (a.max_items_per_panel + per_block - 1) / per_block;
   if (bpp < 1) return;
   const int64_t nt = (a.n_panels + 7) / 8;
-  const int64_t nb = nt * bpp * 8;
+  const int64_t nb = a.n_panels < 8 ? (int64_t)a.n_panels * bpp : nt * bpp * 8;
   const int4* items = reinterpret_cast<const int4*>(a.items);
 #define SPMF_COL_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((col_pass_kernel<KP, L_>), dim3((unsigned)nb), dim3(256), 0, st, a.D,     \
