@@ -184,6 +184,51 @@ int spmf_dense_ll(spmf_ctx* ctx, const spmf_counts* counts, const float* u,
 int spmf_nonfinite_reduce(spmf_ctx* ctx, int64_t n, const float* ll, int pass,
                           double* io, void* stream);
 
+/* ---- VI step around the energy: surrogate posterior and optimiser ------- */
+/* One latent variable of the mean-field surrogate (poisson.py:403-569).
+ * kind 0: theta = softplus(t0 + softplus(t1)*eps)      (tfb.Softplus(Normal))
+ * kind 1: theta = t0 + softplus(t1)*eps                (tfb.Identity(Normal), bernoulli.py:187-193)
+ * kind 2: theta = softplus(softplus(t1) / g), g ~ Gamma(softplus(t0), 1)
+ *                                                      (tfb.Softplus(InverseGamma))
+ * noise = eps or g, [S,n]; dgda = d g / d concentration [S,n] (kind 2). */
+typedef struct spmf_sur_var {
+  const float* t0;
+  const float* t1;
+  const float* noise;
+  const float* dgda;
+  float* theta;        /* [S,n] written by spmf_surrogate_fwd */
+  const float* gtheta; /* [S,n] dE/dtheta, read by spmf_surrogate_bwd */
+  float* g0;           /* [n] d loss / d t0, written by spmf_surrogate_bwd */
+  float* g1;           /* [n] d loss / d t1 */
+  int32_t n;
+  int32_t kind;
+} spmf_sur_var;
+
+/* theta for every variable and logq[S] (fp64) = sum over variables and
+ * elements of log q(theta). */
+int spmf_surrogate_fwd(spmf_ctx* ctx, const spmf_sur_var* vars, int nvars, int S,
+                       double* logq, void* stream);
+/* Gradient of  loss = -(1/(S*B)) sum_s [E_s - c*logq_s]  wrt the trainables,
+ * given gtheta = dE/dtheta; inv_sb = 1/(S*B).  (E = x + z +
+ * c*prior, c = B/N.) */
+int spmf_surrogate_bwd(spmf_ctx* ctx, const spmf_sur_var* vars, int nvars, int S,
+                       double inv_sb, double c, void* stream);
+
+typedef struct spmf_adam_var {
+  float* p;
+  float* m;
+  float* v;
+  const float* g;
+  int32_t n;
+  int32_t reserved_;
+} spmf_adam_var;
+/* tf.keras-style Adam (bias-corrected, eps outside the sqrt) over up to 24
+ * tensors in one launch; clip > 0 clips each gradient element to [-clip, clip]
+ * first (clip_value, bin/factorize_csv.py:44-47); step is 1-based. */
+int spmf_adam_step(spmf_ctx* ctx, const spmf_adam_var* tensors, int ntensors, double lr,
+                   double beta1, double beta2, double eps, int step, double clip,
+                   void* stream);
+
 /* Test/diagnostic taps: per-row z and d/dz of the LAST draw processed by
  * spmf_data_pass, [B,KP] fp32 with KP = spmf_padded_k(). */
 int spmf_padded_k(const spmf_ctx* ctx);

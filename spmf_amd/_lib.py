@@ -46,6 +46,19 @@ class CountsStruct(C.Structure):
 
 PtrArray = C.c_void_p * NVARS
 
+
+class SurVar(C.Structure):
+    """struct spmf_sur_var"""
+    _fields_ = [("t0", C.c_void_p), ("t1", C.c_void_p), ("noise", C.c_void_p),
+                ("dgda", C.c_void_p), ("theta", C.c_void_p), ("gtheta", C.c_void_p),
+                ("g0", C.c_void_p), ("g1", C.c_void_p), ("n", C.c_int32), ("kind", C.c_int32)]
+
+
+class AdamVar(C.Structure):
+    """struct spmf_adam_var"""
+    _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p),
+                ("n", C.c_int32), ("reserved_", C.c_int32)]
+
 #: every symbol include/spmf_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "spmf_version": (C.c_int, []),
@@ -72,6 +85,13 @@ SIGNATURES = {
     "spmf_dense_ll": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct)] + [C.c_void_p] * 8),
     "spmf_nonfinite_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p]),
+    "spmf_surrogate_fwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
+    "spmf_surrogate_bwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
+                                     C.c_double, C.c_double, C.c_void_p]),
+    "spmf_adam_step": (C.c_int, [C.c_void_p, C.POINTER(AdamVar), C.c_int, C.c_double,
+                                 C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
+                                 C.c_void_p]),
     "spmf_padded_k": (C.c_int, [C.c_void_p]),
     "spmf_z_ptr": (C.c_void_p, [C.c_void_p]),
     "spmf_gz_ptr": (C.c_void_p, [C.c_void_p]),

@@ -3,6 +3,7 @@
 // ordered launches.  No device allocation, no host<->device copies, no
 // synchronisation on the hot path (timing taps excepted, off by default).
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -401,6 +402,54 @@ int spmf_nonfinite_reduce(spmf_ctx* c, int64_t n, const float* ll, int pass, dou
   if (!c || !ll || !io || n < 0 || (pass != 0 && pass != 1)) return fail(c, SPMF_E_ARG, "nonfinite_reduce: bad arguments");
   if (n == 0) return SPMF_OK;
   launch_nonfinite(n, ll, pass, io, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, double* logq, void* stream) {
+  if (!c || !vars || nvars < 1 || nvars > 12 || S < 1 || !logq) return fail(c, SPMF_E_ARG, "surrogate_fwd: bad arguments");
+  SurTable T;
+  int max_n = 0;
+  for (int i = 0; i < nvars; ++i) {
+    const spmf_sur_var& v = vars[i];
+    if (!v.t0 || !v.t1 || !v.noise || !v.theta || v.n < 1 || v.kind < 0 || v.kind > 2) return fail(c, SPMF_E_ARG, "surrogate_fwd: bad variable");
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind};
+    if (v.n > max_n) max_n = v.n;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipMemsetAsync(logq, 0, (size_t)S * sizeof(double), st));
+  launch_surrogate_fwd(T, nvars, max_n, S, logq, st);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_surrogate_bwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, double inv_sb, double cw, void* stream) {
+  if (!c || !vars || nvars < 1 || nvars > 12 || S < 1) return fail(c, SPMF_E_ARG, "surrogate_bwd: bad arguments");
+  SurTable T;
+  int max_n = 0;
+  for (int i = 0; i < nvars; ++i) {
+    const spmf_sur_var& v = vars[i];
+    if (!v.t0 || !v.t1 || !v.noise || !v.gtheta || !v.g0 || !v.g1 || v.n < 1 || v.kind < 0 || v.kind > 2 || (v.kind == 2 && !v.dgda)) return fail(c, SPMF_E_ARG, "surrogate_bwd: bad variable");
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind};
+    if (v.n > max_n) max_n = v.n;
+  }
+  launch_surrogate_bwd(T, nvars, max_n, S, (float)inv_sb, (float)cw, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_adam_step(spmf_ctx* c, const spmf_adam_var* tensors, int ntensors, double lr, double beta1, double beta2, double eps, int step, double clip, void* stream) {
+  if (!c || !tensors || ntensors < 1 || ntensors > 24 || step < 1) return fail(c, SPMF_E_ARG, "adam_step: bad arguments");
+  AdamTable T;
+  int max_n = 0;
+  for (int i = 0; i < ntensors; ++i) {
+    const spmf_adam_var& a = tensors[i];
+    if (!a.p || !a.m || !a.v || !a.g || a.n < 1) return fail(c, SPMF_E_ARG, "adam_step: bad tensor");
+    T.v[i] = AdamVar{a.p, a.m, a.v, a.g, a.n};
+    if (a.n > max_n) max_n = a.n;
+  }
+  const double c1 = 1.0 - pow(beta1, step), c2 = 1.0 - pow(beta2, step);
+  launch_adam(T, ntensors, max_n, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)c1, (float)c2, (float)clip, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;
 }

@@ -94,6 +94,32 @@ struct FinishArgs {
 };
 void launch_finish(int KP, const FinishArgs& a, hipStream_t st);
 
+// ---- surrogate posterior / optimiser (surrogate.hip) ----------------------
+struct SurVar {
+  const float* t0;      // loc            | raw concentration
+  const float* t1;      // raw scale      | raw scale
+  const float* noise;   // [S,n] eps ~ N(0,1) | g ~ Gamma(softplus(t0), 1)
+  const float* dgda;    // [S,n] d g / d a (kind 2 only)
+  float* theta;         // [S,n] out (fwd)
+  const float* gtheta;  // [S,n] dE/dtheta (bwd)
+  float *g0, *g1;       // [n] out (bwd)
+  int n, kind;          // kind 0 softplus-normal, 1 identity-normal, 2 softplus-invgamma
+};
+struct SurTable {
+  SurVar v[12];
+};
+struct AdamVar {
+  float *p, *m, *v;
+  const float* g;
+  int n;
+};
+struct AdamTable {
+  AdamVar v[24];
+};
+void launch_surrogate_fwd(const SurTable& T, int nvars, int max_n, int S, double* logq, hipStream_t st);
+void launch_surrogate_bwd(const SurTable& T, int nvars, int max_n, int S, float inv_sb, float c, hipStream_t st);
+void launch_adam(const AdamTable& T, int ntensors, int max_n, float lr, float b1, float b2, float eps, float c1, float c2, float clip, hipStream_t st);
+
 struct StatsArgs {
   int64_t B;
   const int32_t* row_ptr;

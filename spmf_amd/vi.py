@@ -13,9 +13,13 @@ The surrogate is the reference's (poisson.py:403-539): Softplus(Normal) for
 u, v, w, s and Softplus(InverseGamma) for the scale hierarchy; positive
 distribution parameters are softplus(raw) trainables.
 
-Sampling, log q and the reparameterisation chain are plain torch autograd
-(driver plumbing); the energy and its gradient wrt the sampled parameters
-are the HIP hot path.
+The VI step runs on the device end to end: base noise comes from torch's
+generators (``randn`` / ``_standard_gamma`` and its implicit-reparameterisation
+derivative -- RNG plumbing), everything else -- the transform to theta, log q,
+the energy and its gradient, the chain back to the trainables and the Adam
+update -- are HIP kernels behind the C-ABI (surrogate.hip + the hot path).
+``Surrogate.rsample`` / ``elbo_step_reference`` keep a plain torch-autograd
+restatement of the same step; the tests use it as the fp32 reference.
 """
 from __future__ import annotations
 
@@ -27,6 +31,9 @@ from typing import Dict, List
 import numpy as np
 import torch
 
+import ctypes as C
+
+from . import _lib
 from ._lib import VAR_ORDER
 
 _sp = torch.nn.functional.softplus
@@ -125,6 +132,65 @@ class Surrogate:
             logq = logq + lq.sum((-1, -2))
         return theta, logq
 
+    # ---- HIP path -------------------------------------------------------
+    _KIND = {"normal": 0, "normal_identity": 1, "invgamma": 2}
+
+    @torch.no_grad()
+    def draw_noise(self, S):
+        """Base noise per variable: eps ~ N(0,1) [S,*shape], or for the
+        InverseGamma kinds g ~ Gamma(softplus(t0), 1) and d g/d concentration."""
+        out = {}
+        for n in VAR_ORDER:
+            t0, _ = self.params_of(n)
+            shape = (S,) + tuple(t0.shape)
+            if self.kinds[n] == "invgamma":
+                a = _sp(t0).expand(shape).contiguous()
+                g = torch._standard_gamma(a).clamp_min_(1e-30)
+                out[n] = (g, torch._standard_gamma_grad(a, g))
+            else:
+                out[n] = (torch.randn(shape, device=self.device, dtype=torch.float32), None)
+        return out
+
+    def _table(self, S, noise, theta=None, gtheta=None, grads=None):
+        arr = (_lib.SurVar * len(VAR_ORDER))()
+        for i, n in enumerate(VAR_ORDER):
+            t0, t1 = self.params_of(n)
+            nz, dg = noise[n]
+            v = arr[i]
+            v.t0, v.t1 = t0.data_ptr(), t1.data_ptr()
+            v.noise = nz.data_ptr()
+            v.dgda = dg.data_ptr() if dg is not None else None
+            v.theta = theta[n].data_ptr() if theta is not None else None
+            v.gtheta = gtheta[n].data_ptr() if gtheta is not None else None
+            v.g0 = grads[2 * i].data_ptr() if grads is not None else None
+            v.g1 = grads[2 * i + 1].data_ptr() if grads is not None else None
+            v.n, v.kind = t0.numel(), self._KIND[self.kinds[n]]
+        return arr
+
+    @torch.no_grad()
+    def forward_hip(self, model, S, noise):
+        """theta (dict name -> [S,*shape]) and logq [S] (float64) by the HIP kernel."""
+        lib, h = _lib.load(), model._handle()
+        theta = {n: torch.empty_like(noise[n][0]) for n in VAR_ORDER}
+        logq = torch.empty(S, dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        arr = self._table(S, noise, theta=theta)
+        _lib.check(h, lib.spmf_surrogate_fwd(h, arr, len(VAR_ORDER), S, logq.data_ptr(), stream),
+                   "spmf_surrogate_fwd")
+        return theta, logq
+
+    @torch.no_grad()
+    def backward_hip(self, model, S, noise, gtheta, inv_sb, c):
+        """d loss / d trainables (list in trainable order) given dE/dtheta."""
+        lib, h = _lib.load(), model._handle()
+        grads = [torch.empty_like(p) for p in self.trainable_variables]
+        gt = {n: gtheta[n].contiguous() for n in VAR_ORDER}
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        arr = self._table(S, noise, gtheta=gt, grads=grads)
+        _lib.check(h, lib.spmf_surrogate_bwd(h, arr, len(VAR_ORDER), S, float(inv_sb), float(c),
+                                             stream), "spmf_surrogate_bwd")
+        return grads
+
     @torch.no_grad()
     def sample(self, n=1):
         th, _ = self.rsample(n)
@@ -170,8 +236,56 @@ class Adam:
             p.addcdiv_(m / c1, (v / c2).sqrt_().add_(self.eps), value=-self.lr)
 
 
-def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None, generator=None):
-    """One stochastic ELBO evaluation + gradient wrt the surrogate trainables.
+class AdamHIP:
+    """The same update as ``Adam`` in one HIP launch over all trainables
+    (spmf_adam_step), value clipping fused."""
+
+    def __init__(self, model, params, lr, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.model, self.params, self.lr = model, params, lr
+        self.b1, self.b2, self.eps, self.t = beta1, beta2, eps, 0
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+
+    @torch.no_grad()
+    def step(self, grads, clip_value=None):
+        lib, h = _lib.load(), self.model._handle()
+        self.t += 1
+        arr = (_lib.AdamVar * len(self.params))()
+        keep = []
+        for i, (p, g, m, v) in enumerate(zip(self.params, grads, self.m, self.v)):
+            g = g.contiguous()
+            keep.append(g)
+            a = arr[i]
+            a.p, a.m, a.v, a.g, a.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), p.numel()
+        stream = torch.cuda.current_stream(p.device).cuda_stream
+        _lib.check(h, lib.spmf_adam_step(h, arr, len(self.params), float(self.lr), self.b1,
+                                         self.b2, self.eps, self.t,
+                                         float(clip_value) if clip_value else 0.0, stream),
+                   "spmf_adam_step")
+
+
+def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None):
+    """One stochastic ELBO evaluation + gradient wrt the surrogate trainables,
+    all arithmetic in HIP kernels.  Returns (loss, grads list, n_nonfinite)."""
+    sur = model.surrogate_distribution
+    S = int(sample_size)
+    noise = sur.draw_noise(S)
+    theta, logq = sur.forward_hip(model, S, noise)
+    sc, cs = model._batch(batch)
+    B = cs.n_rows
+    c = float(B) / float(dataset_rows)
+    parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=all_reduce, prior_weight=c)
+    rows = B
+    prior = sum(parts[n] for n in VAR_ORDER)
+    energy = parts["x"] + parts["z"] + c * prior           # [S] float64
+    loss = -(energy - c * logq).mean() / rows
+    grads = sur.backward_hip(model, S, noise, g, 1.0 / (S * rows), c)
+    return loss, grads, nnf
+
+
+def elbo_step_reference(model, batch, dataset_rows, sample_size, all_reduce=None, generator=None):
+    """Plain torch-autograd restatement of elbo_step (sampling, log q and the
+    chain rule in torch ops); the fp32 reference the tests compare against.
     Returns (loss float tensor, grads list) -- no optimiser update."""
     sur = model.surrogate_distribution
     theta, logq = sur.rsample(sample_size, generator)
@@ -206,7 +320,7 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
     restores the best trainables (behaviour evidenced by
     notebooks/factorizing_random_noise.ipynb:122-420)."""
     sur = model.surrogate_distribution
-    opt = Adam(sur.trainable_variables, learning_rate)
+    opt = AdamHIP(model, sur.trainable_variables, learning_rate)
     epochs = num_epochs if num_epochs is not None else num_steps
     losses, best, best_state, decays = [], math.inf, None, 0
     for ep in range(epochs):
@@ -218,7 +332,7 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
                 if verbose:
                     print("Batch loss NaN, skipping")
                 continue
-            opt.step(_clip(grads, clip_value))
+            opt.step(grads, clip_value)
             tot += lv
             nb += 1
         if nb == 0:
