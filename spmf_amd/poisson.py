@@ -11,8 +11,7 @@ There is no CPU fallback; without the library / a GPU the energy raises.
 from __future__ import annotations
 
 import ctypes as C
-import math
-from typing import Dict, Optional
+from typing import Dict
 
 import numpy as np
 import torch

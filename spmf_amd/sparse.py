@@ -16,8 +16,6 @@ per-row statistics come from the HIP pre-pass kernel ``spmf_counts_stats``.
 """
 from __future__ import annotations
 
-import ctypes as C
-from typing import Optional
 
 import numpy as np
 import torch

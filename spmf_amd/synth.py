@@ -6,7 +6,6 @@ however many ranks share it.
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from .sparse import SparseCounts

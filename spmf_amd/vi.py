@@ -24,14 +24,11 @@ restatement of the same step; the tests use it as the fp32 reference.
 from __future__ import annotations
 
 import math
-import os
-import uuid
 from typing import Dict, List
 
 import numpy as np
 import torch
 
-import ctypes as C
 
 from . import _lib
 from ._lib import VAR_ORDER
