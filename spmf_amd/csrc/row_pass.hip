@@ -31,6 +31,13 @@
 
 namespace spmf {
 
+#ifndef ROW_MAX_BLOCKS
+#define ROW_MAX_BLOCKS 4096
+#endif
+#ifndef ROW_WAVES_PER_SIMD
+#define ROW_WAVES_PER_SIMD 1
+#endif
+
 namespace {
 
 // LIK: 0 Poisson / linear decoder, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
@@ -130,7 +137,7 @@ struct RowCtx {
 }  // namespace
 
 template <int KP, int LIK>
-__global__ __launch_bounds__(256) void row_pass_kernel(
+__global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
     int64_t B, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ row_scale,
     const float* __restrict__ Ap, const float* __restrict__ Vp, const float* __restrict__ phi,
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256) void row_pass_kernel(
 template <int KP>
 static void launch_row_t(const RowArgs& a, hipStream_t st) {
   int64_t want = (a.B + 3) / 4;  // 4 waves (rows in flight) per 256-thread block
-  int nb = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  int nb = (int)(want < 1 ? 1 : (want > ROW_MAX_BLOCKS ? ROW_MAX_BLOCKS : want));
 #define SPMF_ROW_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb), dim3(256), 0, st, a.B, a.row_ptr,    \
                      a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, a.gzs, a.dacc, \

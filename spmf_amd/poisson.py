@@ -11,6 +11,7 @@ There is no CPU fallback; without the library / a GPU the energy raises.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Dict
 
 import numpy as np
@@ -316,6 +317,32 @@ class PoissonFactorization:
         if prediction['log_likelihood'].dim() > 2:
             prediction['ll'] = prediction['log_likelihood'].sum(-1)
         return prediction
+
+    def waic(self, data=None, nsamples=100):
+        """Widely applicable information criterion on ONE batch, as the notebooks
+        call it (notebooks/factorizing_random_noise.ipynb:447 prints
+        {'waic','se','lppd','pwaic'}; the recorded lppd of -37091 is that of one
+        1000 x 30 batch).  bayesianquilts' implementation is out of tree
+        [UNVERIFIED-3P]; this is the standard pointwise definition over the
+        cells of the batch: lppd_i = log mean_s p(x_i|theta_s),
+        pwaic_i = var_s log p(x_i|theta_s), waic = -2 sum_i (lppd_i - pwaic_i),
+        se = 2 sqrt(n var_i(lppd_i - pwaic_i))."""
+        if data is None:
+            src = getattr(self, "data", None)
+            if src is None:
+                raise ValueError("waic needs a batch (or a model built with data)")
+            data = next(iter(src() if callable(src) else src))
+        th = self.surrogate_distribution.sample(int(nsamples))
+        ll = self.log_likelihood_components(s=th["s"], u=th["u"], v=th["v"], w=th["w"],
+                                            data=data)["log_likelihood"].double()
+        S = ll.shape[0]
+        lppd_i = torch.logsumexp(ll, 0) - math.log(S)
+        pwaic_i = ll.var(0, unbiased=True)
+        elpd_i = lppd_i - pwaic_i
+        n = elpd_i.numel()
+        return {"waic": float(-2.0 * elpd_i.sum()),
+                "se": float(2.0 * torch.sqrt(n * elpd_i.var(unbiased=True))),
+                "lppd": float(lppd_i.sum()), "pwaic": float(pwaic_i.sum())}
 
     def _nonfinite_rule_x(self, data, params):
         """'x' part under the non-finite replacement rule (poisson.py:606-616)

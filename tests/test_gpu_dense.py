@@ -64,3 +64,24 @@ def test_non_finite_rule_matches_reference_semantics():
     # and the energy/grad entry point reports the cell instead of hiding it
     _, _, nnf = m.energy_and_grads({"counts": x}, params)
     assert nnf.cpu().tolist() == [1.0, 0.0]
+
+
+def test_waic_matches_pointwise_definition():
+    from spmf_amd import PoissonFactorization
+    rng = np.random.default_rng(2)
+    x = rng.poisson(1.0, size=(200, 12)).astype(np.float64)
+    m = PoissonFactorization(latent_dim=2, feature_dim=12, u_tau_scale=1 / math.sqrt(2400),
+                             device="cuda", panel_rows=64)
+    torch.manual_seed(4)
+    out = m.waic({"counts": x}, nsamples=50)
+    assert set(out) == {"waic", "se", "lppd", "pwaic"}
+    torch.manual_seed(4)
+    th = m.surrogate_distribution.sample(50)
+    cfg = O.OracleConfig(latent_dim=2, feature_dim=12)
+    ll = O.log_likelihood_components(cfg, T(x), th["s"].double().cpu(), th["u"].double().cpu(),
+                                     th["v"].double().cpu(), th["w"].double().cpu())["log_likelihood"]
+    lppd = (torch.logsumexp(ll, 0) - math.log(50)).sum().item()
+    pw = ll.var(0, unbiased=True).sum().item()
+    assert abs(out["lppd"] - lppd) <= 1e-5 * abs(lppd)
+    assert abs(out["pwaic"] - pw) <= 1e-3 * max(abs(pw), 1e-9) + 1e-9
+    assert abs(out["waic"] + 2 * (lppd - pw)) <= 1e-5 * abs(out["waic"])
