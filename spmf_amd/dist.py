@@ -62,3 +62,21 @@ class ShardReducer:
                 dist.all_reduce(tot, group=self.group)
             return int(round(float(tot[0]))), float(tot[1])
         return self.rows_global, self.lgamma_global
+
+
+def sync_seed(seed=None, group=None):
+    """Every rank must draw the SAME base noise for the replicated surrogate
+    (parameters, and hence theta, are replicated; only the rows are sharded).
+    Broadcast rank 0's seed and seed torch's generators with it."""
+    import random
+    if seed is None:
+        seed = random.SystemRandom().randrange(2 ** 31)
+    t = torch.tensor([int(seed)], dtype=torch.int64)
+    if dist.is_initialized():
+        dev = torch.device("cuda", torch.cuda.current_device()) \
+            if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = t.to(dev)
+        dist.broadcast(t, 0, group=group)
+    seed = int(t.item())
+    torch.manual_seed(seed)
+    return seed

@@ -50,6 +50,9 @@ def _worker(rank, world, port, q):
                                                  one["u"], one["v"], one["w"], one["s"]))
     from scipy.special import gammaln
     lg = float(gammaln(xs.data + 1.0).sum())
+    from spmf_amd.dist import sync_seed
+    seed = sync_seed(1234 + rank)          # rank 0's seed wins everywhere
+    assert seed == 1234 and torch.initial_seed() == 1234
     red = ShardReducer()
     colsum = torch.from_numpy(np.asarray(xs.sum(0)).reshape(-1).copy())
     colnnz = torch.from_numpy(np.asarray((xs > 0).sum(0)).reshape(-1).astype(np.float64))
