@@ -39,34 +39,40 @@ __device__ __forceinline__ double unpack(const float* tail, int i) {
   return (double)tail[2 * i] + (double)tail[2 * i + 1];
 }
 
+// The log-densities (the energy PARTS) are evaluated in fp64: a part is a sum
+// of O(D*K) terms of either sign, so fp32 term error would be amplified by the
+// cancellation (seen: 2.6e-5 relative on a 4307-term part).  Gradients stay fp32.
 // HalfNormal(sig) at y: log-prob, d/dy, d/dsig
-__device__ __forceinline__ void halfnormal(float y, float sig, float& lp, float& gy, float& gs) {
+__device__ __forceinline__ void halfnormal(float y, float sig, double& lp, float& gy, float& gs) {
   const float is = 1.f / sig;
   const float q = y * is;
-  lp = (float)kHalfLog2OverPi - logf(sig) - 0.5f * q * q;
+  const double qd = (double)y / (double)sig;
+  lp = kHalfLog2OverPi - log((double)sig) - 0.5 * qd * qd;
   gy = -q * is;
   gs = (q * q - 1.f) * is;
 }
 // SqrtInvGamma(1/2, scale=1/a) at y: log-prob, d/dy, d/da
-__device__ __forceinline__ void sqrt_ig(float y, float a, float& lp, float& gy, float& ga) {
+__device__ __forceinline__ void sqrt_ig(float y, float a, double& lp, float& gy, float& ga) {
   const float iy = 1.f / y, ia = 1.f / a;
   const float t = ia * iy * iy;  // 1/(a y^2)
-  lp = -0.5f * logf(a) - (float)kLgammaHalf - 2.f * logf(y) - t + (float)kLog2;
+  const double yd = (double)y, ad = (double)a;
+  lp = -0.5 * log(ad) - kLgammaHalf - 2.0 * log(yd) - 1.0 / (ad * yd * yd) + kLog2;
   gy = -2.f * iy + 2.f * t * iy;
   ga = -0.5f * ia + t * ia;
 }
 // InvGamma(1/2, beta) at a: log-prob, d/da
-__device__ __forceinline__ void ig_half(float a, float beta, float half_log_beta, float& lp,
+__device__ __forceinline__ void ig_half(float a, float beta, float half_log_beta, double& lp,
                                         float& ga) {
   const float ia = 1.f / a;
-  lp = half_log_beta - (float)kLgammaHalf - 1.5f * logf(a) - beta * ia;
+  const double ad = (double)a;
+  lp = 0.5 * log((double)beta) - kLgammaHalf - 1.5 * log(ad) - (double)beta / ad;
   ga = -1.5f * ia + beta * ia * ia;
 }
 
 template <int KP>
 __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
                                                      double lgamma_sum, float u_tau_scale,
-                                                     float s_tau_scale, float decay, float pw,
+                                                     float s_tau_scale, double decay, float pw,
                                                      const float* __restrict__ acc,
                                                      const double* __restrict__ dprep, Ptrs12 P,
                                                      const float* __restrict__ eta, MPtrs12 G,
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     // log_transform: the dense kernel already subtracted sum_b E_bd z_b from gV'
     zsum_s[t] = logt ? 0.f : (float)unpack(tail, kDaccHead + t);
     utau_s[t] = t < K ? P.p[UTAU_][t] : 1.f;
-    dec_s[t] = powf(decay, (float)t);
+    dec_s[t] = (float)pow((double)decay, (double)t);   // powf is ~1e-6 off at t~60: a systematic part error
     gutau_s[t] = 0.f;
   }
   if (t < FTD) {
@@ -123,16 +129,19 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       const float dA = gAp[(size_t)d * KP + k] * ietas[dl];
       ga_u = u * dA;
       const float sc = utau_s[k] * dec_s[k];
-      float lp, gy, gs;
+      double lp;
+      float gy, gs;
       halfnormal(u, ue * sc, lp, gy, gs);
       part[U_] += (double)lp;
       G.p[U_][i] = w1s[dl] * dA + pw * gy;
       gut = pw * gs * ue * dec_s[k];
-      float lp2, gy2, ga2;
+      double lp2;
+      float gy2, ga2;
       sqrt_ig(ue, ua, lp2, gy2, ga2);
       part[UETA_] += (double)lp2;
       G.p[UETA_][i] = pw * (gs * sc + gy2);
-      float lp3, ga3;
+      double lp3;
+      float ga3;
       ig_half(ua, 1.f, 0.f, lp3, ga3);
       part[UETAA_] += (double)lp3;
       G.p[UETAA_][i] = pw * (ga2 + ga3);
@@ -164,9 +173,10 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     if (k < K && d < D) {
       const size_t i = (size_t)k * D + d;
       const float v = P.p[V_][i];
-      float lp, gy, gs;
+      double lp;
+      float gy, gs;
       halfnormal(v, 0.1f, lp, gy, gs);
-      if (logt == 2) lp -= (float)kLog2;   // Bernoulli: v ~ Normal(0,.1) (bernoulli.py:187-200)
+      if (logt == 2) lp -= kLog2;   // Bernoulli: v ~ Normal(0,.1) (bernoulli.py:187-200)
       part[V_] += (double)lp;
       G.p[V_][i] = tile[k][dl] + pw * gy;
     }
@@ -181,20 +191,23 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     // Poisson: sum_b x/r - B; Bernoulli: sum_nnz x - sum_b sigmoid (dense kernel already applied)
     const float dphi = logt == 2 ? gph[d] : gph[d] - (float)Bglob;
     const float GA = GAs[t], Gphi = e * w * dphi;
-    float lp, gy, gs;
+    double lp;
+    float gy, gs;
     halfnormal(w, 1.f, lp, gy, gs);
-    if (logt == 2) lp -= (float)kLog2;     // Bernoulli: w ~ Normal(0,1) (bernoulli.py:201-216)
+    if (logt == 2) lp -= kLog2;     // Bernoulli: w ~ Normal(0,1) (bernoulli.py:201-216)
     part[W_] += (double)lp;
     G.p[W_][d] = e * w2 * dphi + pw * gy;
     const float se0 = P.p[SETA_][d], se1 = P.p[SETA_][D + d], stau = P.p[STAU_][d];
-    float lp0, gy0, gs0, lp1, gy1, gs1;
+    double lp0, lp1;
+    float gy0, gs0, gy1, gs1;
     halfnormal(s0, se0 * stau, lp0, gy0, gs0);
     halfnormal(s1, se1 * stau, lp1, gy1, gs1);
     part[S_] += (double)lp0 + (double)lp1;
     G.p[S_][d] = (GA - Gphi) * s1 * iT2 + pw * gy0;
     G.p[S_][D + d] = (Gphi - GA) * s0 * iT2 + pw * gy1;
     const float sa0 = P.p[SETAA_][d], sa1 = P.p[SETAA_][D + d], sta = P.p[STAUA_][d];
-    float a_lp, a_gy, a_ga, b_lp, b_gy, b_ga, c_lp, c_ga;
+    double a_lp, b_lp, c_lp;
+    float a_gy, a_ga, b_gy, b_ga, c_ga;
     sqrt_ig(se0, sa0, a_lp, a_gy, a_ga);
     sqrt_ig(se1, sa1, b_lp, b_gy, b_ga);
     part[SETA_] += (double)a_lp + (double)b_lp;
@@ -220,7 +233,8 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     float g = gutau_s[t];
     if (blockIdx.x == 0) {
       const float ut = P.p[UTAU_][t], uta = P.p[UTAUA_][t];
-      float lp, gy, ga, lp2, ga2;
+      double lp, lp2;
+      float gy, ga, ga2;
       sqrt_ig(ut, uta, lp, gy, ga);
       part[UTAU_] += (double)lp;
       g += pw * gy;
@@ -288,7 +302,7 @@ static void launch_finish_t(const FinishArgs& a, hipStream_t st) {
   }
   const int nb = (a.D + FTD - 1) / FTD;
   hipLaunchKernelGGL(finish_kernel<KP>, dim3(nb), dim3(256), 0, st, a.D, a.K, (double)a.B_global,
-                     a.lgamma_sum, (float)a.u_tau_scale, (float)a.s_tau_scale, (float)a.decay, (float)a.prior_weight,
+                     a.lgamma_sum, (float)a.u_tau_scale, (float)a.s_tau_scale, a.decay, (float)a.prior_weight,
                      a.acc, a.dprep, P, a.eta, G, a.parts, a.n_nonfinite, a.logt);
 }
 

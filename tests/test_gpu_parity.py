@@ -193,3 +193,31 @@ def test_errors_are_loud():
     bad["u"] = bad["u"][:, :, :1]
     with pytest.raises(ValueError):
         m.energy_and_grads({"counts": x}, bad)
+
+
+def test_randomised_shapes_sweep():
+    """40 random (B, D, K, S, density, scale_rows, panel_rows) draws, incl. K
+    not a power of two, single rows/columns, all-zero batches and rows longer
+    than two 64-entry chunks."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        B = int(rng.integers(1, 180))
+        D = int(rng.integers(1, 400))
+        K = int(rng.integers(1, 65))
+        S = int(rng.integers(1, 4))
+        density = float(rng.choice([0.0, 0.02, 0.2, 0.7, 1.0]))
+        scale_rows = bool(rng.integers(0, 2))
+        panel_rows = int(rng.choice([1, 7, 64, 10_000]))
+        cfg, x, params = make_problem(B, D, K, S, 5000 + case, density, scale_rows, empty=False)
+        pref, gref, _ = O.energy_and_grads(cfg, x, params)
+        m = build_model(cfg, panel_rows)
+        parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+        tag = f"case {case}: B={B} D={D} K={K} S={S} dens={density} sr={scale_rows} P={panel_rows}"
+        assert float(nnf.sum()) == 0, tag
+        for k in pref:
+            np.testing.assert_allclose(parts[k].cpu().numpy(), pref[k].numpy(), rtol=RTOL,
+                                       atol=RTOL, err_msg=f"{tag} part {k}")
+        for k in gref:
+            g = grads[k].cpu().double().numpy().reshape(gref[k].shape)
+            r = gref[k].numpy()
+            assert np.abs(g - r).max() <= RTOL * max(np.abs(r).max(), 1e-30), (tag, k)

@@ -237,3 +237,31 @@ def test_bernoulli_restatement():
     logits = (z @ T(params["v"])) * cfg.eta_i + O.intercept_matrix(cfg, T(params["w"]), T(params["s"]))
     ll = st.bernoulli.logpmf(xb.astype(int), expit(logits.numpy()[0])).sum()
     assert abs(parts["x"].item() - ll) < 1e-9
+
+
+from hypothesis import given, settings, strategies as hst
+
+
+@settings(max_examples=40, deadline=None)
+@given(B=hst.integers(1, 9), D=hst.integers(1, 9), K=hst.integers(1, 5),
+       seed=hst.integers(0, 10_000), density=hst.floats(0.0, 1.0),
+       xmax=hst.sampled_from([1, 3, 10_000]), scale_rows=hst.booleans())
+def test_sparse_exact_equals_dense_property(B, D, K, seed, density, xmax, scale_rows):
+    """SURVEY build-plan step 2: sparse == dense for random patterns, incl.
+    empty rows/columns, all-zero matrices and counts up to 1e4."""
+    rng = np.random.default_rng(seed)
+    x = ((rng.random((B, D)) < density) * rng.integers(1, xmax + 1, size=(B, D))).astype(np.float64)
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, scale_rows=scale_rows)
+    cfg.eta_i = T(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = float(rng.uniform(1.0, 5.0))
+    params = O.random_params(cfg, 1, seed + 1)
+    parts, _, groups = O.energy_and_grads(cfg, x, params)
+    one = {k: v[0] for k, v in params.items()}
+    out = SE.data_term(sp.csr_matrix(x), cfg.eta_i.numpy().reshape(-1), cfg.xi_u_global,
+                       scale_rows, one["u"], one["v"], one["w"], one["s"])
+    np.testing.assert_allclose(out["x"], parts["x"][0].item(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(out["z"], parts["z"][0].item(), rtol=1e-11, atol=1e-11)
+    for n in ("u", "v", "w", "s"):
+        ref = groups["data"][n][0].numpy()
+        np.testing.assert_allclose(out["grads"][n], ref, rtol=1e-9,
+                                   atol=1e-10 * max(1.0, np.abs(ref).max()))
