@@ -56,3 +56,26 @@ def test_bernoulli_surrogate_and_fit_smoke():
     losses = m.fit(lambda: [{"counts": X}], dataset_size=400, sample_size=4, num_steps=15,
                    learning_rate=0.05, rel_tol=1e-9, verbose=False)
     assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0]
+
+
+def test_bernoulli_randomised_sweep():
+    from spmf_amd import BernoulliFactorization
+    rng = np.random.default_rng(78)
+    for case in range(12):
+        B, D = int(rng.integers(2, 300)), int(rng.integers(2, 300))
+        K, S = int(rng.integers(1, 65)), int(rng.integers(1, 3))
+        density = float(rng.choice([0.03, 0.2, 0.8]))
+        cfg, x, params = problem(B, D, K, S, 9500 + case, density)
+        pref, gref, _ = O.energy_and_grads(cfg, x, params)
+        m = BernoulliFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
+                                   column_norms=cfg.eta_i, device="cuda",
+                                   panel_rows=int(rng.choice([5, 64, 4096])))
+        parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+        tag = f"case {case}: B={B} D={D} K={K} S={S} dens={density}"
+        assert float(nnf.sum()) == 0, tag
+        for k, r in pref.items():
+            np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=2e-5, atol=2e-5,
+                                       err_msg=f"{tag} {k}")
+        for k, r in gref.items():
+            g = grads[k].cpu().double().numpy().reshape(r.shape)
+            assert np.abs(g - r.numpy()).max() <= 2e-5 * max(np.abs(r.numpy()).max(), 1e-30), (tag, k)

@@ -55,3 +55,29 @@ def test_log_transform_energy_and_grads(B, D, K, S, density, scale_rows):
     z = m.encode(x, u=T(params["u"]), s=T(params["s"])).cpu().numpy()
     zr = O.encode(cfg, T(x), T(params["u"]), T(params["s"])).numpy()
     np.testing.assert_allclose(z, zr, rtol=1e-5, atol=1e-5 * np.abs(zr).max())
+
+
+def test_log_transform_randomised_sweep():
+    from spmf_amd import PoissonFactorization
+    rng = np.random.default_rng(77)
+    for case in range(12):
+        B, D = int(rng.integers(2, 300)), int(rng.integers(2, 300))
+        K, S = int(rng.integers(1, 65)), int(rng.integers(1, 3))
+        density = float(rng.choice([0.03, 0.2, 0.8]))
+        sr = bool(rng.integers(0, 2))
+        cfg, x, params = problem(B, D, K, S, 9000 + case, density, sr)
+        pref, gref, _ = O.energy_and_grads(cfg, x, params)
+        m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
+                                 scale_rows=sr, log_transform=True, column_norms=cfg.eta_i,
+                                 initialize_distributions=False, device="cuda",
+                                 panel_rows=int(rng.choice([5, 64, 4096])))
+        m.xi_u_global = cfg.xi_u_global
+        parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+        tag = f"case {case}: B={B} D={D} K={K} S={S} dens={density} sr={sr}"
+        assert float(nnf.sum()) == 0, tag
+        for k, r in pref.items():
+            np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=2e-5, atol=2e-5,
+                                       err_msg=f"{tag} {k}")
+        for k, r in gref.items():
+            g = grads[k].cpu().double().numpy().reshape(r.shape)
+            assert np.abs(g - r.numpy()).max() <= 2e-5 * max(np.abs(r.numpy()).max(), 1e-30), (tag, k)
