@@ -163,20 +163,50 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
   double ll_acc = 0.0, zsq_acc = 0.0, nnf_acc = 0.0;
   float4 zsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // Software pipeline across rows: the pointers of row b+2*nwaves and the first
+  // two 64-entry chunks of row b+nwaves are in flight while row b is processed,
+  // so the row_ptr -> col/val dependent latency is off the per-row critical path.
+  int start = 0, end = 0, pc0 = 0, pc1 = 0, nstart = 0, nend = 0;
+  float xi = 1.f, px0 = 0.f, px1 = 0.f, nxi = 1.f;
+  if (wave < B) {
+    start = row_ptr[wave];
+    end = row_ptr[wave + 1];
+    xi = row_scale ? row_scale[wave] : 1.f;
+    const int i0 = start + lane, i1 = start + 64 + lane;
+    pc0 = i0 < end ? __builtin_nontemporal_load(&col[i0]) : 0;
+    px0 = i0 < end ? __builtin_nontemporal_load(&val[i0]) : 0.f;
+    pc1 = i1 < end ? __builtin_nontemporal_load(&col[i1]) : 0;
+    px1 = i1 < end ? __builtin_nontemporal_load(&val[i1]) : 0.f;
+  }
+  if (wave + nwaves < B) {
+    nstart = row_ptr[wave + nwaves];
+    nend = row_ptr[wave + nwaves + 1];
+    nxi = row_scale ? row_scale[wave + nwaves] : 1.f;
+  }
   for (int64_t b = wave; b < B; b += nwaves) {
-    const int start = row_ptr[b], end = row_ptr[b + 1];
     const int n = end - start;
-    const float xi = row_scale ? row_scale[b] : 1.f;
+    // prefetch: chunks of the next row, pointers of the one after
+    int qc0 = 0, qc1 = 0, nnstart = 0, nnend = 0;
+    float qx0 = 0.f, qx1 = 0.f, nnxi = 1.f;
+    if (b + nwaves < B) {
+      const int j0 = nstart + lane, j1 = nstart + 64 + lane;
+      qc0 = j0 < nend ? __builtin_nontemporal_load(&col[j0]) : 0;
+      qx0 = j0 < nend ? __builtin_nontemporal_load(&val[j0]) : 0.f;
+      qc1 = j1 < nend ? __builtin_nontemporal_load(&col[j1]) : 0;
+      qx1 = j1 < nend ? __builtin_nontemporal_load(&val[j1]) : 0.f;
+    }
+    if (b + 2 * nwaves < B) {
+      nnstart = row_ptr[b + 2 * nwaves];
+      nnend = row_ptr[b + 2 * nwaves + 1];
+      nnxi = row_scale ? row_scale[b + 2 * nwaves] : 1.f;
+    }
     float4 zacc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 gz = make_float4(0.f, 0.f, 0.f, 0.f);
     float llrow = 0.f;
     if (n <= 128) {
       // ---- short row: col/val stay in registers for both sweeps ----------
-      const int i0 = start + lane, i1 = start + 64 + lane;
-      const int c0 = i0 < end ? __builtin_nontemporal_load(&col[i0]) : 0;
-      const float x0 = i0 < end ? __builtin_nontemporal_load(&val[i0]) : 0.f;
-      const int c1 = i1 < end ? __builtin_nontemporal_load(&col[i1]) : 0;
-      const float x1 = i1 < end ? __builtin_nontemporal_load(&val[i1]) : 0.f;
+      const int c0 = pc0, c1 = pc1;
+      const float x0 = px0, x1 = px1;
       const int n0 = min(n, 64), n1 = n - 64;
       if (mode != 2) {
         cx.sweep1(c0, x0, n0, zacc);
@@ -184,12 +214,13 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
         zacc = across_groups_sum4<LPN>(zacc);
         zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
         if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
-        if (encode_only) continue;
       } else {
         zacc = gather4<LPN>(z, (int)b, sub);
       }
+      if (!encode_only) {
       cx.sweep2(c0, x0, n0, zacc, gz, llrow, nnf_acc);
       if (n1 > 0) cx.sweep2(c1, x1, n1, zacc, gz, llrow, nnf_acc);
+      }
     } else {
       // ---- long row: stream the row twice (second read is L2 served) -----
       if (mode != 2) {
@@ -202,10 +233,10 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
         zacc = across_groups_sum4<LPN>(zacc);
         zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
         if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
-        if (encode_only) continue;
       } else {
         zacc = gather4<LPN>(z, (int)b, sub);
       }
+      if (!encode_only)
       for (int base = start; base < end; base += 64) {
         const int idx = base + lane;
         const int c = idx < end ? col[idx] : 0;
@@ -213,6 +244,12 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
         cx.sweep2(c, x, min(64, end - base), zacc, gz, llrow, nnf_acc);
       }
     }
+    // rotate the pipeline registers
+    const float xi_cur = xi;
+    start = nstart; end = nend; xi = nxi;
+    pc0 = qc0; px0 = qx0; pc1 = qc1; px1 = qx1;
+    nstart = nnstart; nend = nnend; nxi = nnxi;
+    if (encode_only) continue;
     gz = across_groups_sum4<LPN>(gz);
     if (grp == 0) {
       zsq_acc += (double)dot4(zacc, zacc);
@@ -221,10 +258,10 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
       // (linear decoder) or the dense exp term of this row (log_transform)
       const float4 dn = (mode == 2 && gzd) ? gather4<LPN>(gzd, (int)b, sub) : veta4;
       float4 o;
-      o.x = xi * (gz.x - dn.x - zacc.x);
-      o.y = xi * (gz.y - dn.y - zacc.y);
-      o.z = xi * (gz.z - dn.z - zacc.z);
-      o.w = xi * (gz.w - dn.w - zacc.w);
+      o.x = xi_cur * (gz.x - dn.x - zacc.x);
+      o.y = xi_cur * (gz.y - dn.y - zacc.y);
+      o.z = xi_cur * (gz.z - dn.z - zacc.z);
+      o.w = xi_cur * (gz.w - dn.w - zacc.w);
       reinterpret_cast<float4*>(gzs)[(size_t)b * LPN + sub] = o;
     }
     ll_acc += (double)llrow;
