@@ -179,3 +179,27 @@ def test_qualitative_linear_structure_outcome():
     noise_cols = np.delete(np.arange(D), np.arange(0, D, 3))
     assert load[::3].mean() > 10 * load[noise_cols].mean()
     assert load[::3].min() > 2 * load[noise_cols].max()
+
+
+def test_reference_smoke_script_shape():
+    """The reference's own test (tests/spmf_test.py:13-44), scaled down: same
+    constructor, compute_scales(data_factory) and fit(...) keyword arguments."""
+    from mederrata_spmf import PoissonFactorization
+    rng = np.random.default_rng(0)
+    N, D, P = 4000, 35, 5
+    counts = rng.poisson(1.0, size=(N, D))
+    data = {"counts": counts, "indices": np.arange(N), "normalization": np.ones(N)}
+
+    def data_factory(batch_size=1000):
+        perm = rng.permutation(N)                      # ds.shuffle(...).batch(bs)
+        return [{k: v[perm[i:i + batch_size]] for k, v in data.items()}
+                for i in range(0, N, batch_size)]
+
+    factor = PoissonFactorization(latent_dim=P, feature_dim=D, u_tau_scale=1.0 / np.sqrt(N * D),
+                                  dtype=np.float64)
+    factor.compute_scales(data_factory=data_factory)
+    losses = factor.fit(batched_data_factory=data_factory, dataset_size=N, batch_size=1000,
+                        sample_size=20, sample_batches=4, num_steps=6, rel_tol=1e-4,
+                        learning_rate=.01, verbose=False)
+    assert len(losses) >= 2 and all(math.isfinite(v) for v in losses)
+    assert losses[-1] < losses[0]
