@@ -58,6 +58,9 @@ extern "C" {
 #define SPMF_FLAG_SCALE_ROWS 1u     /* poisson.py:61,644-649 */
 #define SPMF_FLAG_BERNOULLI 4u      /* BernoulliFactorization (mederrata_spmf/bernoulli.py): Bernoulli(logits=rate)
                                      * likelihood :147-155, Normal priors on v,w :187-216; linear decoder only */
+#define SPMF_FLAG_MIXED 8u          /* build-defined (mederrata_spmf/mixed.py is an empty file): per-column likelihood,
+                                     * Bernoulli(logits) on the columns flagged by spmf_ctx_set_column_types, Poisson
+                                     * on the others; linear decoder only */
 #define SPMF_FLAG_LOG_TRANSFORM 2u  /* poisson.py:41-42,52-53: sparse stored-cell terms + dense f32-MFMA exp sums */
 
 typedef struct spmf_ctx spmf_ctx;
@@ -109,6 +112,10 @@ const char* spmf_last_error(const spmf_ctx* ctx); /* host string */
 /* Hyper-parameters of the prior (poisson.py:59,106-107,225-226). */
 int spmf_ctx_set_prior(spmf_ctx* ctx, double u_tau_scale, double s_tau_scale,
                        double symmetry_breaking_decay);
+
+/* SPMF_FLAG_MIXED only: column_is_bernoulli[D] (uint8, device, caller-owned,
+ * must outlive the ctx calls). */
+int spmf_ctx_set_column_types(spmf_ctx* ctx, const uint8_t* column_is_bernoulli);
 
 /* Bytes of caller-owned device workspace needed for batches of up to
  * max_rows rows and S draws. */
@@ -202,6 +209,9 @@ typedef struct spmf_sur_var {
   float* g1;           /* [n] d loss / d t1 */
   int32_t n;
   int32_t kind;
+  /* optional per-element override for kind 0 (mixed likelihood): ident[i] != 0
+   * means element i has the Identity bijector (kind 1). NULL otherwise. */
+  const uint8_t* ident;
 } spmf_sur_var;
 
 /* theta for every variable and logq[S] (fp64) = sum over variables and

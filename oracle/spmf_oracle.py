@@ -74,6 +74,10 @@ class OracleConfig:
     # 'poisson' (poisson.py) or 'bernoulli' (mederrata_spmf/bernoulli.py:32-649:
     # Bernoulli(logits=rate) :148, Normal priors / Identity bijectors on v,w
     # :187-216, encode without row scaling :572-589)
+    # 'mixed' is BUILD-DEFINED (mederrata_spmf/mixed.py is an empty file): columns
+    # flagged in extra['bernoulli_columns'] ([D] bool) follow bernoulli.py
+    # (Bernoulli(logits=rate), Normal priors on their v/w entries), the others
+    # poisson.py; encode is the Poisson one (row scaling per scale_rows).
     likelihood: str = "poisson"
     extra: dict = field(default_factory=dict)
 
@@ -200,6 +204,11 @@ def log_likelihood_components(cfg: OracleConfig, x, s, u, v, w):
     rate = theta_beta + phi
     if cfg.likelihood == "bernoulli":                          # bernoulli.py:147-155
         return {"log_likelihood": bernoulli_log_prob(x, rate), "rate": rate}
+    if cfg.likelihood == "mixed":
+        m = torch.as_tensor(np.asarray(cfg.extra["bernoulli_columns"], dtype=bool))
+        safe = torch.where(m, torch.ones_like(rate), rate)     # keep the unused branch finite
+        return {"log_likelihood": torch.where(m, bernoulli_log_prob(x, rate),
+                                              poisson_log_prob(x, safe)), "rate": rate}
     return {"log_likelihood": poisson_log_prob(x, rate), "rate": rate}
 
 
@@ -217,6 +226,13 @@ def prior_log_prob_parts(cfg: OracleConfig, p: Dict[str, torch.Tensor]):
     if cfg.likelihood == "bernoulli":                          # bernoulli.py:187-216
         out["v"] = sm(normal_log_prob(p["v"], torch.tensor(0.1, dtype=F64)))
         out["w"] = sm(normal_log_prob(p["w"], one))
+    elif cfg.likelihood == "mixed":
+        m = torch.as_tensor(np.asarray(cfg.extra["bernoulli_columns"], dtype=bool))
+        tenth = torch.tensor(0.1, dtype=F64)
+        out["v"] = sm(torch.where(m, normal_log_prob(p["v"], tenth),
+                                  halfnormal_log_prob(p["v"], tenth)))
+        out["w"] = sm(torch.where(m, normal_log_prob(p["w"], one),
+                                  halfnormal_log_prob(p["w"], one)))
     else:
         out["v"] = sm(halfnormal_log_prob(p["v"], torch.tensor(0.1, dtype=F64)))
         out["w"] = sm(halfnormal_log_prob(p["w"], one))

@@ -22,6 +22,7 @@ PART_ORDER = VAR_ORDER + ("z", "x")
 FLAG_SCALE_ROWS = 1
 FLAG_LOG_TRANSFORM = 2
 FLAG_BERNOULLI = 4
+FLAG_MIXED = 8
 
 
 class SpmfError(RuntimeError):
@@ -51,7 +52,8 @@ class SurVar(C.Structure):
     """struct spmf_sur_var"""
     _fields_ = [("t0", C.c_void_p), ("t1", C.c_void_p), ("noise", C.c_void_p),
                 ("dgda", C.c_void_p), ("theta", C.c_void_p), ("gtheta", C.c_void_p),
-                ("g0", C.c_void_p), ("g1", C.c_void_p), ("n", C.c_int32), ("kind", C.c_int32)]
+                ("g0", C.c_void_p), ("g1", C.c_void_p), ("n", C.c_int32), ("kind", C.c_int32),
+                ("ident", C.c_void_p)]
 
 
 class AdamVar(C.Structure):
@@ -67,6 +69,7 @@ SIGNATURES = {
     "spmf_ctx_destroy": (None, [C.c_void_p]),
     "spmf_last_error": (C.c_char_p, [C.c_void_p]),
     "spmf_ctx_set_prior": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "spmf_ctx_set_column_types": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spmf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int]),
     "spmf_ctx_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "spmf_counts_stats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 7

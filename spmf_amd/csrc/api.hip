@@ -28,7 +28,8 @@ struct spmf_ctx {
   float* acc = nullptr;
   double* dacc = nullptr;
   double* dprep = nullptr;
-  float *Ap = nullptr, *Vp = nullptr, *phi = nullptr, *z = nullptr, *gzs = nullptr, *gzd = nullptr;
+  float *Ap = nullptr, *Vp = nullptr, *phi = nullptr, *z = nullptr, *gzs = nullptr, *gzd = nullptr, *dbias = nullptr;
+  const uint8_t* ctype = nullptr;   // mixed likelihood: 1 = Bernoulli column (device, caller-owned)
   // timing taps
   int timing = 0;
   static constexpr int kSets = 64;  // ring of event sets: no sync inside a timed loop
@@ -69,7 +70,7 @@ static size_t var_size(const spmf_ctx* c, int i) {
 }
 
 struct Carve {
-  size_t acc, dacc, dprep, Ap, Vp, phi, z, gzs, gzd, total;
+  size_t acc, dacc, dprep, Ap, Vp, phi, dbias, z, gzs, gzd, total;
 };
 static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   Carve k;
@@ -81,9 +82,10 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.Ap = o;    o += al(D * KP * sizeof(float));
   k.Vp = o;    o += al(D * KP * sizeof(float));
   k.phi = o;   o += al(D * sizeof(float));
+  k.dbias = o; o += al(D * sizeof(float));
   k.z = o;     o += al((size_t)rows * KP * sizeof(float));
   k.gzs = o;   o += al((size_t)rows * KP * sizeof(float));
-  k.gzd = o;   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI)) o += al((size_t)rows * KP * sizeof(float));
+  k.gzd = o;   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) o += al((size_t)rows * KP * sizeof(float));
   k.total = o;
   return k;
 }
@@ -103,8 +105,8 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   c->D = D;
   c->KP = padded_k(K);
   // the dense exp kernels of the log_transform decoder work on 32-feature MFMA tiles
-  if ((flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI)) && c->KP < 32) c->KP = 32;
-  if ((flags & SPMF_FLAG_LOG_TRANSFORM) && (flags & SPMF_FLAG_BERNOULLI)) {
+  if ((flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->KP < 32) c->KP = 32;
+  if ((flags & SPMF_FLAG_LOG_TRANSFORM) && (flags & (SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED))) {
     delete c;
     return SPMF_E_UNSUPPORTED;   // Bernoulli with the exp decoder is not built
   }
@@ -132,6 +134,12 @@ int spmf_ctx_set_prior(spmf_ctx* c, double u_tau_scale, double s_tau_scale, doub
 }
 
 int spmf_padded_k(const spmf_ctx* c) { return c ? c->KP : 0; }
+
+int spmf_ctx_set_column_types(spmf_ctx* c, const uint8_t* column_is_bernoulli) {
+  if (!c || !(c->flags & SPMF_FLAG_MIXED) || !column_is_bernoulli) return fail(c, SPMF_E_ARG, "set_column_types: needs a ctx created with SPMF_FLAG_MIXED and a [D] device array");
+  c->ctype = column_is_bernoulli;
+  return SPMF_OK;
+}
 
 size_t spmf_workspace_bytes(const spmf_ctx* c, int64_t max_rows, int S) {
   if (!c || max_rows < 0 || S < 1) return 0;
@@ -162,6 +170,7 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   c->Ap = (float*)(c->ws + k.Ap);
   c->Vp = (float*)(c->ws + k.Vp);
   c->phi = (float*)(c->ws + k.phi);
+  c->dbias = (float*)(c->ws + k.dbias);
   c->z = (float*)(c->ws + k.z);
   c->gzs = (float*)(c->ws + k.gzs);
   c->gzd = (float*)(c->ws + k.gzd);
@@ -189,7 +198,7 @@ int spmf_ctx_enable_timing(spmf_ctx* c, int on) {
 
 int spmf_last_timing(spmf_ctx* c, float* ms5) {
   if (!c || !ms5) return SPMF_E_ARG;
-  const bool logt = (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI)) != 0;
+  const bool logt = (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) != 0;
   if (!c->timing || c->ev_count < 1) return fail(c, SPMF_E_ARG, "no timing recorded (enable timing, run data_pass + finish)");
   // average over the (up to kSets) most recent complete steps
   const int n = c->ev_count < spmf_ctx::kSets ? c->ev_count : spmf_ctx::kSets;
@@ -244,7 +253,8 @@ int spmf_counts_stats(spmf_ctx* c, int64_t n_rows, const int32_t* row_ptr, const
 int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, void* stream) {
   if (!c || !params || !eta || S < 1) return fail(c, SPMF_E_ARG, "data_pass: bad arguments");
   // likelihood / decoder code of the kernels: 0 Poisson linear, 1 Poisson log_transform, 2 Bernoulli
-  const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : 0);
+  const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : ((c->flags & SPMF_FLAG_MIXED) ? 3 : 0));
+  if (logt == 3 && !c->ctype) return fail(c, SPMF_E_ARG, "mixed likelihood: spmf_ctx_set_column_types was not called");
   int rc = check_counts(c, ct);
   if (!rc && logt == 1 && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG, "counts: log_transform needs gval / pc_gval");
   if (rc) return rc;
@@ -269,24 +279,25 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
     double* dacc = c->dacc + (size_t)s * kDaccRep * (kDaccHead + KP);
     double* dprep = c->dprep + (size_t)s * (KP + 1);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
-    PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt == 1 ? 1 : 0};
+    PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt == 1 ? 1 : 0, logt == 3 ? c->ctype : nullptr, logt == 3 ? c->dbias : nullptr};
     launch_prep(KP, pa, st);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
     const float* rscale = (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr;
     float* gVp = acc + (size_t)D * KP;
     if (ct->n_rows > 0 && !logt) {
-      RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 0, 0, nullptr};
+      RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 0, 0, nullptr, nullptr};
       launch_row_pass(KP, ra, st);
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
       // cores, then the stored-cell terms (sweep 2) with the dense row term.
-      RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, logt == 1 ? ct->gval : ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 1, logt, nullptr};
+      RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, logt == 1 ? ct->gval : ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 1, logt, nullptr, c->ctype};
       launch_row_pass(KP, r1, st);
       if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
-      const int act = logt == 2 ? 1 : 0;
+      const int act = logt >= 2 ? 1 : 0;
+      const float* lbias = logt == 3 ? c->dbias : c->phi;   // mixed: -1e30 masks the Poisson columns
       float* gphi_acc = acc + (size_t)2 * D * KP;
       // Z-stationary: Q rows are columns d -> bias_q = phi (Bernoulli logits)
-      ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0, act, nullptr, act ? c->phi : nullptr, nullptr};
+      ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0, act, nullptr, act ? lbias : nullptr, nullptr};
       launch_expdot(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E (or sum softplus)
       // W-stationary launch has only D/128 workgroups: split the row (Q) range
       // into chunks until ~4 workgroups per CU are in flight
@@ -297,15 +308,15 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
       if (chunks < 1) chunks = 1;
       // W-stationary: P rows are columns d -> bias_p = phi; Bernoulli also needs the
       // column sums of sigmoid for d/dphi (subtracted from the gphi accumulators)
-      ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, chunks, 1, act, act ? c->phi : nullptr, nullptr, act ? gphi_acc : nullptr};
+      ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, chunks, 1, act, act ? lbias : nullptr, nullptr, act ? gphi_acc : nullptr};
       launch_expdot(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
-      RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 2, logt, c->gzd};
+      RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 2, logt, c->gzd, c->ctype};
       launch_row_pass(KP, r2, st);
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
     if (ct->n_rows > 0 && ct->nnz > 0) {
-      ColArgs ca{D, ct->n_panels, ct->row_base, ct->max_items_per_panel, ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, gVp, acc + (size_t)2 * D * KP, logt, ct->pc_gval};
+      ColArgs ca{D, ct->n_panels, ct->row_base, ct->max_items_per_panel, ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, gVp, acc + (size_t)2 * D * KP, logt, ct->pc_gval, c->ctype};
       launch_col_pass(KP, ca, st);
     }
     PackArgs pk{KP, dacc, acc + (size_t)2 * D * KP + D};
@@ -337,7 +348,7 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
       P[i] = params[i] + s * var_size(c, i);
       G[i] = grads[i] + s * var_size(c, i);
     }
-    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : 0)};
+    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : ((c->flags & SPMF_FLAG_MIXED) ? 3 : 0)), c->ctype};
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
     launch_finish(KP, fa, st);
     if (tm) {
@@ -369,9 +380,9 @@ int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float*
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(c, hipMemsetAsync(c->dprep, 0, (c->KP + 1) * sizeof(double), st));
-  PrepArgs pa{c->D, c->K, u, nullptr, nullptr, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt};
+  PrepArgs pa{c->D, c->K, u, nullptr, nullptr, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt, nullptr, nullptr};
   launch_prep(c->KP, pa, st);
-  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr};
+  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr, nullptr};
   launch_row_pass(c->KP, ra, st);
   HIPCHK(c, hipMemcpy2DAsync(z_out, (size_t)c->K * sizeof(float), c->z, (size_t)c->KP * sizeof(float), (size_t)c->K * sizeof(float), (size_t)ct->n_rows, hipMemcpyDeviceToDevice, st));
   HIPCHK(c, hipGetLastError());
@@ -380,7 +391,7 @@ int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float*
 
 int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* v, const float* w, const float* s, const float* eta, float* rate_out, float* ll_out, void* stream) {
   if (!c || !u || !v || !w || !s || !eta || !rate_out || !ll_out) return fail(c, SPMF_E_ARG, "dense_ll: bad arguments");
-  if (c->flags & SPMF_FLAG_BERNOULLI) return fail(c, SPMF_E_UNSUPPORTED, "dense_ll: Bernoulli per-cell outputs are not built");
+  if (c->flags & (SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) return fail(c, SPMF_E_UNSUPPORTED, "dense_ll: Bernoulli per-cell outputs are not built");
   const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0;
   int rc = check_counts(c, ct);
   if (!rc && logt && ct->nnz > 0 && !ct->gval) rc = fail(c, SPMF_E_ARG, "dense_ll: log_transform needs counts.gval");
@@ -390,9 +401,9 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(c, hipMemsetAsync(c->dprep, 0, (c->KP + 1) * sizeof(double), st));
-  PrepArgs pa{c->D, c->K, u, v, w, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt};
+  PrepArgs pa{c->D, c->K, u, v, w, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt, nullptr, nullptr};
   launch_prep(c->KP, pa, st);
-  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr};
+  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr, nullptr};
   launch_row_pass(c->KP, ra, st);
   DenseLLArgs da{ct->n_rows, c->D, logt, c->z, c->Vp, c->phi, ct->row_ptr, ct->col_idx, ct->val, rate_out, ll_out};
   launch_dense_ll(c->KP, da, st);
@@ -415,7 +426,7 @@ int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
   for (int i = 0; i < nvars; ++i) {
     const spmf_sur_var& v = vars[i];
     if (!v.t0 || !v.t1 || !v.noise || !v.theta || v.n < 1 || v.kind < 0 || v.kind > 2) return fail(c, SPMF_E_ARG, "surrogate_fwd: bad variable");
-    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind};
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident};
     if (v.n > max_n) max_n = v.n;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -432,7 +443,7 @@ int spmf_surrogate_bwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
   for (int i = 0; i < nvars; ++i) {
     const spmf_sur_var& v = vars[i];
     if (!v.t0 || !v.t1 || !v.noise || !v.gtheta || !v.g0 || !v.g1 || v.n < 1 || v.kind < 0 || v.kind > 2 || (v.kind == 2 && !v.dgda)) return fail(c, SPMF_E_ARG, "surrogate_bwd: bad variable");
-    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind};
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident};
     if (v.n > max_n) max_n = v.n;
   }
   launch_surrogate_bwd(T, nvars, max_n, S, (float)inv_sb, (float)cw, (hipStream_t)stream);

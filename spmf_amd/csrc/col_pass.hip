@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     const int32_t* __restrict__ pc_row, const float* __restrict__ pc_val,
     const float* __restrict__ pc_gval, const float* __restrict__ Vp,
     const float* __restrict__ phi, const float* __restrict__ z, const float* __restrict__ gzs,
-    float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi) {
+    float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi,
+    const uint8_t* __restrict__ ctype) {
   constexpr int LPN = KP / 4;
   constexpr int NG = 64 / LPN;                        // items per wave
   constexpr int GRP = LPN < COL_GRP ? LPN : COL_GRP;  // entries gathered back to back
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
   }
   const float4 vp = ok ? gather4<LPN>(Vp, d, sub) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float ph = ok ? phi[d] : 1.f;
+  const bool bern = LIK == 2 || (LIK == 3 && ok && ctype[d]);   // item's column is Bernoulli
   float4 gV = make_float4(0.f, 0.f, 0.f, 0.f), gA = gV;
   float gph = 0.f;
 
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
         }
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
-          if (LIK == 2) {
+          if (bern) {
             // Bernoulli: d(x*logit)/dV' = x z_b, d/dphi = x: no rate needed
             gV = fma4(xv[j], zz[j], gV);
             gA = fma4(gv[j], gg[j], gA);
@@ -185,8 +187,9 @@ static void launch_col_t(const ColArgs& a, hipStream_t st) {
 #define SPMF_COL_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((col_pass_kernel<KP, L_>), dim3((unsigned)nb), dim3(256), 0, st, a.D,     \
                      a.n_panels, a.row_base, bpp, a.item_ptr, items, a.pc_row, a.pc_val,       \
-                     a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi)
-  if (a.logt == 2) SPMF_COL_LAUNCH(2);
+                     a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi, a.ctype)
+  if (a.logt == 3) SPMF_COL_LAUNCH(3);
+  else if (a.logt == 2) SPMF_COL_LAUNCH(2);
   else if (a.logt == 1) SPMF_COL_LAUNCH(1);
   else SPMF_COL_LAUNCH(0);
 #undef SPMF_COL_LAUNCH

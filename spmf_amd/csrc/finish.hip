@@ -77,11 +77,13 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
                                                      const double* __restrict__ dprep, Ptrs12 P,
                                                      const float* __restrict__ eta, MPtrs12 G,
                                                      double* __restrict__ parts,
-                                                     double* __restrict__ nnf_out, int logt) {
+                                                     double* __restrict__ nnf_out, int logt,
+                                                     const uint8_t* __restrict__ ctype) {
   __shared__ float tile[KP][FTD + 1];
   __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
   __shared__ float zsum_s[KP], utau_s[KP], dec_s[KP], gutau_s[KP];
   __shared__ float gred[256];
+  __shared__ int bern_s[FTD];
   const int t = threadIdx.x;
   const int d0 = blockIdx.x * FTD;
   const float* gAp = acc;
@@ -94,7 +96,8 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
 
   if (t < KP) {
     // log_transform: the dense kernel already subtracted sum_b E_bd z_b from gV'
-    zsum_s[t] = logt ? 0.f : (float)unpack(tail, kDaccHead + t);
+    // (mixed, code 3: still needed for the Poisson columns)
+    zsum_s[t] = (logt == 1 || logt == 2) ? 0.f : (float)unpack(tail, kDaccHead + t);
     utau_s[t] = t < K ? P.p[UTAU_][t] : 1.f;
     dec_s[t] = (float)pow((double)decay, (double)t);   // powf is ~1e-6 off at t~60: a systematic part error
     gutau_s[t] = 0.f;
@@ -111,6 +114,8 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     etas_[t] = e;
     ietas[t] = logt == 1 ? 1.f : 1.f / e;   // A' = w1*u/eta (linear) or w1*u (log_transform)
     GAs[t] = 0.f;
+    // column follows the Bernoulli likelihood: all of them (code 2) or by type (mixed, code 3)
+    bern_s[t] = (logt == 2 || (logt == 3 && d < D && ctype[d])) ? 1 : 0;
   }
   __syncthreads();
 
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   for (int e = t; e < KP * FTD; e += 256) {
     const int dl = e / KP, k = e % KP;
     const int d = d0 + dl;
-    tile[k][dl] = (d < D) ? (gVp[(size_t)d * KP + k] - zsum_s[k]) * etas_[dl] : 0.f;
+    tile[k][dl] = (d < D) ? (gVp[(size_t)d * KP + k] - (bern_s[dl] ? 0.f : zsum_s[k])) * etas_[dl] : 0.f;
   }
   __syncthreads();
   for (int e = t; e < KP * FTD; e += 256) {
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       double lp;
       float gy, gs;
       halfnormal(v, 0.1f, lp, gy, gs);
-      if (logt == 2) lp -= kLog2;   // Bernoulli: v ~ Normal(0,.1) (bernoulli.py:187-200)
+      if (bern_s[dl]) lp -= kLog2;   // Bernoulli column: v ~ Normal(0,.1) (bernoulli.py:187-200)
       part[V_] += (double)lp;
       G.p[V_][i] = tile[k][dl] + pw * gy;
     }
@@ -189,12 +194,12 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     const float T = s0 + s1, iT2 = 1.f / (T * T);
     const float w2 = s1 / T;
     // Poisson: sum_b x/r - B; Bernoulli: sum_nnz x - sum_b sigmoid (dense kernel already applied)
-    const float dphi = logt == 2 ? gph[d] : gph[d] - (float)Bglob;
+    const float dphi = bern_s[t] ? gph[d] : gph[d] - (float)Bglob;
     const float GA = GAs[t], Gphi = e * w * dphi;
     double lp;
     float gy, gs;
     halfnormal(w, 1.f, lp, gy, gs);
-    if (logt == 2) lp -= kLog2;     // Bernoulli: w ~ Normal(0,1) (bernoulli.py:201-216)
+    if (bern_s[t]) lp -= kLog2;     // Bernoulli column: w ~ Normal(0,1) (bernoulli.py:201-216)
     part[W_] += (double)lp;
     G.p[W_][d] = e * w2 * dphi + pw * gy;
     const float se0 = P.p[SETA_][d], se1 = P.p[SETA_][D + d], stau = P.p[STAU_][d];
@@ -268,8 +273,10 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       sum_r = unpack(tail, 3);                 // sum over all cells of softplus(logit)
     else if (logt == 1)
       sum_r += unpack(tail, 3) - Bglob * (double)D;
-    else
+    else {
       for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * dprep[k];
+      if (logt == 3) sum_r += unpack(tail, 3);   // mixed: + softplus over the Bernoulli columns
+    }
     atomicAdd(&parts[13], llx - (logt == 2 ? 0.0 : lgamma_sum) - sum_r);
     atomicAdd(&parts[12], Bglob * (double)K * kHalfLog2OverPi - 0.5 * zsq);
     if (nnf_out) *nnf_out = unpack(tail, 2);
@@ -303,7 +310,7 @@ static void launch_finish_t(const FinishArgs& a, hipStream_t st) {
   const int nb = (a.D + FTD - 1) / FTD;
   hipLaunchKernelGGL(finish_kernel<KP>, dim3(nb), dim3(256), 0, st, a.D, a.K, (double)a.B_global,
                      a.lgamma_sum, (float)a.u_tau_scale, (float)a.s_tau_scale, a.decay, (float)a.prior_weight,
-                     a.acc, a.dprep, P, a.eta, G, a.parts, a.n_nonfinite, a.logt);
+                     a.acc, a.dprep, P, a.eta, G, a.parts, a.n_nonfinite, a.logt, a.ctype);
 }
 
 void launch_finish(int KP, const FinishArgs& a, hipStream_t st) {

@@ -11,6 +11,8 @@ struct PrepArgs {
   float *Ap, *Vp, *phi;
   double* dprep;  // [KP+1]: veta[KP], phisum   (zeroed by the caller)
   int logt;       // log_transform: A' = w1*u (g(x) is data side), V' = eta*v^T
+  const uint8_t* ctype;  // mixed likelihood: 1 = Bernoulli column (may be null)
+  float* dbias;          // mixed likelihood: dense-kernel logit bias per column (may be null)
 };
 void launch_prep(int KP, const PrepArgs& a, hipStream_t st);
 
@@ -27,6 +29,7 @@ struct RowArgs {
   int mode;            // 0 full (linear decoder), 1 sweep 1 only (encode), 2 sweep 2 only
   int logt;            // log_transform rate r = exp(<z,V'>) - 1 + phi
   const float* gzd;    // mode 2: per-row dense term sum_d E_bd V'_d  [B,KP]
+  const uint8_t* ctype;  // likelihood code 3 (mixed): column types
 };
 void launch_row_pass(int KP, const RowArgs& a, hipStream_t st);
 
@@ -41,6 +44,7 @@ struct ColArgs {
   float *gAp, *gVp, *gphi;  // accumulated with float atomics (zeroed by the caller)
   int logt;
   const float* pc_gval;     // log_transform: g(x) per panel-CSC entry
+  const uint8_t* ctype;     // likelihood code 3 (mixed): column types
 };
 
 struct ExpdotArgs {
@@ -91,6 +95,7 @@ struct FinishArgs {
   double* parts;        // [14] (zeroed by the caller)
   double* n_nonfinite;  // [1] or null
   int logt;
+  const uint8_t* ctype;  // likelihood code 3 (mixed): column types
 };
 void launch_finish(int KP, const FinishArgs& a, hipStream_t st);
 
@@ -104,6 +109,7 @@ struct SurVar {
   const float* gtheta;  // [S,n] dE/dtheta (bwd)
   float *g0, *g1;       // [n] out (bwd)
   int n, kind;          // kind 0 softplus-normal, 1 identity-normal, 2 softplus-invgamma
+  const uint8_t* ident; // optional per-element kind-1 override of kind 0
 };
 struct SurTable {
   SurVar v[12];

@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void prep_kernel(int D, int K, const float* __
                                                    const float* __restrict__ eta,
                                                    float* __restrict__ Ap, float* __restrict__ Vp,
                                                    float* __restrict__ phi,
-                                                   double* __restrict__ dprep, int logt) {
+                                                   double* __restrict__ dprep, int logt,
+                                                   const uint8_t* __restrict__ ctype,
+                                                   float* __restrict__ dbias) {
   __shared__ float tile[KP][TD + 1];
   __shared__ float w1ie[TD], etas[TD];
   __shared__ double red[16];
@@ -47,7 +49,12 @@ __global__ __launch_bounds__(256) void prep_kernel(int D, int K, const float* __
       a = logt ? (s0 / T) : (s0 / T) / e;
       const float p = w ? e * (s1 / T) * w[d] : 0.f;
       phi[d] = p;
-      phi_local = (double)p;
+      // mixed likelihood: the closed-form sums cover the Poisson columns only;
+      // Bernoulli columns go through the dense softplus kernel, whose logit bias
+      // is phi there and -1e30 (sigmoid = softplus = 0) on Poisson columns
+      const bool bern = ctype && ctype[d];
+      phi_local = bern ? 0.0 : (double)p;
+      if (dbias) dbias[d] = bern ? p : -1e30f;
     }
     w1ie[t] = a;
     etas[t] = e;
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void prep_kernel(int D, int K, const float* __
   if (t < KP) {
     double acc = 0.0;
     for (int dl = 0; dl < TD; ++dl)
-      if (d0 + dl < D) acc += (double)tile[t][dl];
+      if (d0 + dl < D && !(ctype && ctype[d0 + dl])) acc += (double)tile[t][dl];
     atomicAdd(&dprep[t], acc);
   }
   const double ps = block_sum(phi_local, red);
@@ -85,7 +92,7 @@ template <int KP>
 static void launch_prep_t(const PrepArgs& a, hipStream_t st) {
   const int nb = (a.D + TD - 1) / TD;
   hipLaunchKernelGGL(prep_kernel<KP>, dim3(nb), dim3(256), 0, st, a.D, a.K, a.u, a.v, a.w, a.s,
-                     a.eta, a.Ap, a.Vp, a.phi, a.dprep, a.logt);
+                     a.eta, a.Ap, a.Vp, a.phi, a.dprep, a.logt, a.ctype, a.dbias);
 }
 
 void launch_prep(int KP, const PrepArgs& a, hipStream_t st) {

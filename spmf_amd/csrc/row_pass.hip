@@ -49,6 +49,7 @@ struct RowCtx {
   const float* Ap;
   const float* Vp;
   const float* phi;
+  const uint8_t* ctype;   // LIK 3 (mixed): 1 = Bernoulli column
   int lane, sub, grp;
 
   // z partial: zacc += sum over the chunk of x * A'_d
@@ -100,7 +101,7 @@ struct RowCtx {
     const int cs = __shfl(c, slot);
     float cc = 0.f;
     if (slot < nchunk && xs > 0.f) {
-      if (LIK == 2) {
+      if (LIK == 2 || (LIK == 3 && ctype[cs])) {
         // Bernoulli(logits = <z,V'> + phi) (bernoulli.py:147-155): stored-cell part x*logit
         const float lg = rmine + phi[cs];
         if (lg > -INFINITY && lg < INFINITY) {
@@ -142,13 +143,15 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
     const float* __restrict__ val, const float* __restrict__ row_scale,
     const float* __restrict__ Ap, const float* __restrict__ Vp, const float* __restrict__ phi,
     const double* __restrict__ dprep, float* __restrict__ z, float* __restrict__ gzs,
-    double* __restrict__ dacc, int mode, const float* __restrict__ gzd) {
+    double* __restrict__ dacc, int mode, const float* __restrict__ gzd,
+    const uint8_t* __restrict__ ctype) {
   const bool encode_only = mode == 1;
   constexpr int LPN = KP / 4;
   RowCtx<KP, LIK> cx;
   cx.Ap = Ap;
   cx.Vp = Vp;
   cx.phi = phi;
+  cx.ctype = ctype;
   cx.lane = threadIdx.x & 63;
   cx.sub = cx.lane % LPN;
   cx.grp = cx.lane / LPN;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
 
   float4 veta4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!encode_only)
+  if (!encode_only && (mode != 2 || LIK == 3))
     veta4 = make_float4((float)dprep[sub * 4 + 0], (float)dprep[sub * 4 + 1],
                         (float)dprep[sub * 4 + 2], (float)dprep[sub * 4 + 3]);
   double ll_acc = 0.0, zsq_acc = 0.0, nnf_acc = 0.0;
@@ -256,7 +259,9 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
       zsum = add4(zsum, zacc);
       // minus the derivative of sum_d r_bd over ALL columns: closed form veta
       // (linear decoder) or the dense exp term of this row (log_transform)
-      const float4 dn = (mode == 2 && gzd) ? gather4<LPN>(gzd, (int)b, sub) : veta4;
+      // (mixed: closed-form Poisson-column part veta PLUS the dense Bernoulli-column term)
+      float4 dn = (mode == 2 && gzd) ? gather4<LPN>(gzd, (int)b, sub) : veta4;
+      if (LIK == 3 && mode == 2 && gzd) dn = add4(dn, veta4);
       float4 o;
       o.x = xi_cur * (gz.x - dn.x - zacc.x);
       o.y = xi_cur * (gz.y - dn.y - zacc.y);
@@ -303,8 +308,9 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
 #define SPMF_ROW_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb), dim3(256), 0, st, a.B, a.row_ptr,    \
                      a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, a.gzs, a.dacc, \
-                     a.mode, a.gzd)
-  if (a.logt == 2) SPMF_ROW_LAUNCH(2);
+                     a.mode, a.gzd, a.ctype)
+  if (a.logt == 3) SPMF_ROW_LAUNCH(3);
+  else if (a.logt == 2) SPMF_ROW_LAUNCH(2);
   else if (a.logt == 1) SPMF_ROW_LAUNCH(1);
   else SPMF_ROW_LAUNCH(0);
 #undef SPMF_ROW_LAUNCH

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
         l = -0.5f * nz * nz - logf(sg) - 0.91893853320467274178f;
       }
       float th = y;
-      if (v.kind != 1) {
+      if (v.kind != 1 && !(v.ident && v.ident[i])) {
         th = softplusf(y);
         l -= logsigmoidf_(y);
       }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void surrogate_bwd_kernel(SurTable T, int S, f
       const float eps = v.noise[o], ge = v.gtheta[o];
       const float y = t0 + sg * eps;
       float dth = 1.f, dlq_dy = 0.f;
-      if (v.kind == 0) {
+      if (v.kind == 0 && !(v.ident && v.ident[i])) {
         dth = sigmoidf_(y);
         dlq_dy = -(1.f - dth);
       }

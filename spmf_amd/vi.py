@@ -76,6 +76,8 @@ class Surrogate:
         self._index = {}
         init = _initial_state(D, K, model.u_tau_scale, model.s_tau_scale)
         identity = set(getattr(model, "_identity_vars", ()))
+        # per-element Identity flags (mixed likelihood): name -> uint8 tensor
+        self.ident_mask = dict(getattr(model, "_identity_mask", {}) or {})
         for n in VAR_ORDER:
             kind, a, b = init[n]
             if n in identity:          # tfb.Identity(Normal): bernoulli.py:187-193,362-381
@@ -122,6 +124,10 @@ class Surrogate:
                 lq = (a * torch.log(b) - torch.lgamma(a) - (a + 1.0) * torch.log(y) - b / y)
             if self.kinds[n] == "normal_identity":
                 th = y                                          # no Jacobian
+            elif n in self.ident_mask:                          # per-element bijector
+                im = self.ident_mask[n].bool()
+                th = torch.where(im, y, _sp(y))
+                lq = lq - torch.where(im, torch.zeros_like(y), torch.nn.functional.logsigmoid(y))
             else:
                 th = _sp(y)
                 lq = lq - torch.nn.functional.logsigmoid(y)
@@ -162,6 +168,8 @@ class Surrogate:
             v.g0 = grads[2 * i].data_ptr() if grads is not None else None
             v.g1 = grads[2 * i + 1].data_ptr() if grads is not None else None
             v.n, v.kind = t0.numel(), self._KIND[self.kinds[n]]
+            im = self.ident_mask.get(n)
+            v.ident = im.data_ptr() if im is not None else None
         return arr
 
     @torch.no_grad()

@@ -1,0 +1,63 @@
+"""GPU parity of the (build-defined) mixed Poisson/Bernoulli likelihood vs the
+fp64 oracle's definition of it (BASELINE.json config 5; mixed.py is empty in
+the reference, so this pins the build against its own restatement only)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def problem(B, D, K, S, seed, density, scale_rows=True):
+    rng = np.random.default_rng(seed)
+    mask = (np.arange(D) % 2 == 1)                       # 50/50 columns, as config 5
+    x = ((rng.random((B, D)) < density) * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    x[:, mask] = (x[:, mask] > 0)
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, scale_rows=scale_rows, likelihood="mixed",
+                         u_tau_scale=1.0 / math.sqrt(B * D), extra={"bernoulli_columns": mask})
+    cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 2.0, size=(1, D)))
+    cfg.xi_u_global = float(rng.uniform(2.0, 6.0))
+    params = O.random_params(cfg, S, seed + 1)
+    sign = np.where(mask, rng.choice([-1.0, 1.0], size=D), 1.0)
+    params["v"] = params["v"] * sign[None, None, :]
+    params["w"] = params["w"] * np.where(mask, -3.0, 1.0)[None, None, :]
+    return cfg, x, params, mask
+
+
+@pytest.mark.parametrize("B,D,K,S,density,sr", [(37, 24, 3, 2, 0.3, True), (150, 90, 8, 1, 0.1, False),
+                                                (260, 200, 32, 1, 0.05, True), (300, 129, 64, 2, 0.05, True)])
+def test_mixed_energy_and_grads(B, D, K, S, density, sr):
+    from spmf_amd import MixedFactorization
+    cfg, x, params, mask = problem(B, D, K, S, 800 + B + K, density, sr)
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    m = MixedFactorization(mask, latent_dim=K, u_tau_scale=cfg.u_tau_scale, scale_rows=sr,
+                           column_norms=cfg.eta_i, device="cuda", panel_rows=64)
+    m.xi_u_global = cfg.xi_u_global
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    assert float(nnf.sum()) == 0
+    for k, r in pref.items():
+        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=2e-5, atol=2e-5,
+                                   err_msg=k)
+    for k, r in gref.items():
+        g = grads[k].cpu().double().numpy().reshape(r.shape)
+        assert np.abs(g - r.numpy()).max() <= 2e-5 * np.abs(r.numpy()).max(), k
+
+
+def test_mixed_fit_smoke():
+    from spmf_amd import MixedFactorization
+    rng = np.random.default_rng(0)
+    mask = np.arange(20) % 2 == 1
+    X = rng.poisson(1.0, size=(400, 20)).astype(np.float64)
+    X[:, mask] = (rng.random((400, 10)) < 0.2)
+    m = MixedFactorization(mask, latent_dim=2, u_tau_scale=1 / math.sqrt(8000), device="cuda",
+                           panel_rows=100)
+    th = m.surrogate_distribution.sample(2)
+    assert float(th["v"][:, :, mask].max()) < 0 < float(th["v"][:, :, ~mask].min())
+    torch.manual_seed(1)
+    losses = m.fit(lambda: [{"counts": X}], dataset_size=400, sample_size=4, num_steps=15,
+                   learning_rate=0.05, rel_tol=1e-9, verbose=False)
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0]
