@@ -126,3 +126,28 @@ def scrna_like(rows, D, device, seed, first_chunk=0, panel_rows=8192, chunk_rows
     row_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
     row_ptr[1:] = torch.cumsum(cnt, 0)
     return SparseCounts(row_ptr, torch.cat(cols), torch.cat(vals), rows, D, panel_rows)
+
+
+def mixed_c5(rows, D, device, seed, panel_rows=8192):
+    """C5: even columns Poisson as C2 (Bernoulli(0.01) mask x
+    (1 + Poisson(2))), odd columns Bernoulli(0.05) 0/1.  Returns
+    (SparseCounts, bernoulli_column_mask)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    dens = 0.5 * 0.01 + 0.5 * 0.05
+    lam = torch.full((rows,), D * dens * 1.05, device=device)
+    n = torch.poisson(lam, generator=g).clamp_(max=D).to(torch.int64)
+    r = torch.repeat_interleave(torch.arange(rows, device=device), n)
+    # draw a column: odd (Bernoulli) with prob 5/6, even (Poisson) with prob 1/6
+    odd = torch.rand(r.numel(), device=device, generator=g) < (0.05 / 0.06)
+    half = torch.randint(0, D // 2, (int(r.numel()),), device=device, generator=g)
+    c = 2 * half + odd.to(torch.int64)
+    key = torch.unique(r * D + c)
+    r, c = key // D, key % D
+    x = torch.where(c % 2 == 1, torch.ones(key.numel(), device=device),
+                    1.0 + torch.poisson(torch.full((key.numel(),), 2.0, device=device), generator=g))
+    cnt = torch.bincount(r, minlength=rows)
+    row_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    row_ptr[1:] = torch.cumsum(cnt, 0)
+    mask = (torch.arange(D) % 2 == 1).numpy()
+    return SparseCounts(row_ptr, c.to(torch.int32), x.to(torch.float32), rows, D, panel_rows), mask
