@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
   constexpr int MT = KD / 32;  // 32-feature tiles of the second product
   __shared__ __attribute__((aligned(16))) float qs[2][QT * PITCH];
   __shared__ double red[16];
+  __shared__ float bqs[2][QT];   // ACT 1: logit bias of the staged Q rows
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -84,8 +85,10 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
   // (one 32-row part per sub-tile of the compute loop: only PER registers live)
   constexpr int PER4 = 32 * KD / 256 / 4;   // float4 per thread per 32-row part
   float4 stage[PER4];
+  float bstage = 0.f;
   auto gload = [&](int tile, int part) {
     const int q0 = tile * QT + part * 32;
+    if (ACT == 1 && t < 32) bstage = (bias_q && q0 + t < NQ) ? bias_q[q0 + t] : 0.f;
 #pragma unroll
     for (int i = 0; i < PER4; ++i) {
       const int e = (i * 256 + t) * 4;
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
     }
   };
   auto swrite = [&](int buf, int part) {
+    if (ACT == 1 && t < 32) bqs[buf][part * 32 + t] = bstage;
 #pragma unroll
     for (int i = 0; i < PER4; ++i) {
       const int e = (i * 256 + t) * 4;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
     const int buf = (tile - tile0) & 1;
     const bool more = tile + 1 < tile1;     // block-uniform
     // interior tiles need no masking (block-uniform); the sigmoid form always masks
-    const bool edge = ACT == 1 || (tile * QT + QT > NQ) || ((int)(blockIdx.x * 128 + 128) > NP);
+    const bool edge = (tile * QT + QT > NQ) || ((int)(blockIdx.x * 128 + 128) > NP);
     const float* qb = qs[buf];
     const int q0 = tile * QT;
     // Software pipeline over the 4 sub-tiles of the stage: product 1 of
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int q = q0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const bool in = q < NQ && p < NP;
-          const float l = xcur[i] + bp + ((bias_q && in) ? bias_q[q] : 0.f);
+          const bool in = !edge || (q < NQ && p < NP);     // `edge` is block-uniform
+          const float l = xcur[i] + bp + bqs[buf][sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
           const float en = __expf(-fabsf(l));             // exp(-|l|) in (0,1]
           const float inv = __builtin_amdgcn_rcpf(1.f + en);
           const float sg = l >= 0.f ? inv : en * inv;     // sigmoid(l)
