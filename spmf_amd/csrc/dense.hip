@@ -33,6 +33,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int QT = 128;  // Q rows per LDS stage
 
+template <int PB>
+struct XB {
+  f32x16 v[PB];
+};
+
 // ACT 0: E = exp(X)                         esum += sum E          (Poisson, log_transform)
 // ACT 1: E = sigmoid(X + bias)              esum += sum softplus(X + bias)   (Bernoulli logits,
 //        bernoulli.py:147-155; bias = phi of the column: bias_q when Q rows are columns,
@@ -48,41 +53,50 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
   constexpr int PITCH = KD + 4;   // 16-B aligned rows; (KD+4) % 64 = 4 keeps b128 column reads conflict free
   constexpr int KH = KD / 2;      // lane half h covers k in [h*KH, (h+1)*KH): any k order is valid
                                   // as long as A and B agree, and this one makes A a contiguous read
-  constexpr int MT = KD / 32;  // 32-feature tiles of the second product
+  constexpr int MT = KD / 32;     // 32-feature tiles of the second product
+  // P blocks (of 32 rows) per wave: at KD = 32 a sub-tile is only 32 MFMAs, so a
+  // wave carries two P blocks that share every LDS operand read and the loop
+  // overhead (the MFMA : overhead ratio of the KD = 64 form)
+  constexpr int PB = KD == 32 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float qs[2][QT * PITCH];
   __shared__ double red[16];
   __shared__ float bqs[2][QT];   // ACT 1: logit bias of the staged Q rows
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const int p0 = (blockIdx.x * 4 + wid) * 32;
-  const int p = p0 + c;
+  const int p0 = (blockIdx.x * 4 + wid) * 32 * PB;
   // Q range of this block (gridDim.y chunks, whole QT tiles)
   const int ntiles = (NQ + QT - 1) / QT;
   const int tpc = (ntiles + gridDim.y - 1) / gridDim.y;
   const int tile0 = blockIdx.y * tpc;
   const int tile1 = min(ntiles, tile0 + tpc);
 
-  // P fragment: B operand of product 1, step s: B[k][j=c] = P[p0+c][h*KH + s]
-  float pb[KH];
+  // P fragments: B operand of product 1, step s: B[k][j=c] = P[p][h*KH + s]
+  float pb[PB][KH];
+  float bp[PB];
+  f32x16 acc[PB][MT];
+  float colsum[PB];
 #pragma unroll
-  for (int s4 = 0; s4 < KH / 4; ++s4) {
-    const float4 v = p < NP ? *reinterpret_cast<const float4*>(P + (size_t)p * KD + h * KH + 4 * s4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-    pb[4 * s4 + 0] = v.x; pb[4 * s4 + 1] = v.y; pb[4 * s4 + 2] = v.z; pb[4 * s4 + 3] = v.w;
+  for (int b = 0; b < PB; ++b) {
+    const int p = p0 + b * 32 + c;
+#pragma unroll
+    for (int s4 = 0; s4 < KH / 4; ++s4) {
+      const float4 v = p < NP ? *reinterpret_cast<const float4*>(P + (size_t)p * KD + h * KH + 4 * s4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[b][4 * s4 + 0] = v.x; pb[b][4 * s4 + 1] = v.y;
+      pb[b][4 * s4 + 2] = v.z; pb[b][4 * s4 + 3] = v.w;
+    }
+    bp[b] = (ACT == 1 && bias_p && p < NP) ? bias_p[p] : 0.f;
+    colsum[b] = 0.f;                                     // ACT 1: sum_q E for this lane's p
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[b][m][i] = 0.f;
   }
-
-  f32x16 acc[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
   double es = 0.0;
-  float colsum = 0.f;                                   // ACT 1: sum_q E for this lane's p
-  const float bp = (ACT == 1 && bias_p && p < NP) ? bias_p[p] : 0.f;
 
   // stage loader: 256 threads move the QT*KD floats of a tile in QT/32 parts
-  // (one 32-row part per sub-tile of the compute loop: only PER registers live)
+  // (one 32-row part per sub-tile of the compute loop: only PER4 registers live)
   constexpr int PER4 = 32 * KD / 256 / 4;   // float4 per thread per 32-row part
   float4 stage[PER4];
   float bstage = 0.f;
@@ -118,36 +132,48 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
   for (int tile = tile0; tile < tile1; ++tile) {
     const int buf = (tile - tile0) & 1;
     const bool more = tile + 1 < tile1;     // block-uniform
-    // interior tiles need no masking (block-uniform); the sigmoid form always masks
-    const bool edge = (tile * QT + QT > NQ) || ((int)(blockIdx.x * 128 + 128) > NP);
+    // interior tiles need no masking (block-uniform)
+    const bool edge = (tile * QT + QT > NQ) || ((int)(blockIdx.x * 128 * PB + 128 * PB) > NP);
     const float* qb = qs[buf];
     const int q0 = tile * QT;
     // Software pipeline over the 4 sub-tiles of the stage: product 1 of
-    // sub-tile s+1 (an MFMA chain) is issued in the same basic block as the
+    // sub-tile s+1 (MFMA chains) is issued in the same basic block as the
     // exp() VALU work of sub-tile s, so the two pipes overlap inside one wave.
     // Rows past NQ hold zeros in LDS and are masked in E, so no early exit.
     auto product1 = [&](const float* qt) {
-      f32x16 x;
+      XB<PB> xb;
+      f32x16* x = xb.v;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) x[i] = 0.f;
+      for (int b = 0; b < PB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[b][i] = 0.f;
 #pragma unroll
       for (int s4 = 0; s4 < KH / 4; ++s4) {
         const float4 a = *reinterpret_cast<const float4*>(qt + c * PITCH + h * KH + 4 * s4);
-        x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, pb[4 * s4 + 0], x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, pb[4 * s4 + 1], x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, pb[4 * s4 + 2], x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, pb[4 * s4 + 3], x, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+          x[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, pb[b][4 * s4 + 0], x[b], 0, 0, 0);
+          x[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, pb[b][4 * s4 + 1], x[b], 0, 0, 0);
+          x[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, pb[b][4 * s4 + 2], x[b], 0, 0, 0);
+          x[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, pb[b][4 * s4 + 3], x[b], 0, 0, 0);
+        }
       }
-      return x;
+      return xb;
     };
     float es_tile = 0.f;
-    f32x16 xcur = product1(qb);
-#pragma unroll
+    // (with two P blocks per wave the two MFMA chains already interleave; carrying
+    // a second pair of tiles across sub-tiles only costs registers)
+    constexpr bool PIPE = PB == 1;
+    XB<PB> xc, xn;
+    if (PIPE) xc = product1(qb);
+    f32x16* xcur = xc.v;
+    constexpr int UNR = PIPE ? QT / 32 : 1;
+#pragma unroll UNR
     for (int sub = 0; sub < QT / 32; ++sub) {
       const float* qt = qb + sub * 32 * PITCH;
       if (more) gload(tile + 1, sub);       // lands under this sub-tile's MFMAs
-      f32x16 xnext;
-      if (sub + 1 < QT / 32) xnext = product1(qt + 32 * PITCH);
+      if (!PIPE) xc = product1(qt);
+      if (PIPE && sub + 1 < QT / 32) xn = product1(qt + 32 * PITCH);
       // A operands of product 2 for the whole sub-tile, issued before the exp
       // block so their LDS latency is not paid per MFMA pair
       float aq[16][MT];
@@ -158,37 +184,41 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
         for (int m = 0; m < MT; ++m) aq[tt][m] = qt[row * PITCH + m * 32 + c];
       }
       __builtin_amdgcn_sched_barrier(0);
-      // ---- E = exp(X), masked outside [NQ) x [NP) ------------------------
+      // ---- E = act(X), masked outside [NQ) x [NP) on edge tiles ------------
       // exp via v_exp_f32 (2^x): |rel err| ~ 1e-7 * (1 + |x|), inside the 1e-5 budget
       float part = 0.f;
-      if (ACT == 1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int q = q0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const bool in = !edge || (q < NQ && p < NP);     // `edge` is block-uniform
-          const float l = xcur[i] + bp + bqs[buf][sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
-          const float en = __expf(-fabsf(l));             // exp(-|l|) in (0,1]
-          const float inv = __builtin_amdgcn_rcpf(1.f + en);
-          const float sg = l >= 0.f ? inv : en * inv;     // sigmoid(l)
-          const float sp = fmaxf(l, 0.f) + __logf(1.f + en);   // softplus(l)
-          xcur[i] = in ? sg : 0.f;
-          part += in ? sp : 0.f;
-          colsum += in ? sg : 0.f;
-        }
-      } else if (edge) {
+      for (int b = 0; b < PB; ++b) {
+        const int p = p0 + b * 32 + c;
+        if (ACT == 1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int q = q0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const float e = (q < NQ && p < NP) ? __expf(xcur[i]) : 0.f;
-          xcur[i] = e;
-          part += e;
-        }
-      } else {
+          for (int i = 0; i < 16; ++i) {
+            const int ql = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const bool in = !edge || (q0 + ql < NQ && p < NP);   // `edge` is block-uniform
+            const float l = xcur[b][i] + bp[b] + bqs[buf][ql];
+            const float en = __expf(-fabsf(l));             // exp(-|l|) in (0,1]
+            const float inv = __builtin_amdgcn_rcpf(1.f + en);
+            const float sg = l >= 0.f ? inv : en * inv;     // sigmoid(l)
+            const float sp = fmaxf(l, 0.f) + __logf(1.f + en);   // softplus(l)
+            xcur[b][i] = in ? sg : 0.f;
+            part += in ? sp : 0.f;
+            colsum[b] += in ? sg : 0.f;
+          }
+        } else if (edge) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float e = __expf(xcur[i]);
-          xcur[i] = e;
-          part += e;
+          for (int i = 0; i < 16; ++i) {
+            const int q = q0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float e = (q < NQ && p < NP) ? __expf(xcur[b][i]) : 0.f;
+            xcur[b][i] = e;
+            part += e;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float e = __expf(xcur[b][i]);
+            xcur[b][i] = e;
+            part += e;
+          }
         }
       }
       es_tile += part;
@@ -197,34 +227,41 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
       for (int tt = 0; tt < 16; ++tt) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[tt][m], xcur[tt], acc[m], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < PB; ++b)
+            acc[b][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[tt][m], xcur[b][tt], acc[b][m], 0, 0, 0);
       }
-      if (sub + 1 < QT / 32) xcur = xnext;
+      if (PIPE && sub + 1 < QT / 32) xc = xn;
       if (more) swrite(buf ^ 1, sub);
     }
     es += (double)es_tile;
     __syncthreads();
   }
   // ---- store: lane holds features (i&3)+8(i>>2)+4h (+32m) of row p --------
-  if (p < NP) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+  for (int b = 0; b < PB; ++b) {
+    const int p = p0 + b * 32 + c;
+    if (p < NP) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float* dst = out + (size_t)p * KD + m * 32 + 8 * g + 4 * h;
-        if (atomic_out) {
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) atomicAdd(dst + j, sign * acc[m][4 * g + j]);
-        } else {
-          *reinterpret_cast<float4*>(dst) =
-              make_float4(sign * acc[m][4 * g + 0], sign * acc[m][4 * g + 1],
-                          sign * acc[m][4 * g + 2], sign * acc[m][4 * g + 3]);
+        for (int g = 0; g < 4; ++g) {
+          float* dst = out + (size_t)p * KD + m * 32 + 8 * g + 4 * h;
+          if (atomic_out) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(dst + j, sign * acc[b][m][4 * g + j]);
+          } else {
+            *reinterpret_cast<float4*>(dst) =
+                make_float4(sign * acc[b][m][4 * g + 0], sign * acc[b][m][4 * g + 1],
+                            sign * acc[b][m][4 * g + 2], sign * acc[b][m][4 * g + 3]);
+          }
         }
-      }
-  }
-  if (ACT == 1 && out2) {
-    colsum += __shfl_xor(colsum, 32);                   // the two lane halves hold disjoint q rows
-    if (h == 0 && p < NP && colsum != 0.f) atomicAdd(&out2[p], sign * colsum);
+    }
+    if (ACT == 1 && out2) {
+      float cs = colsum[b];
+      cs += __shfl_xor(cs, 32);                         // the two lane halves hold disjoint q rows
+      if (h == 0 && p < NP && cs != 0.f) atomicAdd(&out2[p], sign * cs);
+    }
   }
   if (esum) {
     const double tot = block_sum(es, red);
@@ -233,7 +270,8 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
 }
 
 void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st) {
-  const int nbx = (a.NP + 127) / 128;
+  const int pb = KD == 32 ? 2 : 1;
+  const int nbx = (a.NP + 128 * pb - 1) / (128 * pb);
   int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
   dim3 grid(nbx, chunks);
 #define SPMF_ED_LAUNCH(KD_, ACT_)                                                              \
