@@ -43,7 +43,7 @@ struct XB {
 //        bernoulli.py:147-155; bias = phi of the column: bias_q when Q rows are columns,
 //        bias_p when P rows are columns); out2[p] += sign * sum_q E (the d/dphi column sums)
 template <int KD, int ACT>
-__global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float* __restrict__ P,
+__global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_kernel(int NP, int NQ, const float* __restrict__ P,
                                                      const float* __restrict__ Q,
                                                      float* __restrict__ out, float sign,
                                                      double* __restrict__ esum, int atomic_out,
@@ -140,13 +140,15 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
     // sub-tile s+1 (MFMA chains) is issued in the same basic block as the
     // exp() VALU work of sub-tile s, so the two pipes overlap inside one wave.
     // Rows past NQ hold zeros in LDS and are masked in E, so no early exit.
-    auto product1 = [&](const float* qt) {
+    auto product1 = [&](const float* qt, int sub) {
       XB<PB> xb;
       f32x16* x = xb.v;
+      // ACT 1: the logit biases ride in the accumulator instead of the epilogue
 #pragma unroll
       for (int b = 0; b < PB; ++b)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[b][i] = 0.f;
+        for (int i = 0; i < 16; ++i)
+          x[b][i] = ACT == 1 ? bp[b] + bqs[buf][sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] : 0.f;
 #pragma unroll
       for (int s4 = 0; s4 < KH / 4; ++s4) {
         const float4 a = *reinterpret_cast<const float4*>(qt + c * PITCH + h * KH + 4 * s4);
@@ -165,15 +167,15 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
     // a second pair of tiles across sub-tiles only costs registers)
     constexpr bool PIPE = PB == 1;
     XB<PB> xc, xn;
-    if (PIPE) xc = product1(qb);
+    if (PIPE) xc = product1(qb, 0);
     f32x16* xcur = xc.v;
     constexpr int UNR = PIPE ? QT / 32 : 1;
 #pragma unroll UNR
     for (int sub = 0; sub < QT / 32; ++sub) {
       const float* qt = qb + sub * 32 * PITCH;
       if (more) gload(tile + 1, sub);       // lands under this sub-tile's MFMAs
-      if (!PIPE) xc = product1(qt);
-      if (PIPE && sub + 1 < QT / 32) xn = product1(qt + 32 * PITCH);
+      if (!PIPE) xc = product1(qt, sub);
+      if (PIPE && sub + 1 < QT / 32) xn = product1(qt + 32 * PITCH, sub + 1);
       // A operands of product 2 for the whole sub-tile, issued before the exp
       // block so their LDS latency is not paid per MFMA pair
       float aq[16][MT];
@@ -191,19 +193,39 @@ __global__ __launch_bounds__(256) void expdot_kernel(int NP, int NQ, const float
       for (int b = 0; b < PB; ++b) {
         const int p = p0 + b * 32 + c;
         if (ACT == 1) {
+          // softplus(l) = max(l,0) + ln2*log2(1+e^-|l|): the two sums are kept apart
+          // so the ln2 factor is applied once per sub-tile
+          float pmax = 0.f, plog = 0.f;
+          if (edge) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int ql = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const bool in = !edge || (q0 + ql < NQ && p < NP);   // `edge` is block-uniform
-            const float l = xcur[b][i] + bp[b] + bqs[buf][ql];
-            const float en = __expf(-fabsf(l));             // exp(-|l|) in (0,1]
-            const float inv = __builtin_amdgcn_rcpf(1.f + en);
-            const float sg = l >= 0.f ? inv : en * inv;     // sigmoid(l)
-            const float sp = fmaxf(l, 0.f) + __logf(1.f + en);   // softplus(l)
-            xcur[b][i] = in ? sg : 0.f;
-            part += in ? sp : 0.f;
-            colsum[b] += in ? sg : 0.f;
+            for (int i = 0; i < 16; ++i) {
+              const int ql = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+              const bool in = q0 + ql < NQ && p < NP;
+              const float l = xcur[b][i];
+              const float en = __expf(-fabsf(l));             // exp(-|l|) in (0,1]
+              const float d = 1.f + en;
+              const float inv = __builtin_amdgcn_rcpf(d);
+              const float sg = in ? (l >= 0.f ? inv : en * inv) : 0.f;   // sigmoid(l)
+              xcur[b][i] = sg;
+              pmax += in ? fmaxf(l, 0.f) : 0.f;
+              plog += in ? __builtin_amdgcn_logf(d) : 0.f;
+              colsum[b] += sg;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float l = xcur[b][i];
+              const float en = __expf(-fabsf(l));
+              const float d = 1.f + en;
+              const float inv = __builtin_amdgcn_rcpf(d);
+              const float sg = l >= 0.f ? inv : en * inv;
+              xcur[b][i] = sg;
+              pmax += fmaxf(l, 0.f);
+              plog += __builtin_amdgcn_logf(d);
+              colsum[b] += sg;
+            }
           }
+          part += pmax + 0.69314718056f * plog;
         } else if (edge) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
