@@ -239,6 +239,28 @@ int spmf_adam_step(spmf_ctx* ctx, const spmf_adam_var* tensors, int ntensors, do
                    double beta1, double beta2, double eps, int step, double clip,
                    void* stream);
 
+/* Device-resident optimiser state, so that a whole VI step (noise, surrogate,
+ * energy + gradient, chain rule, Adam) is a fixed launch sequence with no host
+ * read-back and can be captured in a hipGraph and replayed.  state is a device
+ * array of SPMF_VI_STATE_LEN doubles:
+ *   [0] lr  [1] beta1  [2] beta2  [3] eps  [4] clip (0 = off)     (host-written)
+ *   [5] beta1^t  [6] beta2^t  [7] t                               (init 1, 1, 0)
+ *   [8] loss of the last step  [9] 1 if it was applied, 0 if skipped
+ *   [10] sum of applied losses  [11] applied steps  [12] skipped steps
+ * spmf_vi_gate computes loss = -mean_s[x + z + c*(prior - log q)]/rows from the
+ * [S,14] parts of spmf_finish and log q of spmf_surrogate_fwd (SURVEY 8a row
+ * 14), marks the step skipped when the loss is not finite or a stored cell's
+ * log-pmf was not ("Batch loss NaN, skipping",
+ * notebooks/factorizing_random_noise.ipynb:122-420), and advances [5..7],
+ * [10..12].  spmf_adam_step_dev is spmf_adam_step reading every scalar from
+ * state; it does nothing when [9] == 0. */
+#define SPMF_VI_STATE_LEN 16
+int spmf_vi_gate(spmf_ctx* ctx, const double* parts, const double* logq,
+                 const double* n_nonfinite, int S, double c, double rows, double* state,
+                 void* stream);
+int spmf_adam_step_dev(spmf_ctx* ctx, const spmf_adam_var* tensors, int ntensors,
+                       const double* state, void* stream);
+
 /* Test/diagnostic taps: per-row z and d/dz of the LAST draw processed by
  * spmf_data_pass, [B,KP] fp32 with KP = spmf_padded_k(). */
 int spmf_padded_k(const spmf_ctx* ctx);

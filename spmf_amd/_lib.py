@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspmf_hip.so")
 
 NVARS = 12
+VI_STATE_LEN = 16
 NPARTS = 14
 #: variable order of the C-ABI = the reference's var_list (poisson.py:403-539,572)
 VAR_ORDER = ("v", "w", "u", "u_eta", "u_tau", "s_eta", "s_tau", "s",
@@ -92,6 +93,10 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "spmf_surrogate_bwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_void_p]),
+    "spmf_vi_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                               C.c_double, C.c_void_p, C.c_void_p]),
+    "spmf_adam_step_dev": (C.c_int, [C.c_void_p, C.POINTER(AdamVar), C.c_int, C.c_void_p,
+                                     C.c_void_p]),
     "spmf_adam_step": (C.c_int, [C.c_void_p, C.POINTER(AdamVar), C.c_int, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
                                  C.c_void_p]),

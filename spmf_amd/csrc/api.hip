@@ -467,4 +467,26 @@ int spmf_adam_step(spmf_ctx* c, const spmf_adam_var* tensors, int ntensors, doub
   return SPMF_OK;
 }
 
+int spmf_vi_gate(spmf_ctx* c, const double* parts, const double* logq, const double* n_nonfinite, int S, double cw, double rows, double* state, void* stream) {
+  if (!c || !parts || !logq || !state || S < 1 || !(rows > 0.0)) return fail(c, SPMF_E_ARG, "vi_gate: bad arguments");
+  launch_vi_gate(parts, logq, n_nonfinite, S, cw, rows, state, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_adam_step_dev(spmf_ctx* c, const spmf_adam_var* tensors, int ntensors, const double* state, void* stream) {
+  if (!c || !tensors || ntensors < 1 || ntensors > 24 || !state) return fail(c, SPMF_E_ARG, "adam_step_dev: bad arguments");
+  AdamTable T;
+  int max_n = 0;
+  for (int i = 0; i < ntensors; ++i) {
+    const spmf_adam_var& a = tensors[i];
+    if (!a.p || !a.m || !a.v || !a.g || a.n < 1) return fail(c, SPMF_E_ARG, "adam_step_dev: bad tensor");
+    T.v[i] = AdamVar{a.p, a.m, a.v, a.g, a.n};
+    if (a.n > max_n) max_n = a.n;
+  }
+  launch_adam_dev(T, ntensors, max_n, state, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
 }  // extern "C"

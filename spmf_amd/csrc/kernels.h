@@ -124,6 +124,8 @@ struct AdamTable {
 };
 void launch_surrogate_fwd(const SurTable& T, int nvars, int max_n, int S, double* logq, hipStream_t st);
 void launch_surrogate_bwd(const SurTable& T, int nvars, int max_n, int S, float inv_sb, float c, hipStream_t st);
+void launch_vi_gate(const double* parts, const double* logq, const double* nnf, int S, double c, double rows, double* state, hipStream_t st);
+void launch_adam_dev(const AdamTable& T, int ntensors, int max_n, const double* state, hipStream_t st);
 void launch_adam(const AdamTable& T, int ntensors, int max_n, float lr, float b1, float b2, float eps, float c1, float c2, float clip, hipStream_t st);
 
 struct StatsArgs {

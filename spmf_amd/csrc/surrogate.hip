@@ -142,6 +142,61 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable T, float lr, float 
   a.p[i] -= lr * (m / c1) / (sqrtf(vv / c2) + eps);
 }
 
+// ---- device-resident optimiser state (graph-capturable VI step) -------------
+// state[]: see include/spmf_hip.h (SPMF_VI_*).  One thread: loss of this step
+// from the 14 parts and log q, the apply/skip decision, Adam's running powers.
+__global__ void vi_gate_kernel(const double* __restrict__ parts, const double* __restrict__ logq,
+                               const double* __restrict__ nnf, int S, double c, double rows,
+                               double* __restrict__ state) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double acc = 0.0, bad = 0.0;
+  for (int s = 0; s < S; ++s) {
+    double prior = 0.0;
+    for (int i = 0; i < 12; ++i) prior += parts[s * 14 + i];
+    acc += parts[s * 14 + 13] + parts[s * 14 + 12] + c * (prior - logq[s]);
+    bad += nnf ? nnf[s] : 0.0;
+  }
+  const double loss = -(acc / S) / rows;
+  const bool ok = (loss - loss == 0.0) && bad == 0.0;      // finite and no non-finite cell
+  state[8] = loss;
+  state[9] = ok ? 1.0 : 0.0;
+  if (ok) {
+    state[5] *= state[1];
+    state[6] *= state[2];
+    state[7] += 1.0;
+    state[10] += loss;
+    state[11] += 1.0;
+  } else {
+    state[12] += 1.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(AdamTable T, const double* __restrict__ state) {
+  if (state[9] == 0.0) return;                              // step skipped (poisson.py fit: NaN batch)
+  const AdamVar a = T.v[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float lr = (float)state[0], b1 = (float)state[1], b2 = (float)state[2];
+  const float eps = (float)state[3], clip = (float)state[4];
+  const float c1 = (float)(1.0 - state[5]), c2 = (float)(1.0 - state[6]);
+  float g = a.g[i];
+  if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+  const float m = b1 * a.m[i] + (1.f - b1) * g;
+  const float vv = b2 * a.v[i] + (1.f - b2) * g * g;
+  a.m[i] = m;
+  a.v[i] = vv;
+  a.p[i] -= lr * (m / c1) / (sqrtf(vv / c2) + eps);
+}
+
+void launch_vi_gate(const double* parts, const double* logq, const double* nnf, int S, double c,
+                    double rows, double* state, hipStream_t st) {
+  hipLaunchKernelGGL(vi_gate_kernel, dim3(1), dim3(64), 0, st, parts, logq, nnf, S, c, rows, state);
+}
+void launch_adam_dev(const AdamTable& T, int ntensors, int max_n, const double* state, hipStream_t st) {
+  dim3 grid((max_n + 255) / 256, ntensors);
+  hipLaunchKernelGGL(adam_dev_kernel, grid, dim3(256), 0, st, T, state);
+}
+
 void launch_surrogate_fwd(const SurTable& T, int nvars, int max_n, int S, double* logq,
                           hipStream_t st) {
   dim3 grid((max_n + 255) / 256, nvars);

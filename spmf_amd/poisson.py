@@ -90,6 +90,8 @@ class PoissonFactorization:
         self._eta_dev = None
         self._eta_key = None
         self._batch_cache = {}
+        self.max_cached_batches = 256
+        self.max_cached_nnz = 1 << 28
         self.calibrated_expectations = {}
         self.surrogate_distribution = None
         self.surrogate_vars = []
@@ -174,7 +176,15 @@ class PoissonFactorization:
                 sc = hit[1]
             else:
                 sc = SparseCounts.from_any(x, self.device, self.panel_rows)
-                self._batch_cache = {ck: (x, sc)}   # keep only the latest
+                # device layouts of the most recent batches (an epoch loop over a
+                # fixed list of host batches re-uses them; bounded by stored entries)
+                self._batch_cache[ck] = (x, sc)
+                tot = sum(h[1].nnz for h in self._batch_cache.values())
+                while len(self._batch_cache) > 1 and (
+                        len(self._batch_cache) > self.max_cached_batches
+                        or tot > self.max_cached_nnz):
+                    old = next(iter(self._batch_cache))
+                    tot -= self._batch_cache.pop(old)[1].nnz
         if sc.n_cols != self.feature_dim:
             raise ValueError(
                 f"counts have {sc.n_cols} features, model has {self.feature_dim}")
@@ -260,6 +270,7 @@ class PoissonFactorization:
                                       parts.data_ptr(), gout, nnf.data_ptr(), stream),
                    "spmf_finish")
         pd = {n: parts[:, i] for i, n in enumerate(PART_ORDER)}
+        self._last_parts = parts                      # [S,14] block (spmf_vi_gate input)
         return pd, grads, nnf
 
     def unormalized_log_prob_parts(self, data, prior_weight=1., **params):

@@ -130,7 +130,15 @@ class SparseCounts:
         panel sorted by length (descending) so the lane groups of a wave get
         items of similar length.  Deterministic (stable sorts)."""
         dev, D, nP = self.device, self.n_cols, self.n_panels
-        seg = int(seg or SEGMENT_ENTRIES)
+        if seg is None:
+            # a panel should offer a few thousand items: small or nearly dense
+            # batches (few, long column lists) are otherwise a handful of serial
+            # 256-entry walks -- 128 us of latency for a 1000 x 30 batch
+            seg, per_panel = 16, self.nnz / max(1, nP)
+            while seg < SEGMENT_ENTRIES and per_panel / seg > 4096:
+                seg *= 2
+            seg = min(seg, SEGMENT_ENTRIES)
+        seg = int(seg)
         nseg = (cnt + seg - 1) // seg                       # segments per list
         lists = torch.nonzero(nseg > 0, as_tuple=False).view(-1)
         rep = nseg[lists]

@@ -250,6 +250,44 @@ class AdamHIP:
         self.b1, self.b2, self.eps, self.t = beta1, beta2, eps, 0
         self.m = [torch.zeros_like(p) for p in params]
         self.v = [torch.zeros_like(p) for p in params]
+        self.state = None                                 # device state of step_dev()
+
+    # -- device-resident state (include/spmf_hip.h, SPMF_VI_STATE_LEN) ----------
+    def init_state(self, clip_value=None):
+        st = torch.zeros(_lib.VI_STATE_LEN, dtype=torch.float64)
+        st[0], st[1], st[2], st[3] = self.lr, self.b1, self.b2, self.eps
+        st[4] = float(clip_value) if clip_value else 0.0
+        st[5], st[6] = self.b1 ** self.t, self.b2 ** self.t
+        st[7] = self.t
+        self.state = st.to(self.params[0].device)
+        return self.state
+
+    def set_lr(self, lr):
+        self.lr = lr
+        if self.state is not None:
+            self.state[0:1].fill_(lr)
+
+    def read_state(self):
+        """Host copy of the device state (one sync)."""
+        return self.state.cpu().tolist()
+
+    def reset_epoch_counters(self):
+        self.state[10:13].zero_()
+
+    @torch.no_grad()
+    def step_dev(self, grads):
+        """Adam update gated by state[9]; every scalar comes from the device
+        state, so the launch is identical from step to step (graph-capturable)."""
+        lib, h = _lib.load(), self.model._handle()
+        arr = (_lib.AdamVar * len(self.params))()
+        for i, (p, g, m, v) in enumerate(zip(self.params, grads, self.m, self.v)):
+            if not g.is_contiguous():
+                raise ValueError("step_dev needs contiguous gradients")
+            a = arr[i]
+            a.p, a.m, a.v, a.g, a.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), p.numel()
+        stream = torch.cuda.current_stream(p.device).cuda_stream
+        _lib.check(h, lib.spmf_adam_step_dev(h, arr, len(self.params), self.state.data_ptr(),
+                                             stream), "spmf_adam_step_dev")
 
     @torch.no_grad()
     def step(self, grads, clip_value=None):
@@ -286,6 +324,91 @@ def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None):
     loss = -(energy - c * logq).mean() / rows
     grads = sur.backward_hip(model, S, noise, g, 1.0 / (S * rows), c)
     return loss, grads, nnf
+
+
+@torch.no_grad()
+def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None):
+    """One whole VI step with no host read-back: noise, surrogate, energy +
+    gradient, loss/skip decision (spmf_vi_gate), chain rule, gated Adam
+    (spmf_adam_step_dev).  The launch sequence depends only on the batch
+    object, so it can be captured in a hipGraph (StepRunner)."""
+    lib, h = _lib.load(), model._handle()
+    sur = model.surrogate_distribution
+    S = int(sample_size)
+    noise = sur.draw_noise(S)
+    theta, logq = sur.forward_hip(model, S, noise)
+    sc, cs = model._batch(batch)
+    B = cs.n_rows
+    c = float(B) / float(dataset_rows)
+    parts, g, nnf = model.energy_and_grads(batch, theta, prior_weight=c)
+    stream = torch.cuda.current_stream(sur.device).cuda_stream
+    _lib.check(h, lib.spmf_vi_gate(h, model._last_parts.data_ptr(), logq.data_ptr(),
+                                   nnf.data_ptr(), S, c, float(B), opt.state.data_ptr(), stream),
+               "spmf_vi_gate")
+    grads = sur.backward_hip(model, S, noise, g, 1.0 / (S * B), c)
+    opt.step_dev(grads)
+    if keep is not None:
+        keep.update(noise=noise, theta=theta, logq=logq, parts=model._last_parts, g=g,
+                    grads=grads, nnf=nnf)
+
+
+class StepRunner:
+    """Runs vi_step_dev per batch; the second time a batch object is seen its
+    step is captured into a hipGraph (torch.cuda.CUDAGraph: the library's
+    launches go to torch's capturing stream) and replayed from then on.  Small
+    batches are launch-bound (about 40 launches per step), which is what the
+    graph removes; large ones lose nothing."""
+
+    def __init__(self, model, opt, dataset_rows, sample_size, use_graph=True, max_graphs=64):
+        self.model, self.opt = model, opt
+        self.dataset_rows, self.S = dataset_rows, int(sample_size)
+        self.use_graph = bool(use_graph)
+        self.max_graphs = max_graphs
+        self.graphs = {}           # key -> (graph, workspace ptr, pinned refs)
+        self.seen = {}
+        self.pool = None
+        self.replays = 0
+        self.keep_tensors = False  # tests: keep the captured step's tensors
+        self.kept = {}
+
+    def _key(self, batch):
+        sc, cs = self.model._batch(batch)
+        return (id(cs), self.S, float(self.dataset_rows)), cs
+
+    def step(self, batch):
+        if not self.use_graph:
+            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S)
+            return
+        key, cs = self._key(batch)
+        hit = self.graphs.get(key)
+        ws = self.model._ws.data_ptr() if self.model._ws is not None else 0
+        if hit is not None and hit[1] == ws and hit[2] is cs:
+            hit[0].replay()
+            self.replays += 1
+            return
+        if hit is not None:
+            del self.graphs[key]
+        if self.seen.get(key) is not cs or ws == 0:
+            # first sight: eager (also the warm-up that sizes the workspace)
+            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S)
+            if len(self.seen) > 4 * self.max_graphs:
+                self.seen.clear()
+            self.seen[key] = cs
+            return
+        if len(self.graphs) >= self.max_graphs:
+            self.graphs.pop(next(iter(self.graphs)))
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        graph = torch.cuda.CUDAGraph()
+        keep = {} if self.keep_tensors else None
+        torch.cuda.synchronize(self.model.device)
+        with torch.cuda.graph(graph, pool=self.pool):
+            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, keep=keep)
+        if keep is not None:
+            self.kept[key] = keep
+        self.graphs[key] = (graph, self.model._ws.data_ptr(), cs)
+        graph.replay()             # capture does not execute: run the step once
+        self.replays += 1
 
 
 def elbo_step_reference(model, batch, dataset_rows, sample_size, all_reduce=None, generator=None):
@@ -328,18 +451,35 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
     opt = AdamHIP(model, sur.trainable_variables, learning_rate)
     epochs = num_epochs if num_epochs is not None else num_steps
     losses, best, best_state, decays = [], math.inf, None, 0
+    device_loop = all_reduce is None
+    if device_loop:
+        opt.init_state(clip_value)
+        runner = StepRunner(model, opt, dataset_size, sample_size,
+                            use_graph=kwargs.get("use_graph", True))
+        model._step_runner = runner
     for ep in range(epochs):
         tot, nb = 0.0, 0
-        for batch in iter(batched_data_factory()):
-            loss, grads, nnf = elbo_step(model, batch, dataset_size, sample_size, all_reduce)
-            lv = float(loss)
-            if not math.isfinite(lv) or float(nnf.sum()) > 0:
-                if verbose:
-                    print("Batch loss NaN, skipping")
-                continue
-            opt.step(grads, clip_value)
-            tot += lv
-            nb += 1
+        if device_loop:
+            # no host read-back inside the epoch: the loss sum, the applied and
+            # the skipped step counts live in the optimiser's device state
+            opt.reset_epoch_counters()
+            for batch in iter(batched_data_factory()):
+                runner.step(batch)
+            st = opt.read_state()
+            tot, nb, skipped = st[10], int(st[11]), int(st[12])
+            if verbose and skipped:
+                print(f"Batch loss NaN, skipping ({skipped} batches)")
+        else:
+            for batch in iter(batched_data_factory()):
+                loss, grads, nnf = elbo_step(model, batch, dataset_size, sample_size, all_reduce)
+                lv = float(loss)
+                if not math.isfinite(lv) or float(nnf.sum()) > 0:
+                    if verbose:
+                        print("Batch loss NaN, skipping")
+                    continue
+                opt.step(grads, clip_value)
+                tot += lv
+                nb += 1
         if nb == 0:
             break
         ep_loss = tot / nb
@@ -355,7 +495,7 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
             best_state = [p.detach().clone() for p in sur.trainable_variables]
         else:
             decays += 1
-            opt.lr *= lr_decay_factor
+            opt.set_lr(opt.lr * lr_decay_factor)
             if verbose:
                 print(f"We are in a loss plateau learning rate: {opt.lr}")
             if best_state is not None:
