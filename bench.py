@@ -104,12 +104,37 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          "torch.distributed.run --nproc-per-node N")
+    # rehearsal on a one-GPU box: SPMF_BENCH_BACKEND=gloo SPMF_BENCH_ONE_GPU=1 puts every
+    # rank on cuda:0 with host-staged collectives (same sharding/reducer/timing logic)
+    backend = os.environ.get("SPMF_BENCH_BACKEND", "nccl")
+    if os.environ.get("SPMF_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # launched by torch.distributed.run (also with one rank: exercises RCCL)
     distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce_(t, op=None):
+        op = op or dist.ReduceOp.SUM
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h_ = t.cpu()
+            dist.all_reduce(h_, op=op)
+            t.copy_(h_)
+
+    def broadcast_(t, src):
+        if backend == "nccl":
+            dist.broadcast(t, src)
+        else:
+            h_ = t.cpu()
+            dist.broadcast(h_, src)
+            t.copy_(h_)
 
     rows, D, density, K, desc = WORKLOADS[args.workload]
     if args.rows:
@@ -121,6 +146,9 @@ def main():
     c0 = nchunks * rank // world
     c1 = nchunks * (rank + 1) // world
     my_rows = min(rows, c1 * chunk) - c0 * chunk
+    if my_rows <= 0:
+        raise SystemExit(f"{rows} rows are {nchunks} generator chunks of {chunk}: too few for "
+                         f"{world} ranks")
     logt = args.workload.startswith("c4")
     mixed_mask = None
     if args.workload == "c5":
@@ -155,7 +183,7 @@ def main():
                        dtype=torch.float64, device=dev)
     if distributed:
         for t in (colsum, colnnz, tot):
-            dist.all_reduce(t)
+            all_reduce_(t)
     cm = colsum / colnnz
     if logt:
         # bin/factorize_scrnaseq_counts.py:93-99: column_norms = plain column means
@@ -173,7 +201,7 @@ def main():
     params = model.surrogate_distribution.sample(S)
     if distributed:
         for n in _lib.VAR_ORDER:            # replicate rank 0's draw
-            dist.broadcast(params[n], 0)
+            broadcast_(params[n], 0)
     batch = {"counts": sc}
 
     hook = None
@@ -208,7 +236,7 @@ def main():
     lib.spmf_ctx_enable_timing(h, 0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if distributed:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce_(tmax, dist.ReduceOp.MAX)
     dt = float(tmax[0])
 
     # extra (not the contract's `value`): the whole VI step -- base noise, surrogate

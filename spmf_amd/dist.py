@@ -43,7 +43,7 @@ class ShardReducer:
                            device=colsum.device)
         if self.active:
             for t in (colsum, colnnz, tot):
-                dist.all_reduce(t, group=self.group)
+                self._sum(t)
         self.rows_global = int(round(float(tot[0])))
         self.lgamma_global = float(tot[1])
         return self.rows_global, self.lgamma_global
@@ -51,15 +51,23 @@ class ShardReducer:
     def set_batch_totals(self, rows_global, lgamma_global):
         self.rows_global, self.lgamma_global = int(rows_global), float(lgamma_global)
 
+    def _sum(self, t):
+        if dist.get_backend(self.group) != "nccl" and t.is_cuda:
+            h = t.cpu()                      # rehearsal transport (gloo): host-staged
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
+
     def __call__(self, acc, rows, lgamma_sum):
         """all_reduce hook of PoissonFactorization.energy_and_grads."""
         if self.active:
-            dist.all_reduce(acc, group=self.group)
+            self._sum(acc)
         if self.rows_global is None:
             tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64,
                                device=acc.device)
             if self.active:
-                dist.all_reduce(tot, group=self.group)
+                self._sum(tot)
             return int(round(float(tot[0]))), float(tot[1])
         return self.rows_global, self.lgamma_global
 
