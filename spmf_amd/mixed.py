@@ -18,8 +18,6 @@ bias of -1e30 on the Poisson columns (sigmoid = softplus = 0 there).
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import numpy as np
 import torch
 
