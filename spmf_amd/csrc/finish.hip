@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   __shared__ float tile[KP][FTD + 1];
   __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
   __shared__ float zsum_s[KP], utau_s[KP], dec_s[KP], gutau_s[KP];
+  __shared__ double lsc_s[KP];     // log(u_tau_k * decay^k)
   __shared__ float gred[256];
   __shared__ int bern_s[FTD];
   const int t = threadIdx.x;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     utau_s[t] = t < K ? P.p[UTAU_][t] : 1.f;
     dec_s[t] = (float)pow((double)decay, (double)t);   // powf is ~1e-6 off at t~60: a systematic part error
     gutau_s[t] = 0.f;
+    lsc_s[t] = log((double)utau_s[t]) + (double)t * log(decay);
   }
   if (t < FTD) {
     const int d = d0 + t;
@@ -134,21 +136,23 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       const float dA = gAp[(size_t)d * KP + k] * ietas[dl];
       ga_u = u * dA;
       const float sc = utau_s[k] * dec_s[k];
-      double lp;
-      float gy, gs;
-      halfnormal(u, ue * sc, lp, gy, gs);
-      part[U_] += (double)lp;
+      // the three log-densities share their fp64 logs (software fp64 log is what
+      // this kernel's time goes to): log sig = log ue + log(utau_k dec_k)
+      const double Lue = log((double)ue), Lua = log((double)ua);
+      const float sig = ue * sc, is = 1.f / sig, q = u * is;
+      const double qd = (double)u / ((double)ue * (double)sc);
+      part[U_] += kHalfLog2OverPi - (Lue + lsc_s[k]) - 0.5 * qd * qd;
+      const float gy = -q * is, gs = (q * q - 1.f) * is;
       G.p[U_][i] = w1s[dl] * dA + pw * gy;
       gut = pw * gs * ue * dec_s[k];
-      double lp2;
-      float gy2, ga2;
-      sqrt_ig(ue, ua, lp2, gy2, ga2);
-      part[UETA_] += (double)lp2;
+      const float iy = 1.f / ue, ia = 1.f / ua;
+      const float tt = ia * iy * iy;                       // 1/(ua ue^2)
+      part[UETA_] += -0.5 * Lua - kLgammaHalf - 2.0 * Lue
+                     - 1.0 / ((double)ua * (double)ue * (double)ue) + kLog2;
+      const float gy2 = -2.f * iy + 2.f * tt * iy, ga2 = -0.5f * ia + tt * ia;
       G.p[UETA_][i] = pw * (gs * sc + gy2);
-      double lp3;
-      float ga3;
-      ig_half(ua, 1.f, 0.f, lp3, ga3);
-      part[UETAA_] += (double)lp3;
+      part[UETAA_] += -kLgammaHalf - 1.5 * Lua - 1.0 / (double)ua;   // InvGamma(1/2, 1)
+      const float ga3 = -1.5f * ia + ia * ia;
       G.p[UETAA_][i] = pw * (ga2 + ga3);
     }
     // GA_d = sum_k u*dA : fold over the LW lanes that share d
