@@ -146,6 +146,18 @@ int spmf_data_pass(spmf_ctx* ctx, const spmf_counts* counts, int S,
 float* spmf_acc_ptr(const spmf_ctx* ctx);      /* device pointer into the workspace */
 int64_t spmf_acc_len(const spmf_ctx* ctx, int S); /* floats, all S draws */
 
+/* Optional overlap for the multi-GPU step: launch the prior half of
+ * spmf_finish (all twelve prior log-densities and prior_weight * d prior /
+ * d theta; it reads no accumulator) on the context's side stream, forked from
+ * `stream`.  Meant to be called between spmf_data_pass and the all-reduce, so
+ * it runs while the collective leaves the GPU mostly idle (beside the sparse
+ * passes it costs them more than it hides: 3.60 -> 3.80 ms on C3).
+ * spmf_finish with the same S, parts and grads then joins the side stream and
+ * adds the data half only; without this call it does both halves itself. */
+int spmf_prior_async(spmf_ctx* ctx, int S, double prior_weight,
+                     const float* const params[SPMF_NVARS], const float* eta, double* parts,
+                     float* const grads[SPMF_NVARS], void* stream);
+
 /* Phase 2: chain the accumulators to d/d(u,v,w,s), add the horseshoe-plus
  * prior (poisson.py:228-377) parts and gradients for all 12 variables, and
  * finish the 14 energy parts.  n_rows_global / lgamma_sum_global are the

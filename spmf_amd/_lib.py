@@ -93,6 +93,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "spmf_surrogate_bwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_void_p]),
+    "spmf_prior_async": (C.c_int, [C.c_void_p, C.c_int, C.c_double, PtrArray, C.c_void_p, C.c_void_p,
+                                   PtrArray, C.c_void_p]),
     "spmf_vi_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
                                C.c_double, C.c_void_p, C.c_void_p]),
     "spmf_adam_step_dev": (C.c_int, [C.c_void_p, C.POINTER(AdamVar), C.c_int, C.c_void_p,

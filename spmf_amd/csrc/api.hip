@@ -38,6 +38,11 @@ struct spmf_ctx {
   int ev_set = -1;      // set used by the call in flight
   int ev_count = 0;     // complete sets recorded since enable
   int ev_valid = 0;
+  // prior half of the finish on a side stream (spmf_prior_async)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int prior_pending = 0;          // S of the launched prior half, 0 = none
+  const double* prior_parts = nullptr;
   std::string err;
 };
 
@@ -120,6 +125,9 @@ void spmf_ctx_destroy(spmf_ctx* c) {
   for (auto& set : c->evs)
     for (auto& e : set)
       if (e) (void)hipEventDestroy(e);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
 
@@ -330,6 +338,42 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
   return SPMF_OK;
 }
 
+static int likelihood_code(const spmf_ctx* c) {
+  return (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : ((c->flags & SPMF_FLAG_MIXED) ? 3 : 0));
+}
+
+int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS], void* stream) {
+  if (!c || !params || !grads || !eta || !parts || S < 1) return fail(c, SPMF_E_ARG, "prior_async: bad arguments");
+  for (int i = 0; i < SPMF_NVARS; ++i)
+    if (!params[i] || !grads[i]) return fail(c, SPMF_E_ARG, "prior_async: all 12 params/grads must be non-null");
+  hipStream_t st = (hipStream_t)stream;
+  if (!c->side) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
+  // outputs are zeroed in stream order, then the side stream forks off `stream`
+  HIPCHK(c, hipMemsetAsync(parts, 0, (size_t)S * SPMF_NPARTS * sizeof(double), st));
+  HIPCHK(c, hipMemsetAsync(grads[4], 0, (size_t)S * c->K * sizeof(float), st));
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));
+  HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+  for (int s = 0; s < S; ++s) {
+    const float* P[SPMF_NVARS];
+    float* G[SPMF_NVARS];
+    for (int i = 0; i < SPMF_NVARS; ++i) {
+      P[i] = params[i] + s * var_size(c, i);
+      G[i] = grads[i] + s * var_size(c, i);
+    }
+    FinishArgs fa{c->D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, nullptr, nullptr, P, eta, G, parts + (size_t)s * SPMF_NPARTS, nullptr, likelihood_code(c), c->ctype};
+    launch_finish(c->KP, fa, 1, c->side);
+  }
+  HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+  HIPCHK(c, hipGetLastError());
+  c->prior_pending = S;
+  c->prior_parts = parts;
+  return SPMF_OK;
+}
+
 int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_global, double prior_weight, const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS], double* n_nonfinite, void* stream) {
   if (!c || !params || !grads || !eta || !parts || S < 1) return fail(c, SPMF_E_ARG, "finish: bad arguments");
   if (!c->acc || c->ws_S < S) return fail(c, SPMF_E_ARG, "finish: no data pass precedes it for this S");
@@ -338,8 +382,17 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
   hipStream_t st = (hipStream_t)stream;
   const int KP = c->KP, D = c->D;
   const size_t al_ = acc_len(D, KP);
-  HIPCHK(c, hipMemsetAsync(parts, 0, (size_t)S * SPMF_NPARTS * sizeof(double), st));
-  HIPCHK(c, hipMemsetAsync(grads[4], 0, (size_t)S * c->K * sizeof(float), st));
+  // the prior half may already be running on the side stream (spmf_prior_async
+  // with these outputs): join it and add the data half only
+  const bool joined = c->prior_pending == S && c->prior_parts == parts;
+  c->prior_pending = 0;
+  c->prior_parts = nullptr;
+  if (joined) {
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+  } else {
+    HIPCHK(c, hipMemsetAsync(parts, 0, (size_t)S * SPMF_NPARTS * sizeof(double), st));
+    HIPCHK(c, hipMemsetAsync(grads[4], 0, (size_t)S * c->K * sizeof(float), st));
+  }
   for (int s = 0; s < S; ++s) {
     const bool tm = c->timing && s == S - 1;
     const float* P[SPMF_NVARS];
@@ -348,9 +401,9 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
       P[i] = params[i] + s * var_size(c, i);
       G[i] = grads[i] + s * var_size(c, i);
     }
-    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : ((c->flags & SPMF_FLAG_MIXED) ? 3 : 0)), c->ctype};
+    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, likelihood_code(c), c->ctype};
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
-    launch_finish(KP, fa, st);
+    launch_finish(KP, fa, joined ? 2 : 0, st);
     if (tm) {
       HIPCHK(c, hipEventRecord(c->ev[5], st));
       if (c->ev_valid == 1) {

@@ -15,7 +15,7 @@
 //   parts 'x','z' (poisson.py:599-619) from the fp64 scalars in the
 //   accumulator tail and the closed-form sum of the rate over all cells.
 //
-// One block per 64 features; [D,K]-shaped arrays are walked flat (coalesced),
+// One block per 32 features; [D,K]-shaped arrays are walked flat (coalesced),
 // the [K,D]-shaped v / dv through an LDS transpose tile.  O(D*K) elementwise
 // work with fp64 block reductions: HBM-bound and tiny next to the nnz passes.
 #include "common.h"
@@ -23,7 +23,7 @@
 
 namespace spmf {
 
-constexpr int FTD = 64;
+constexpr int FTD = 32;
 constexpr int SPMF_NPARTS_LOCAL = 12;
 
 struct Ptrs12 {
@@ -69,7 +69,12 @@ __device__ __forceinline__ void ig_half(float a, float beta, float half_log_beta
   ga = -1.5f * ia + beta * ia * ia;
 }
 
-template <int KP>
+// PHASE 0: everything (one launch).  PHASE 1: the prior half only -- all twelve
+// log-densities and pw * d prior/d theta written to G; needs nothing from the
+// data pass, so the host runs it on a side stream beside the sparse passes.
+// PHASE 2: the data half only -- the chain rule from the accumulators ADDED to
+// G, and parts 'z', 'x'.  PHASE 1 then 2 == PHASE 0.
+template <int KP, int PHASE>
 __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
                                                      double lgamma_sum, float u_tau_scale,
                                                      float s_tau_scale, double decay, float pw,
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
                                                      double* __restrict__ parts,
                                                      double* __restrict__ nnf_out, int logt,
                                                      const uint8_t* __restrict__ ctype) {
+  constexpr bool PRIOR = PHASE != 2, DATA = PHASE != 1;
   __shared__ float tile[KP][FTD + 1];
   __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
   __shared__ float zsum_s[KP], utau_s[KP], dec_s[KP], gutau_s[KP];
@@ -98,11 +104,11 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   if (t < KP) {
     // log_transform: the dense kernel already subtracted sum_b E_bd z_b from gV'
     // (mixed, code 3: still needed for the Poisson columns)
-    zsum_s[t] = (logt == 1 || logt == 2) ? 0.f : (float)unpack(tail, kDaccHead + t);
+    zsum_s[t] = (!DATA || logt == 1 || logt == 2) ? 0.f : (float)unpack(tail, kDaccHead + t);
     utau_s[t] = t < K ? P.p[UTAU_][t] : 1.f;
     dec_s[t] = (float)pow((double)decay, (double)t);   // powf is ~1e-6 off at t~60: a systematic part error
     gutau_s[t] = 0.f;
-    lsc_s[t] = log((double)utau_s[t]) + (double)t * log(decay);
+    if (PRIOR) lsc_s[t] = log((double)utau_s[t]) + (double)t * log(decay);
   }
   if (t < FTD) {
     const int d = d0 + t;
@@ -132,33 +138,44 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     float ga_u = 0.f, gut = 0.f;
     if (d < D && k < K) {
       const size_t i = (size_t)d * K + k;
-      const float u = P.p[U_][i], ue = P.p[UETA_][i], ua = P.p[UETAA_][i];
-      const float dA = gAp[(size_t)d * KP + k] * ietas[dl];
-      ga_u = u * dA;
-      const float sc = utau_s[k] * dec_s[k];
-      // the three log-densities share their fp64 logs (software fp64 log is what
-      // this kernel's time goes to): log sig = log ue + log(utau_k dec_k)
-      const double Lue = log((double)ue), Lua = log((double)ua);
-      const float sig = ue * sc, is = 1.f / sig, q = u * is;
-      const double qd = (double)u / ((double)ue * (double)sc);
-      part[U_] += kHalfLog2OverPi - (Lue + lsc_s[k]) - 0.5 * qd * qd;
-      const float gy = -q * is, gs = (q * q - 1.f) * is;
-      G.p[U_][i] = w1s[dl] * dA + pw * gy;
-      gut = pw * gs * ue * dec_s[k];
-      const float iy = 1.f / ue, ia = 1.f / ua;
-      const float tt = ia * iy * iy;                       // 1/(ua ue^2)
-      part[UETA_] += -0.5 * Lua - kLgammaHalf - 2.0 * Lue
-                     - 1.0 / ((double)ua * (double)ue * (double)ue) + kLog2;
-      const float gy2 = -2.f * iy + 2.f * tt * iy, ga2 = -0.5f * ia + tt * ia;
-      G.p[UETA_][i] = pw * (gs * sc + gy2);
-      part[UETAA_] += -kLgammaHalf - 1.5 * Lua - 1.0 / (double)ua;   // InvGamma(1/2, 1)
-      const float ga3 = -1.5f * ia + ia * ia;
-      G.p[UETAA_][i] = pw * (ga2 + ga3);
+      const float u = P.p[U_][i];
+      float du = 0.f;
+      if (DATA) {
+        const float dA = gAp[(size_t)d * KP + k] * ietas[dl];
+        ga_u = u * dA;
+        du = w1s[dl] * dA;
+      }
+      if (PRIOR) {
+        const float ue = P.p[UETA_][i], ua = P.p[UETAA_][i];
+        const float sc = utau_s[k] * dec_s[k];
+        // the three log-densities share their fp64 logs (software fp64 log is what
+        // this kernel's time goes to): log sig = log ue + log(utau_k dec_k)
+        const double Lue = log((double)ue), Lua = log((double)ua);
+        const float sig = ue * sc, is = 1.f / sig, q = u * is;
+        const double qd = (double)u / ((double)ue * (double)sc);
+        part[U_] += kHalfLog2OverPi - (Lue + lsc_s[k]) - 0.5 * qd * qd;
+        const float gy = -q * is, gs = (q * q - 1.f) * is;
+        G.p[U_][i] = du + pw * gy;
+        gut = pw * gs * ue * dec_s[k];
+        const float iy = 1.f / ue, ia = 1.f / ua;
+        const float tt = ia * iy * iy;                       // 1/(ua ue^2)
+        part[UETA_] += -0.5 * Lua - kLgammaHalf - 2.0 * Lue
+                       - 1.0 / ((double)ua * (double)ue * (double)ue) + kLog2;
+        const float gy2 = -2.f * iy + 2.f * tt * iy, ga2 = -0.5f * ia + tt * ia;
+        G.p[UETA_][i] = pw * (gs * sc + gy2);
+        part[UETAA_] += -kLgammaHalf - 1.5 * Lua - 1.0 / (double)ua;   // InvGamma(1/2, 1)
+        const float ga3 = -1.5f * ia + ia * ia;
+        G.p[UETAA_][i] = pw * (ga2 + ga3);
+      } else {
+        G.p[U_][i] += du;
+      }
     }
-    // GA_d = sum_k u*dA : fold over the LW lanes that share d
+    if (DATA) {
+      // GA_d = sum_k u*dA : fold over the LW lanes that share d
 #pragma unroll
-    for (int m = 1; m < LW; m <<= 1) ga_u += __shfl_xor(ga_u, m);
-    if ((k % LW) == 0 && d < D) GAs[dl] = ga_u;   // one writer per dl
+      for (int m = 1; m < LW; m <<= 1) ga_u += __shfl_xor(ga_u, m);
+      if ((k % LW) == 0 && d < D) GAs[dl] = ga_u;   // one writer per dl
+    }
     gut_acc += gut;
   }
   // fold gut over the threads that share k: t, t+KP, t+2KP, ... (256/KP of them)
@@ -170,10 +187,12 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     gutau_s[t] = g;
   }
   // ---- v / dv through the transpose tile ---------------------------------
-  for (int e = t; e < KP * FTD; e += 256) {
-    const int dl = e / KP, k = e % KP;
-    const int d = d0 + dl;
-    tile[k][dl] = (d < D) ? (gVp[(size_t)d * KP + k] - (bern_s[dl] ? 0.f : zsum_s[k])) * etas_[dl] : 0.f;
+  if (DATA) {
+    for (int e = t; e < KP * FTD; e += 256) {
+      const int dl = e / KP, k = e % KP;
+      const int d = d0 + dl;
+      tile[k][dl] = (d < D) ? (gVp[(size_t)d * KP + k] - (bern_s[dl] ? 0.f : zsum_s[k])) * etas_[dl] : 0.f;
+    }
   }
   __syncthreads();
   for (int e = t; e < KP * FTD; e += 256) {
@@ -181,13 +200,18 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     const int d = d0 + dl;
     if (k < K && d < D) {
       const size_t i = (size_t)k * D + d;
-      const float v = P.p[V_][i];
-      double lp;
-      float gy, gs;
-      halfnormal(v, 0.1f, lp, gy, gs);
-      if (bern_s[dl]) lp -= kLog2;   // Bernoulli column: v ~ Normal(0,.1) (bernoulli.py:187-200)
-      part[V_] += (double)lp;
-      G.p[V_][i] = tile[k][dl] + pw * gy;
+      const float dv = DATA ? tile[k][dl] : 0.f;
+      if (PRIOR) {
+        const float v = P.p[V_][i];
+        double lp;
+        float gy, gs;
+        halfnormal(v, 0.1f, lp, gy, gs);
+        if (bern_s[dl]) lp -= kLog2;   // Bernoulli column: v ~ Normal(0,.1) (bernoulli.py:187-200)
+        part[V_] += (double)lp;
+        G.p[V_][i] = dv + pw * gy;
+      } else {
+        G.p[V_][i] += dv;
+      }
     }
   }
   // ---- [.,D] vectors: w, s, s_eta, s_tau, s_eta_a, s_tau_a ---------------
@@ -195,67 +219,79 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     const int d = d0 + t;
     const float e = etas_[t];
     const float s0 = P.p[S_][d], s1 = P.p[S_][D + d], w = P.p[W_][d];
-    const float T = s0 + s1, iT2 = 1.f / (T * T);
-    const float w2 = s1 / T;
-    // Poisson: sum_b x/r - B; Bernoulli: sum_nnz x - sum_b sigmoid (dense kernel already applied)
-    const float dphi = bern_s[t] ? gph[d] : gph[d] - (float)Bglob;
-    const float GA = GAs[t], Gphi = e * w * dphi;
-    double lp;
-    float gy, gs;
-    halfnormal(w, 1.f, lp, gy, gs);
-    if (bern_s[t]) lp -= kLog2;     // Bernoulli column: w ~ Normal(0,1) (bernoulli.py:201-216)
-    part[W_] += (double)lp;
-    G.p[W_][d] = e * w2 * dphi + pw * gy;
-    const float se0 = P.p[SETA_][d], se1 = P.p[SETA_][D + d], stau = P.p[STAU_][d];
-    double lp0, lp1;
-    float gy0, gs0, gy1, gs1;
-    halfnormal(s0, se0 * stau, lp0, gy0, gs0);
-    halfnormal(s1, se1 * stau, lp1, gy1, gs1);
-    part[S_] += (double)lp0 + (double)lp1;
-    G.p[S_][d] = (GA - Gphi) * s1 * iT2 + pw * gy0;
-    G.p[S_][D + d] = (Gphi - GA) * s0 * iT2 + pw * gy1;
-    const float sa0 = P.p[SETAA_][d], sa1 = P.p[SETAA_][D + d], sta = P.p[STAUA_][d];
-    double a_lp, b_lp, c_lp;
-    float a_gy, a_ga, b_gy, b_ga, c_ga;
-    sqrt_ig(se0, sa0, a_lp, a_gy, a_ga);
-    sqrt_ig(se1, sa1, b_lp, b_gy, b_ga);
-    part[SETA_] += (double)a_lp + (double)b_lp;
-    G.p[SETA_][d] = pw * (gs0 * stau + a_gy);
-    G.p[SETA_][D + d] = pw * (gs1 * stau + b_gy);
-    ig_half(sa0, 1.f, 0.f, c_lp, c_ga);
-    part[SETAA_] += (double)c_lp;
-    G.p[SETAA_][d] = pw * (a_ga + c_ga);
-    ig_half(sa1, 1.f, 0.f, c_lp, c_ga);
-    part[SETAA_] += (double)c_lp;
-    G.p[SETAA_][D + d] = pw * (b_ga + c_ga);
-    sqrt_ig(stau, sta, a_lp, a_gy, a_ga);
-    part[STAU_] += (double)a_lp;
-    G.p[STAU_][d] = pw * (gs0 * se0 + gs1 * se1 + a_gy);
-    const float beta = 1.f / (s_tau_scale * s_tau_scale);
-    ig_half(sta, beta, 0.5f * logf(beta), c_lp, c_ga);
-    part[STAUA_] += (double)c_lp;
-    G.p[STAUA_][d] = pw * (a_ga + c_ga);
+    float dw = 0.f, ds0 = 0.f, ds1 = 0.f;
+    if (DATA) {
+      const float T = s0 + s1, iT2 = 1.f / (T * T);
+      const float w2 = s1 / T;
+      // Poisson: sum_b x/r - B; Bernoulli: sum_nnz x - sum_b sigmoid (dense kernel already applied)
+      const float dphi = bern_s[t] ? gph[d] : gph[d] - (float)Bglob;
+      const float GA = GAs[t], Gphi = e * w * dphi;
+      dw = e * w2 * dphi;
+      ds0 = (GA - Gphi) * s1 * iT2;
+      ds1 = (Gphi - GA) * s0 * iT2;
+    }
+    if (PRIOR) {
+      double lp;
+      float gy, gs;
+      halfnormal(w, 1.f, lp, gy, gs);
+      if (bern_s[t]) lp -= kLog2;     // Bernoulli column: w ~ Normal(0,1) (bernoulli.py:201-216)
+      part[W_] += (double)lp;
+      G.p[W_][d] = dw + pw * gy;
+      const float se0 = P.p[SETA_][d], se1 = P.p[SETA_][D + d], stau = P.p[STAU_][d];
+      double lp0, lp1;
+      float gy0, gs0, gy1, gs1;
+      halfnormal(s0, se0 * stau, lp0, gy0, gs0);
+      halfnormal(s1, se1 * stau, lp1, gy1, gs1);
+      part[S_] += (double)lp0 + (double)lp1;
+      G.p[S_][d] = ds0 + pw * gy0;
+      G.p[S_][D + d] = ds1 + pw * gy1;
+      const float sa0 = P.p[SETAA_][d], sa1 = P.p[SETAA_][D + d], sta = P.p[STAUA_][d];
+      double a_lp, b_lp, c_lp;
+      float a_gy, a_ga, b_gy, b_ga, c_ga;
+      sqrt_ig(se0, sa0, a_lp, a_gy, a_ga);
+      sqrt_ig(se1, sa1, b_lp, b_gy, b_ga);
+      part[SETA_] += (double)a_lp + (double)b_lp;
+      G.p[SETA_][d] = pw * (gs0 * stau + a_gy);
+      G.p[SETA_][D + d] = pw * (gs1 * stau + b_gy);
+      ig_half(sa0, 1.f, 0.f, c_lp, c_ga);
+      part[SETAA_] += (double)c_lp;
+      G.p[SETAA_][d] = pw * (a_ga + c_ga);
+      ig_half(sa1, 1.f, 0.f, c_lp, c_ga);
+      part[SETAA_] += (double)c_lp;
+      G.p[SETAA_][D + d] = pw * (b_ga + c_ga);
+      sqrt_ig(stau, sta, a_lp, a_gy, a_ga);
+      part[STAU_] += (double)a_lp;
+      G.p[STAU_][d] = pw * (gs0 * se0 + gs1 * se1 + a_gy);
+      const float beta = 1.f / (s_tau_scale * s_tau_scale);
+      ig_half(sta, beta, 0.5f * logf(beta), c_lp, c_ga);
+      part[STAUA_] += (double)c_lp;
+      G.p[STAUA_][d] = pw * (a_ga + c_ga);
+    } else {
+      G.p[W_][d] += dw;
+      G.p[S_][d] += ds0;
+      G.p[S_][D + d] += ds1;
+    }
   }
   __syncthreads();
-  // ---- [1,K] vectors: u_tau, u_tau_a (block 0 adds their own prior) ------
-  if (t < K) {
-    float g = gutau_s[t];
-    if (blockIdx.x == 0) {
-      const float ut = P.p[UTAU_][t], uta = P.p[UTAUA_][t];
-      double lp, lp2;
-      float gy, ga, ga2;
-      sqrt_ig(ut, uta, lp, gy, ga);
-      part[UTAU_] += (double)lp;
-      g += pw * gy;
-      const float beta = 1.f / (u_tau_scale * u_tau_scale);
-      ig_half(uta, beta, 0.5f * logf(beta), lp2, ga2);
-      part[UTAUA_] += (double)lp2;
-      G.p[UTAUA_][t] = pw * (ga + ga2);
+  if (PRIOR) {
+    // ---- [1,K] vectors: u_tau, u_tau_a (block 0 adds their own prior) ------
+    if (t < K) {
+      float g = gutau_s[t];
+      if (blockIdx.x == 0) {
+        const float ut = P.p[UTAU_][t], uta = P.p[UTAUA_][t];
+        double lp, lp2;
+        float gy, ga, ga2;
+        sqrt_ig(ut, uta, lp, gy, ga);
+        part[UTAU_] += (double)lp;
+        g += pw * gy;
+        const float beta = 1.f / (u_tau_scale * u_tau_scale);
+        ig_half(uta, beta, 0.5f * logf(beta), lp2, ga2);
+        part[UTAUA_] += (double)lp2;
+        G.p[UTAUA_][t] = pw * (ga + ga2);
+      }
+      atomicAdd(&G.p[UTAU_][t], g);  // zeroed by the host before launch
     }
-    atomicAdd(&G.p[UTAU_][t], g);  // zeroed by the host before launch
-  }
-  // ---- energy parts ------------------------------------------------------
-  {
+    // ---- energy parts ------------------------------------------------------
     __shared__ double pred[12][4];
     const int wid = t >> 6, lane = t & 63;
 #pragma unroll
@@ -269,7 +305,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       if (s != 0.0) atomicAdd(&parts[t], s);
     }
   }
-  if (blockIdx.x == 0 && t == 0) {
+  if (DATA && blockIdx.x == 0 && t == 0) {
     const double llx = unpack(tail, 0), zsq = unpack(tail, 1);
     // sum of the rate over ALL cells: closed form (linear) or the dense exp sum
     double sum_r = Bglob * dprep[KP];
@@ -304,7 +340,7 @@ void launch_pack(const PackArgs& a, hipStream_t st) {
 }
 
 template <int KP>
-static void launch_finish_t(const FinishArgs& a, hipStream_t st) {
+static void launch_finish_t(const FinishArgs& a, int phase, hipStream_t st) {
   Ptrs12 P;
   MPtrs12 G;
   for (int i = 0; i < 12; ++i) {
@@ -312,18 +348,25 @@ static void launch_finish_t(const FinishArgs& a, hipStream_t st) {
     G.p[i] = a.grads[i];
   }
   const int nb = (a.D + FTD - 1) / FTD;
-  hipLaunchKernelGGL(finish_kernel<KP>, dim3(nb), dim3(256), 0, st, a.D, a.K, (double)a.B_global,
-                     a.lgamma_sum, (float)a.u_tau_scale, (float)a.s_tau_scale, a.decay, (float)a.prior_weight,
-                     a.acc, a.dprep, P, a.eta, G, a.parts, a.n_nonfinite, a.logt, a.ctype);
+#define SPMF_FIN(PH_)                                                                            \
+  hipLaunchKernelGGL((finish_kernel<KP, PH_>), dim3(nb), dim3(256), 0, st, a.D, a.K,             \
+                     (double)a.B_global, a.lgamma_sum, (float)a.u_tau_scale,                     \
+                     (float)a.s_tau_scale, a.decay, (float)a.prior_weight, a.acc, a.dprep, P,    \
+                     a.eta, G, a.parts, a.n_nonfinite, a.logt, a.ctype)
+  if (phase == 1) SPMF_FIN(1);
+  else if (phase == 2) SPMF_FIN(2);
+  else SPMF_FIN(0);
+#undef SPMF_FIN
 }
 
-void launch_finish(int KP, const FinishArgs& a, hipStream_t st) {
+// phase 0: whole finish; 1: prior half (no accumulators read); 2: data half (adds to G)
+void launch_finish(int KP, const FinishArgs& a, int phase, hipStream_t st) {
   switch (KP) {
-    case 4: launch_finish_t<4>(a, st); break;
-    case 8: launch_finish_t<8>(a, st); break;
-    case 16: launch_finish_t<16>(a, st); break;
-    case 32: launch_finish_t<32>(a, st); break;
-    case 64: launch_finish_t<64>(a, st); break;
+    case 4: launch_finish_t<4>(a, phase, st); break;
+    case 8: launch_finish_t<8>(a, phase, st); break;
+    case 16: launch_finish_t<16>(a, phase, st); break;
+    case 32: launch_finish_t<32>(a, phase, st); break;
+    case 64: launch_finish_t<64>(a, phase, st); break;
     default: break;
   }
 }

@@ -97,7 +97,7 @@ struct FinishArgs {
   int logt;
   const uint8_t* ctype;  // likelihood code 3 (mixed): column types
 };
-void launch_finish(int KP, const FinishArgs& a, hipStream_t st);
+void launch_finish(int KP, const FinishArgs& a, int phase, hipStream_t st);
 
 // ---- surrogate posterior / optimiser (surrogate.hip) ----------------------
 struct SurVar {
