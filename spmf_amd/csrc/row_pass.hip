@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
 
   float4 veta4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!encode_only && (mode != 2 || LIK == 3))
+  if (!encode_only && (mode != 2 || LIK == 3 || !gzd))
     veta4 = make_float4((float)dprep[sub * 4 + 0], (float)dprep[sub * 4 + 1],
                         (float)dprep[sub * 4 + 2], (float)dprep[sub * 4 + 3]);
   double ll_acc = 0.0, zsq_acc = 0.0, nnf_acc = 0.0;
