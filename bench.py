@@ -75,7 +75,7 @@ def cpu_baseline(sc, model, params, K, max_rows=40_000):
         SE.prior_term(one, model.u_tau_scale, model.s_tau_scale, decay)
     step()
     reps, t0 = 0, time.perf_counter()
-    while reps < 3 or (time.perf_counter() - t0 < 8.0 and reps < 50):
+    while reps < 3 or (time.perf_counter() - t0 < 12.0 and reps < 60):
         step()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
