@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--rows", type=int, default=None, help="override total rows")
     ap.add_argument("--panel-rows", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the S=20 / minibatch lines")
     args = ap.parse_args()
 
     import torch
@@ -239,6 +240,28 @@ def main():
         all_reduce_(tmax, dist.ReduceOp.MAX)
     dt = float(tmax[0])
 
+    # extras SURVEY 8(d) asks to report beside the headline (1 GPU only, not `value`):
+    # S=20 draws per step (tests/spmf_test.py:39) and a B~20000-row minibatch
+    extras = {}
+    if world == 1 and not args.no_extras and not logt and mixed_mask is None:
+        def timed(fn, n, w):
+            for _ in range(w):
+                fn()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t_) / n
+        torch.manual_seed(gen_seed)
+        p20 = model.surrogate_distribution.sample(20)
+        extras["S20_ms_per_step"] = timed(lambda: model.energy_and_grads(batch, p20), 2, 1)
+        del p20
+        npan = max(1, min(sc.n_panels, -(-20000 // sc.panel_rows)))
+        mb = {"counts": sc, "panels": (0, npan)}
+        extras["minibatch_rows"] = min(sc.n_rows, npan * sc.panel_rows)
+        extras["minibatch_ms_per_step"] = timed(lambda: model.energy_and_grads(mb, params), 50, 5)
+
     # extra (not the contract's `value`): the whole VI step -- base noise, surrogate
     # transform + log q, energy + gradient, chain to the trainables, Adam -- per step
     from spmf_amd import vi
@@ -298,6 +321,7 @@ def main():
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic},
             "vi_step_ms": vi_ms,
+            "also": extras,
             "n_nonfinite": float(nnf.sum()),
             "elbo_x": float(parts["x"][0]),
         }

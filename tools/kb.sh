@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/kb.sh [bench args]   -> prints ms/step and per-kernel ms
 mkdir -p gpurun_out
-python bench.py --no-cpu-baseline "$@" > gpurun_out/kb.json 2> gpurun_out/kb.err || { tail -20 gpurun_out/kb.err; exit 1; }
+python bench.py --no-cpu-baseline --no-extras "$@" > gpurun_out/kb.json 2> gpurun_out/kb.err || { tail -20 gpurun_out/kb.err; exit 1; }
 python -c '
 import json
 d=json.load(open("gpurun_out/kb.json"))

@@ -6,7 +6,7 @@ mkdir -p $out
 i=0
 for ctrs in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/p$i -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $out/p$i.json 2> $out/p$i.err || { tail -5 $out/p$i.err; }
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/p$i -- python3 bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 "$@" > $out/p$i.json 2> $out/p$i.err || { tail -5 $out/p$i.err; }
 done
 python3 - "$out" <<'PY'
 import csv,glob,sys,collections
