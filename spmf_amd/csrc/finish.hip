@@ -132,21 +132,41 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   // 256 % KP == 0, so a thread keeps the same k in every iteration: gut_acc
   // sums its d's in a register (LDS float atomics cost ~200 cycles each here)
   float gut_acc = 0.f;
-  for (int e = t; e < KP * FTD; e += 256) {
+  // The output pointers may alias the inputs as far as the compiler knows, so a
+  // load cannot move above an earlier store: fetch the operands of ALL iterations
+  // first, otherwise every iteration pays its own memory round trip in series.
+  constexpr int NIT = (KP * FTD + 255) / 256;
+  float in_u[NIT], in_ue[NIT], in_ua[NIT], in_ga[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = t + it * 256;
+    const int dl = e / KP, k = e % KP;
+    const int d = d0 + dl;
+    const bool on = e < KP * FTD && d < D && k < K;
+    const size_t i = on ? (size_t)d * K + k : 0;
+    in_u[it] = on ? P.p[U_][i] : 0.f;
+    in_ue[it] = (PRIOR && on) ? P.p[UETA_][i] : 1.f;
+    in_ua[it] = (PRIOR && on) ? P.p[UETAA_][i] : 1.f;
+    in_ga[it] = (DATA && on) ? gAp[(size_t)d * KP + k] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = t + it * 256;
+    if (e >= KP * FTD) break;
     const int dl = e / KP, k = e % KP;
     const int d = d0 + dl;
     float ga_u = 0.f, gut = 0.f;
     if (d < D && k < K) {
       const size_t i = (size_t)d * K + k;
-      const float u = P.p[U_][i];
+      const float u = in_u[it];
       float du = 0.f;
       if (DATA) {
-        const float dA = gAp[(size_t)d * KP + k] * ietas[dl];
+        const float dA = in_ga[it] * ietas[dl];
         ga_u = u * dA;
         du = w1s[dl] * dA;
       }
       if (PRIOR) {
-        const float ue = P.p[UETA_][i], ua = P.p[UETAA_][i];
+        const float ue = in_ue[it], ua = in_ua[it];
         const float sc = utau_s[k] * dec_s[k];
         // the three log-densities share their fp64 logs (software fp64 log is what
         // this kernel's time goes to): log sig = log ue + log(utau_k dec_k)
@@ -195,14 +215,25 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     }
   }
   __syncthreads();
-  for (int e = t; e < KP * FTD; e += 256) {
+  float in_v[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = t + it * 256;
+    const int k = e / FTD, dl = e % FTD;
+    const int d = d0 + dl;
+    in_v[it] = (PRIOR && e < KP * FTD && k < K && d < D) ? P.p[V_][(size_t)k * D + d] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = t + it * 256;
+    if (e >= KP * FTD) break;
     const int k = e / FTD, dl = e % FTD;
     const int d = d0 + dl;
     if (k < K && d < D) {
       const size_t i = (size_t)k * D + d;
       const float dv = DATA ? tile[k][dl] : 0.f;
       if (PRIOR) {
-        const float v = P.p[V_][i];
+        const float v = in_v[it];
         double lp;
         float gy, gs;
         halfnormal(v, 0.1f, lp, gy, gs);
@@ -219,12 +250,17 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     const int d = d0 + t;
     const float e = etas_[t];
     const float s0 = P.p[S_][d], s1 = P.p[S_][D + d], w = P.p[W_][d];
+    // all operands before the first store (see the [D,K] loop)
+    const float se0 = PRIOR ? P.p[SETA_][d] : 1.f, se1 = PRIOR ? P.p[SETA_][D + d] : 1.f;
+    const float stau = PRIOR ? P.p[STAU_][d] : 1.f, sta = PRIOR ? P.p[STAUA_][d] : 1.f;
+    const float sa0 = PRIOR ? P.p[SETAA_][d] : 1.f, sa1 = PRIOR ? P.p[SETAA_][D + d] : 1.f;
+    const float gph_d = DATA ? gph[d] : 0.f;
     float dw = 0.f, ds0 = 0.f, ds1 = 0.f;
     if (DATA) {
       const float T = s0 + s1, iT2 = 1.f / (T * T);
       const float w2 = s1 / T;
       // Poisson: sum_b x/r - B; Bernoulli: sum_nnz x - sum_b sigmoid (dense kernel already applied)
-      const float dphi = bern_s[t] ? gph[d] : gph[d] - (float)Bglob;
+      const float dphi = bern_s[t] ? gph_d : gph_d - (float)Bglob;
       const float GA = GAs[t], Gphi = e * w * dphi;
       dw = e * w2 * dphi;
       ds0 = (GA - Gphi) * s1 * iT2;
@@ -237,7 +273,6 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       if (bern_s[t]) lp -= kLog2;     // Bernoulli column: w ~ Normal(0,1) (bernoulli.py:201-216)
       part[W_] += (double)lp;
       G.p[W_][d] = dw + pw * gy;
-      const float se0 = P.p[SETA_][d], se1 = P.p[SETA_][D + d], stau = P.p[STAU_][d];
       double lp0, lp1;
       float gy0, gs0, gy1, gs1;
       halfnormal(s0, se0 * stau, lp0, gy0, gs0);
@@ -245,7 +280,6 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       part[S_] += (double)lp0 + (double)lp1;
       G.p[S_][d] = ds0 + pw * gy0;
       G.p[S_][D + d] = ds1 + pw * gy1;
-      const float sa0 = P.p[SETAA_][d], sa1 = P.p[SETAA_][D + d], sta = P.p[STAUA_][d];
       double a_lp, b_lp, c_lp;
       float a_gy, a_ga, b_gy, b_ga, c_ga;
       sqrt_ig(se0, sa0, a_lp, a_gy, a_ga);

@@ -141,17 +141,30 @@ class Surrogate:
     @torch.no_grad()
     def draw_noise(self, S):
         """Base noise per variable: eps ~ N(0,1) [S,*shape], or for the
-        InverseGamma kinds g ~ Gamma(softplus(t0), 1) and d g/d concentration."""
+        InverseGamma kinds g ~ Gamma(softplus(t0), 1) and d g/d concentration.
+        One randn and one gamma draw over the concatenation of all variables
+        (torch's gamma sampler costs ~30 us per call whatever the size; per
+        variable that was 0.45 ms of a 4.2 ms C3 step); each variable's [S,n]
+        block is a contiguous slice of the flat buffers."""
         out = {}
-        for n in VAR_ORDER:
-            t0, _ = self.params_of(n)
-            shape = (S,) + tuple(t0.shape)
-            if self.kinds[n] == "invgamma":
-                a = _sp(t0).expand(shape).contiguous()
-                g = torch._standard_gamma(a).clamp_min_(1e-30)
-                out[n] = (g, torch._standard_gamma_grad(a, g))
-            else:
-                out[n] = (torch.randn(shape, device=self.device, dtype=torch.float32), None)
+        nor = [n for n in VAR_ORDER if self.kinds[n] != "invgamma"]
+        gam = [n for n in VAR_ORDER if self.kinds[n] == "invgamma"]
+        if nor:
+            sizes = [S * self.params_of(n)[0].numel() for n in nor]
+            eps = torch.randn(sum(sizes), device=self.device, dtype=torch.float32)
+            for n, piece in zip(nor, eps.split(sizes)):
+                out[n] = (piece.view((S,) + tuple(self.params_of(n)[0].shape)), None)
+        if gam:
+            raws = [self.params_of(n)[0].detach().reshape(1, -1) for n in gam]
+            sizes = [S * r.numel() for r in raws]
+            raw = torch.cat([r.expand(S, -1).reshape(-1) for r in raws]) if S > 1 \
+                else torch.cat([r.reshape(-1) for r in raws])
+            a = _sp(raw)
+            g = torch._standard_gamma(a).clamp_min_(1e-30)
+            dg = torch._standard_gamma_grad(a, g)
+            for n, gp, dp in zip(gam, g.split(sizes), dg.split(sizes)):
+                shape = (S,) + tuple(self.params_of(n)[0].shape)
+                out[n] = (gp.view(shape), dp.view(shape))
         return out
 
     def _table(self, S, noise, theta=None, gtheta=None, grads=None):
