@@ -504,10 +504,20 @@ class PoissonFactorization:
         """poisson.py:711-717: rebuild, then assign surrogate variables BY
         POSITION (the ordering is part of the pickle format)."""
         self.create_distributions()
-        for j, value in enumerate(state['surrogate_vars']):
-            self.surrogate_distribution.trainable_variables[j].copy_(
-                torch.as_tensor(np.asarray(value)).to(
-                    self.surrogate_distribution.trainable_variables[j]))
+        tv = self.surrogate_distribution.trainable_variables
+        if len(state['surrogate_vars']) != len(tv):
+            raise ValueError(f"checkpoint holds {len(state['surrogate_vars'])} surrogate "
+                             f"variables, the model has {len(tv)}")
+        with torch.no_grad():
+            for j, value in enumerate(state['surrogate_vars']):
+                src = torch.as_tensor(np.asarray(value))
+                if tuple(src.shape) != tuple(tv[j].shape):
+                    raise ValueError(f"surrogate variable {j}: checkpoint shape "
+                                     f"{tuple(src.shape)}, model {tuple(tv[j].shape)}")
+                tv[j].copy_(src.to(tv[j]))
+        for k in ("eta_i", "xi_u_global"):
+            if k in state and state[k] is not None:
+                setattr(self, k, state[k])
 
     # fit / calibrate_advi / save / waic are attached in vi.py
     def fit(self, *args, **kwargs):

@@ -242,7 +242,7 @@ def test_device_gated_step_equals_host_driven_step():
     assert abs(st[10] - sum(ref_losses)) <= 1e-9 * abs(sum(ref_losses)) and st[11] == 3 and st[12] == 0
     for p, q in zip(a.surrogate_distribution.trainable_variables,
                     b.surrogate_distribution.trainable_variables):
-        assert (p - q).abs().max() <= 1e-6 * max(1.0, float(p.abs().max()))
+        assert (p.detach() - q.detach()).abs().max() <= 1e-6 * max(1.0, float(p.detach().abs().max()))
 
 
 def test_device_gate_skips_non_finite_step():
@@ -324,3 +324,35 @@ def test_fit_with_and_without_graph_agree():
     # same model, same optimiser, independent noise streams: the curves track each other
     assert abs(np.mean(a[-5:]) - np.mean(b[-5:])) < 0.05 * abs(np.mean(a[-5:]))
     assert np.mean(b[-3:]) < b[0] - 0.5
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """factor.save -> pickle -> reconstitute BY POSITION (poisson.py:711-717):
+    the restored model encodes identically."""
+    import pickle
+    from spmf_amd import PoissonFactorization
+    X = _data(300, 12)
+    m = _fresh_model(X)
+    torch.manual_seed(3)
+    m.fit(lambda: [{"counts": X}], dataset_size=X.shape[0], sample_size=2, num_steps=5,
+          learning_rate=0.05, verbose=False)
+    f = tmp_path / "model.pkl"
+    m.save(str(f))
+    state = pickle.load(open(f, "rb"))
+    assert len(state["surrogate_vars"]) == 24 and list(state["var_list"]) == list(m.var_list)
+    m2 = PoissonFactorization(latent_dim=m.latent_dim, feature_dim=m.feature_dim,
+                              u_tau_scale=m.u_tau_scale, device="cuda", panel_rows=100)
+    m2.reconstitute(state)
+    for p, q in zip(m.surrogate_distribution.trainable_variables,
+                    m2.surrogate_distribution.trainable_variables):
+        assert torch.equal(p.detach(), q.detach())
+    m2.eta_i, m2.xi_u_global = m.eta_i, m.xi_u_global
+    torch.manual_seed(9)
+    m.set_calibration_expectations()
+    torch.manual_seed(9)
+    m2.set_calibration_expectations()
+    z1, z2 = m.encode(X), m2.encode(X)
+    assert float((z1 - z2).abs().max()) <= 1e-6 * float(z1.abs().max())
+    bad = dict(state, surrogate_vars=state["surrogate_vars"][:-1])
+    with pytest.raises(ValueError):
+        m2.reconstitute(bad)
