@@ -224,6 +224,9 @@ typedef struct spmf_sur_var {
   /* optional per-element override for kind 0 (mixed likelihood): ident[i] != 0
    * means element i has the Identity bijector (kind 1). NULL otherwise. */
   const uint8_t* ident;
+  /* elements between consecutive draws in noise / dgda (they may be slices of
+   * one [S, total] buffer drawn for all variables at once); 0 means n. */
+  int64_t noise_ld;
 } spmf_sur_var;
 
 /* theta for every variable and logq[S] (fp64) = sum over variables and

@@ -54,7 +54,7 @@ class SurVar(C.Structure):
     _fields_ = [("t0", C.c_void_p), ("t1", C.c_void_p), ("noise", C.c_void_p),
                 ("dgda", C.c_void_p), ("theta", C.c_void_p), ("gtheta", C.c_void_p),
                 ("g0", C.c_void_p), ("g1", C.c_void_p), ("n", C.c_int32), ("kind", C.c_int32),
-                ("ident", C.c_void_p)]
+                ("ident", C.c_void_p), ("noise_ld", C.c_int64)]
 
 
 class AdamVar(C.Structure):

@@ -275,7 +275,7 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
   const int KP = c->KP, D = c->D;
   const size_t al_ = acc_len(D, KP);
   // zero acc | dacc | dprep (contiguous in the carve)
-  HIPCHK(c, hipMemsetAsync(c->acc, 0, (size_t)((char*)c->Ap - (char*)c->acc), st));
+  launch_zero(c->acc, (size_t)((char*)c->Ap - (char*)c->acc), st);
   if (c->timing) {
     c->ev_set = (c->ev_set + 1) % spmf_ctx::kSets;
     c->ev = c->evs[c->ev_set];
@@ -353,8 +353,8 @@ int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
   // outputs are zeroed in stream order, then the side stream forks off `stream`
-  HIPCHK(c, hipMemsetAsync(parts, 0, (size_t)S * SPMF_NPARTS * sizeof(double), st));
-  HIPCHK(c, hipMemsetAsync(grads[4], 0, (size_t)S * c->K * sizeof(float), st));
+  launch_zero(parts, (size_t)S * SPMF_NPARTS * sizeof(double), st);
+  launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
   HIPCHK(c, hipEventRecord(c->ev_fork, st));
   HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
   for (int s = 0; s < S; ++s) {
@@ -390,8 +390,8 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
   if (joined) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   } else {
-    HIPCHK(c, hipMemsetAsync(parts, 0, (size_t)S * SPMF_NPARTS * sizeof(double), st));
-    HIPCHK(c, hipMemsetAsync(grads[4], 0, (size_t)S * c->K * sizeof(float), st));
+    launch_zero(parts, (size_t)S * SPMF_NPARTS * sizeof(double), st);
+    launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
   }
   for (int s = 0; s < S; ++s) {
     const bool tm = c->timing && s == S - 1;
@@ -432,7 +432,7 @@ int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float*
   rc = bind_ws(c, ct->n_rows, 1);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(c, hipMemsetAsync(c->dprep, 0, (c->KP + 1) * sizeof(double), st));
+  launch_zero(c->dprep, (c->KP + 1) * sizeof(double), st);
   PrepArgs pa{c->D, c->K, u, nullptr, nullptr, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt, nullptr, nullptr};
   launch_prep(c->KP, pa, st);
   RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr, nullptr};
@@ -453,7 +453,7 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
   rc = bind_ws(c, ct->n_rows, 1);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(c, hipMemsetAsync(c->dprep, 0, (c->KP + 1) * sizeof(double), st));
+  launch_zero(c->dprep, (c->KP + 1) * sizeof(double), st);
   PrepArgs pa{c->D, c->K, u, v, w, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt, nullptr, nullptr};
   launch_prep(c->KP, pa, st);
   RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr, nullptr};
@@ -479,11 +479,12 @@ int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
   for (int i = 0; i < nvars; ++i) {
     const spmf_sur_var& v = vars[i];
     if (!v.t0 || !v.t1 || !v.noise || !v.theta || v.n < 1 || v.kind < 0 || v.kind > 2) return fail(c, SPMF_E_ARG, "surrogate_fwd: bad variable");
-    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident};
+    if (v.noise_ld != 0 && v.noise_ld < v.n) return fail(c, SPMF_E_ARG, "surrogate: noise_ld < n");
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident, v.noise_ld ? v.noise_ld : (int64_t)v.n};
     if (v.n > max_n) max_n = v.n;
   }
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(c, hipMemsetAsync(logq, 0, (size_t)S * sizeof(double), st));
+  launch_zero(logq, (size_t)S * sizeof(double), st);
   launch_surrogate_fwd(T, nvars, max_n, S, logq, st);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;
@@ -496,7 +497,8 @@ int spmf_surrogate_bwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
   for (int i = 0; i < nvars; ++i) {
     const spmf_sur_var& v = vars[i];
     if (!v.t0 || !v.t1 || !v.noise || !v.gtheta || !v.g0 || !v.g1 || v.n < 1 || v.kind < 0 || v.kind > 2 || (v.kind == 2 && !v.dgda)) return fail(c, SPMF_E_ARG, "surrogate_bwd: bad variable");
-    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident};
+    if (v.noise_ld != 0 && v.noise_ld < v.n) return fail(c, SPMF_E_ARG, "surrogate: noise_ld < n");
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident, v.noise_ld ? v.noise_ld : (int64_t)v.n};
     if (v.n > max_n) max_n = v.n;
   }
   launch_surrogate_bwd(T, nvars, max_n, S, (float)inv_sb, (float)cw, (hipStream_t)stream);

@@ -81,6 +81,7 @@ struct PackArgs {
   float* tail;  // acc tail: 2*(kDaccHead+KP) floats
 };
 void launch_pack(const PackArgs& a, hipStream_t st);
+void launch_zero(void* p, size_t bytes, hipStream_t st);   // zero fill as a kernel (see stats.hip)
 
 struct FinishArgs {
   int D, K;
@@ -110,6 +111,7 @@ struct SurVar {
   float *g0, *g1;       // [n] out (bwd)
   int n, kind;          // kind 0 softplus-normal, 1 identity-normal, 2 softplus-invgamma
   const uint8_t* ident; // optional per-element kind-1 override of kind 0
+  int64_t ld;           // stride between draws in noise / dgda
 };
 struct SurTable {
   SurVar v[12];

@@ -45,4 +45,21 @@ void launch_stats(const StatsArgs& a, hipStream_t st) {
                      a.colsum, a.colnnz, a.row_sum, a.row_lgamma);
 }
 
+// Zero fill as a KERNEL.  hipMemsetAsync is avoided on the step path: captured into a
+// hipGraph its memset node was observed to run out of order with the kernels of the
+// PREVIOUS graph launch on the same stream (rare, timing dependent: accumulators zeroed
+// while the preceding step's finish kernel still read them; gone with per-step syncs).
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) p[i] = 0u;
+}
+
+void launch_zero(void* p, size_t bytes, hipStream_t st) {
+  const size_t n4 = bytes / 4;          // every buffer zeroed here is float / double sized
+  if (n4 == 0) return;
+  size_t nb = (n4 + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)nb), dim3(256), 0, st, (uint32_t*)p, n4);
+}
+
 }  // namespace spmf

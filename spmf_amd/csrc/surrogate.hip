@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
   if (base >= v.n) return;   // block-uniform
   for (int s = 0; s < S; ++s) {
     double lq = 0.0;
-    const float* __restrict__ nzp = v.noise + (size_t)s * v.n;
+    const float* __restrict__ nzp = v.noise + (size_t)s * v.ld;
     float* __restrict__ thp = v.theta + (size_t)s * v.n;
 #pragma unroll
     for (int e = 0; e < kEPT; ++e) {
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void surrogate_bwd_kernel(SurTable T, int S, f
         const float a = softplusf(t0), b = softplusf(t1);
         const float lb = logf(b), dga = digammaf_(a);
         for (int s = 0; s < S; ++s) {
-          const size_t o = (size_t)s * v.n + i;
-          const float g = v.noise[o], dgda = v.dgda[o], ge = v.gtheta[o];
+          const size_t o = (size_t)s * v.n + i, on = (size_t)s * v.ld + i;
+          const float g = v.noise[on], dgda = v.dgda[on], ge = v.gtheta[o];
           const float y = b / g, sig = sigmoidf_(y);
           const float dlq_dy = -(a + 1.f) / y + b / (y * y) - (1.f - sig);
           const float dL_dy = inv_sb * (-ge * sig + c * dlq_dy);
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void surrogate_bwd_kernel(SurTable T, int S, f
         const float sg = softplusf(t1);
         const bool ident = v.kind != 0 || (v.ident && v.ident[i]);
         for (int s = 0; s < S; ++s) {
-          const size_t o = (size_t)s * v.n + i;
-          const float eps = v.noise[o], ge = v.gtheta[o];
+          const size_t o = (size_t)s * v.n + i, on = (size_t)s * v.ld + i;
+          const float eps = v.noise[on], ge = v.gtheta[o];
           const float y = t0 + sg * eps;
           float dth = 1.f, dlq_dy = 0.f;
           if (!ident) {

@@ -78,6 +78,7 @@ class Surrogate:
         identity = set(getattr(model, "_identity_vars", ()))
         # per-element Identity flags (mixed likelihood): name -> uint8 tensor
         self.ident_mask = dict(getattr(model, "_identity_mask", {}) or {})
+        staged = []
         for n in VAR_ORDER:
             kind, a, b = init[n]
             if n in identity:          # tfb.Identity(Normal): bernoulli.py:187-193,362-381
@@ -87,10 +88,28 @@ class Surrogate:
                 t0, t1 = a, softplus_inverse(b)                 # loc, raw scale
             else:
                 t0, t1 = softplus_inverse(a), softplus_inverse(b)  # raw conc, raw scale
+            staged.append((n, kind, t0, t1))
+        # the raw concentrations of all Softplus(InverseGamma) variables live in one
+        # flat buffer (each trainable is a view of it), so one softplus + one gamma
+        # draw per step covers them all without a concatenation
+        self._gam_names = [n for n, kind, _, _ in staged if kind == "invgamma"]
+        total = sum(int(np.asarray(t0).size) for n, kind, t0, _ in staged if kind == "invgamma")
+        self._gam_flat = torch.empty(total, dtype=torch.float32, device=dev)
+        off = 0
+        for n, kind, t0, t1 in staged:
             self._index[n] = len(self.trainable_variables)
-            for t in (t0, t1):
+            if kind == "invgamma":
+                src = torch.as_tensor(np.asarray(t0), dtype=torch.float32)
+                view = self._gam_flat[off:off + src.numel()].view(src.shape)
+                view.copy_(src)
+                off += src.numel()
+                view.requires_grad_(True)
+                self.trainable_variables.append(view)
+            else:
                 self.trainable_variables.append(
-                    torch.tensor(t, dtype=torch.float32, device=dev, requires_grad=True))
+                    torch.tensor(t0, dtype=torch.float32, device=dev, requires_grad=True))
+            self.trainable_variables.append(
+                torch.tensor(t1, dtype=torch.float32, device=dev, requires_grad=True))
 
     @property
     def variables(self):
@@ -142,27 +161,26 @@ class Surrogate:
     def draw_noise(self, S):
         """Base noise per variable: eps ~ N(0,1) [S,*shape], or for the
         InverseGamma kinds g ~ Gamma(softplus(t0), 1) and d g/d concentration.
-        One randn and one gamma draw over the concatenation of all variables
-        (torch's gamma sampler costs ~30 us per call whatever the size; per
-        variable that was 0.45 ms of a 4.2 ms C3 step); each variable's [S,n]
-        block is a contiguous slice of the flat buffers."""
+        One randn and one gamma draw over ALL variables (torch's gamma sampler
+        costs ~30 us per call whatever the size; per variable that was 0.45 ms of
+        a 4.2 ms C3 step): a variable's noise is a column slice of the [S, total]
+        buffer (row stride = total, passed to the kernels as noise_ld)."""
         out = {}
         nor = [n for n in VAR_ORDER if self.kinds[n] != "invgamma"]
-        gam = [n for n in VAR_ORDER if self.kinds[n] == "invgamma"]
         if nor:
-            sizes = [S * self.params_of(n)[0].numel() for n in nor]
-            eps = torch.randn(sum(sizes), device=self.device, dtype=torch.float32)
-            for n, piece in zip(nor, eps.split(sizes)):
+            sizes = [self.params_of(n)[0].numel() for n in nor]
+            eps = torch.randn(S, sum(sizes), device=self.device, dtype=torch.float32)
+            for n, piece in zip(nor, eps.split(sizes, dim=1)):
                 out[n] = (piece.view((S,) + tuple(self.params_of(n)[0].shape)), None)
-        if gam:
-            raws = [self.params_of(n)[0].detach().reshape(1, -1) for n in gam]
-            sizes = [S * r.numel() for r in raws]
-            raw = torch.cat([r.expand(S, -1).reshape(-1) for r in raws]) if S > 1 \
-                else torch.cat([r.reshape(-1) for r in raws])
-            a = _sp(raw)
+        if self._gam_names:
+            a = _sp(self._gam_flat)                       # raw concentrations share one buffer
+            if S > 1:
+                a = a.expand(S, -1).contiguous()
+            a = a.view(S, -1)
             g = torch._standard_gamma(a).clamp_min_(1e-30)
             dg = torch._standard_gamma_grad(a, g)
-            for n, gp, dp in zip(gam, g.split(sizes), dg.split(sizes)):
+            sizes = [self.params_of(n)[0].numel() for n in self._gam_names]
+            for n, gp, dp in zip(self._gam_names, g.split(sizes, dim=1), dg.split(sizes, dim=1)):
                 shape = (S,) + tuple(self.params_of(n)[0].shape)
                 out[n] = (gp.view(shape), dp.view(shape))
         return out
@@ -175,6 +193,7 @@ class Surrogate:
             v = arr[i]
             v.t0, v.t1 = t0.data_ptr(), t1.data_ptr()
             v.noise = nz.data_ptr()
+            v.noise_ld = nz.stride(0) if nz.dim() > 1 and nz.shape[0] > 1 else 0
             v.dgda = dg.data_ptr() if dg is not None else None
             v.theta = theta[n].data_ptr() if theta is not None else None
             v.gtheta = gtheta[n].data_ptr() if gtheta is not None else None
@@ -189,7 +208,8 @@ class Surrogate:
     def forward_hip(self, model, S, noise):
         """theta (dict name -> [S,*shape]) and logq [S] (float64) by the HIP kernel."""
         lib, h = _lib.load(), model._handle()
-        theta = {n: torch.empty_like(noise[n][0]) for n in VAR_ORDER}
+        theta = {n: torch.empty(noise[n][0].shape, dtype=torch.float32, device=self.device)
+                 for n in VAR_ORDER}
         logq = torch.empty(S, dtype=torch.float64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         arr = self._table(S, noise, theta=theta)
@@ -415,8 +435,18 @@ class StepRunner:
         graph = torch.cuda.CUDAGraph()
         keep = {} if self.keep_tensors else None
         torch.cuda.synchronize(self.model.device)
-        with torch.cuda.graph(graph, pool=self.pool):
-            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, keep=keep)
+        # no garbage collection while capturing: a collected cycle that owns device
+        # memory or another graph would free it inside the capture (process abort)
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(graph, pool=self.pool):
+                vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, keep=keep)
+        finally:
+            if gc_was_on:
+                gc.enable()
         if keep is not None:
             self.kept[key] = keep
         self.graphs[key] = (graph, self.model._ws.data_ptr(), cs)
@@ -469,7 +499,6 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
         opt.init_state(clip_value)
         runner = StepRunner(model, opt, dataset_size, sample_size,
                             use_graph=kwargs.get("use_graph", True))
-        model._step_runner = runner
     for ep in range(epochs):
         tot, nb = 0.0, 0
         if device_loop:

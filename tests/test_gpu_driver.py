@@ -173,7 +173,8 @@ def test_qualitative_linear_structure_outcome():
     batches = [{"counts": sc, "panels": (p, p + 1)} for p in range(sc.n_panels)]
     factor = PoissonMatrixFactorization(batches, latent_dim=P, u_tau_scale=1 / math.sqrt(D * N))
     torch.manual_seed(0)
-    losses = factor.calibrate_advi(num_steps=250, learning_rate=0.05, rel_tol=1e-9, verbose=False)
+    losses = factor.calibrate_advi(num_steps=250, learning_rate=0.05, rel_tol=1e-9, verbose=False,
+                                   max_decay_steps=1000)   # the plateau rule may fire early: do not stop on it
     assert losses[-1] < 50.0 < losses[0]
     load = factor.encoding_matrix().abs().sum(1).cpu().numpy()
     noise_cols = np.delete(np.arange(D), np.arange(0, D, 3))
@@ -238,8 +239,8 @@ def test_device_gated_step_equals_host_driven_step():
         vi_step_dev(b, ob, batch, N, 3)
         st = ob.read_state()
         assert st[9] == 1.0 and st[7] == step + 1
-        assert abs(st[8] - ref_losses[-1]) <= 1e-9 * abs(ref_losses[-1])
-    assert abs(st[10] - sum(ref_losses)) <= 1e-9 * abs(sum(ref_losses)) and st[11] == 3 and st[12] == 0
+        assert abs(st[8] - ref_losses[-1]) <= 1e-6 * abs(ref_losses[-1])   # float-atomic order differs run to run
+    assert abs(st[10] - sum(ref_losses)) <= 1e-6 * abs(sum(ref_losses)) and st[11] == 3 and st[12] == 0
     for p, q in zip(a.surrogate_distribution.trainable_variables,
                     b.surrogate_distribution.trainable_variables):
         assert (p.detach() - q.detach()).abs().max() <= 1e-6 * max(1.0, float(p.detach().abs().max()))

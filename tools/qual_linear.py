@@ -16,10 +16,10 @@ sc = SparseCounts.from_any(X, "cuda", 1000)
 batches = [{"counts": sc, "panels": (p, p + 1), "indices": np.arange(p * 1000, (p + 1) * 1000)}
            for p in range(sc.n_panels)]
 factor = PoissonMatrixFactorization(batches, latent_dim=P, u_tau_scale=1.0 / math.sqrt(D * N))
-torch.manual_seed(0)
+torch.manual_seed(int(__import__("os").environ.get("SEED", "0")))
 t0 = time.time()
 losses = factor.calibrate_advi(num_steps=int(sys.argv[1]) if len(sys.argv) > 1 else 100,
-                               learning_rate=0.05, rel_tol=1e-9, check_every=20,
+                               learning_rate=0.05, rel_tol=1e-9, check_every=int(__import__("os").environ.get("EVERY", "20")),
                                use_graph=(len(sys.argv) < 3 or sys.argv[2] != 'eager'))
 print("epochs", len(losses), "time", round(time.time() - t0, 1), "loss", losses[0], "->", losses[-1])
 A = factor.encoding_matrix().cpu().numpy()          # [D, P]
