@@ -221,3 +221,38 @@ def test_randomised_shapes_sweep():
             g = grads[k].cpu().double().numpy().reshape(gref[k].shape)
             r = gref[k].numpy()
             assert np.abs(g - r).max() <= RTOL * max(np.abs(r).max(), 1e-30), (tag, k)
+
+
+def test_c_abi_argument_errors():
+    """The C entry points validate their arguments and report through
+    spmf_last_error instead of launching on bad pointers."""
+    import ctypes as C
+    from spmf_amd import _lib
+    cfg, x, params = make_problem(20, 10, 2, 1, 1, 0.5, empty=False)
+    m = build_model(cfg)
+    lib, h = _lib.load(), m._handle()
+    # finish without a data pass for this S
+    S, P = m._pack_params(params)
+    pin = _lib.PtrArray(*[P[n].data_ptr() for n in _lib.VAR_ORDER])
+    g = {n: torch.empty_like(P[n]) for n in _lib.VAR_ORDER}
+    gout = _lib.PtrArray(*[g[n].data_ptr() for n in _lib.VAR_ORDER])
+    parts = torch.empty(S, _lib.NPARTS, dtype=torch.float64, device="cuda")
+    eta = m._eta_device()
+    rc = lib.spmf_finish(h, S, 20, 0.0, 1.0, pin, eta.data_ptr(), parts.data_ptr(), gout, None, None)
+    assert rc != 0 and b"data pass" in lib.spmf_last_error(h)
+    # surrogate: noise stride shorter than the variable
+    sur = m.surrogate_distribution if m.surrogate_distribution is not None else None
+    if sur is None:
+        m.create_distributions()
+        sur = m.surrogate_distribution
+    noise = sur.draw_noise(2)
+    theta = {n: torch.empty(noise[n][0].shape, dtype=torch.float32, device="cuda")
+             for n in _lib.VAR_ORDER}
+    arr = sur._table(2, noise, theta=theta)
+    arr[0].noise_ld = 1
+    logq = torch.empty(2, dtype=torch.float64, device="cuda")
+    rc = lib.spmf_surrogate_fwd(h, arr, len(_lib.VAR_ORDER), 2, logq.data_ptr(), None)
+    assert rc != 0 and b"noise_ld" in lib.spmf_last_error(h)
+    # null state for the device-side optimiser
+    assert lib.spmf_vi_gate(h, parts.data_ptr(), logq.data_ptr(), None, 1, 1.0, 20.0, None, None) != 0
+    torch.cuda.synchronize()
