@@ -81,3 +81,23 @@ def test_log_transform_randomised_sweep():
         for k, r in gref.items():
             g = grads[k].cpu().double().numpy().reshape(r.shape)
             assert np.abs(g - r.numpy()).max() <= 2e-5 * max(np.abs(r.numpy()).max(), 1e-30), (tag, k)
+
+
+def test_log_transform_fit_smoke():
+    """The training loop (device-gated steps, hipGraph replay from the second
+    epoch on) over the log_transform decoder: dense exp kernels inside the graph."""
+    from spmf_amd import PoissonFactorization
+    rng = np.random.default_rng(5)
+    N, D, K = 400, 40, 3
+    X = rng.poisson(rng.gamma(1.0, 1.0, size=(1, D)) * rng.gamma(2.0, 0.5, size=(N, 1))).astype(np.float64)
+    colmean = np.maximum(X.mean(0, keepdims=True), 1e-3)
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(N * D),
+                             log_transform=True, column_norms=colmean, device="cuda", panel_rows=128)
+    m.xi_u_global = float(colmean.sum())
+    torch.manual_seed(1)
+    losses = m.fit(lambda: [{"counts": X}], dataset_size=N, sample_size=4, num_steps=20,
+                   learning_rate=0.02, rel_tol=1e-9, verbose=False)
+    assert len(losses) == 20 and all(math.isfinite(v) for v in losses)
+    assert np.mean(losses[-3:]) < losses[0]
+    z = m.encode(X)
+    assert tuple(z.shape) == (N, K) and bool(torch.isfinite(z).all())
