@@ -51,7 +51,10 @@ __device__ __forceinline__ float digammaf_(float x) {
 // fp64 atomic on logq[s] -- all blocks add to the SAME address, ~13 ns each,
 // serialised at the memory side -- is paid once per 2048 elements (it was 134 us
 // of atomics for the 2.7 M trainable elements of C3 at one per 256).
-constexpr int kEPT = 8;
+#ifndef SPMF_EPT
+#define SPMF_EPT 8
+#endif
+constexpr int kEPT = SPMF_EPT;
 
 __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
                                                             double* __restrict__ logq) {
@@ -158,12 +161,54 @@ __global__ __launch_bounds__(256) void surrogate_bwd_kernel(SurTable T, int S, f
   }
 }
 
-// Adam over 256*kEPT consecutive elements per block: operands of all steps are
-// loaded before the first store (p, m, v are updated in place).
+// Adam over 256*kEPT consecutive elements per block.
+__device__ __forceinline__ float adam_elem(float& m, float& v, float p, float g, float lr, float b1,
+                                           float b2, float eps, float c1, float c2, float clip) {
+  if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  return p - lr * (m / c1) / (sqrtf(v / c2) + eps);
+}
+
 __device__ __forceinline__ void adam_block(const AdamVar& a, float lr, float b1, float b2, float eps,
                                            float c1, float c2, float clip) {
   const int base = blockIdx.x * (256 * kEPT);
   if (base >= a.n) return;
+  // 16-B lanes when the four arrays allow it (dword streams run at about half the
+  // dwordx4 rate on this part): block-uniform choice
+  const bool vec = (a.n & 3) == 0 &&
+                   (((uintptr_t)a.p | (uintptr_t)a.m | (uintptr_t)a.v | (uintptr_t)a.g) & 15) == 0;
+  if (vec) {
+    constexpr int NV = kEPT / 4;
+    float4 p[NV], m[NV], vv[NV], g[NV];
+    const int n4 = a.n >> 2, base4 = base >> 2;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const int i = base4 + e * 256 + threadIdx.x;
+      if (i < n4) {
+        p[e] = reinterpret_cast<const float4*>(a.p)[i];
+        m[e] = reinterpret_cast<const float4*>(a.m)[i];
+        vv[e] = reinterpret_cast<const float4*>(a.v)[i];
+        g[e] = reinterpret_cast<const float4*>(a.g)[i];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const int i = base4 + e * 256 + threadIdx.x;
+      if (i < n4) {
+        float4 o;
+        o.x = adam_elem(m[e].x, vv[e].x, p[e].x, g[e].x, lr, b1, b2, eps, c1, c2, clip);
+        o.y = adam_elem(m[e].y, vv[e].y, p[e].y, g[e].y, lr, b1, b2, eps, c1, c2, clip);
+        o.z = adam_elem(m[e].z, vv[e].z, p[e].z, g[e].z, lr, b1, b2, eps, c1, c2, clip);
+        o.w = adam_elem(m[e].w, vv[e].w, p[e].w, g[e].w, lr, b1, b2, eps, c1, c2, clip);
+        reinterpret_cast<float4*>(a.m)[i] = m[e];
+        reinterpret_cast<float4*>(a.v)[i] = vv[e];
+        reinterpret_cast<float4*>(a.p)[i] = o;
+      }
+    }
+    return;
+  }
+  // operands of all steps are loaded before the first store (p, m, v are updated in place)
   float p[kEPT], m[kEPT], vv[kEPT], g[kEPT];
 #pragma unroll
   for (int e = 0; e < kEPT; ++e) {
@@ -178,13 +223,10 @@ __device__ __forceinline__ void adam_block(const AdamVar& a, float lr, float b1,
   for (int e = 0; e < kEPT; ++e) {
     const int i = base + e * 256 + threadIdx.x;
     if (i < a.n) {
-      float gg = g[e];
-      if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
-      const float mn = b1 * m[e] + (1.f - b1) * gg;
-      const float vn = b2 * vv[e] + (1.f - b2) * gg * gg;
-      a.m[i] = mn;
-      a.v[i] = vn;
-      a.p[i] = p[e] - lr * (mn / c1) / (sqrtf(vn / c2) + eps);
+      const float o = adam_elem(m[e], vv[e], p[e], g[e], lr, b1, b2, eps, c1, c2, clip);
+      a.m[i] = m[e];
+      a.v[i] = vv[e];
+      a.p[i] = o;
     }
   }
 }
