@@ -93,6 +93,10 @@ def main():
     ap.add_argument("--panel-rows", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the S=20 / minibatch lines")
+    ap.add_argument("--split", action="store_true",
+                    help="multi-rank: all-reduce the lower column half while the column pass "
+                         "produces the upper one (off by default: on ONE rank it costs 56 us "
+                         "per step; needs an 8-GPU measurement to decide)")
     args = ap.parse_args()
 
     import torch
@@ -162,8 +166,11 @@ def main():
                               panel_rows=args.panel_rows, chunk_rows=per,
                               target_density=density)
     else:
+        # --split: gradient accumulators and work items in two column halves, so the
+        # all-reduce of the lower half overlaps the upper half's column pass
+        col_split = (D // 2) // 32 * 32 if (distributed and args.split) else 0
         sc = synth.linear_structure(my_rows, D, density, dev, first_chunk=c0,
-                                    panel_rows=args.panel_rows)
+                                    panel_rows=args.panel_rows, col_split=col_split)
 
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):   # the class prints like the reference
@@ -176,6 +183,8 @@ def main():
             model = PoissonFactorization(latent_dim=K, feature_dim=D,
                                          u_tau_scale=1.0 / (rows * D) ** 0.5, device=dev,
                                          panel_rows=args.panel_rows, log_transform=logt)
+    if getattr(sc, "col_split", 0):
+        model.enable_column_split(sc.col_split)
     # compute_scales (poisson.py:113-154) over all shards: one pre-pass + all-reduce
     colsum = torch.zeros(D, dtype=torch.float64, device=dev)
     colnnz = torch.zeros(D, dtype=torch.float64, device=dev)

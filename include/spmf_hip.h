@@ -100,6 +100,15 @@ typedef struct spmf_counts {
   const int32_t* items;
   int32_t max_items_per_panel;
   int32_t reserved_;
+  /* Optional column split of the work items (multi-GPU overlap): inside a panel
+   * the items are sorted by column half first (columns < col_split, then the
+   * rest), then by length; item_mid[p] is the first item of panel p's upper
+   * half (absolute item index, pointer offset like item_ptr) and
+   * max_items_half[h] sizes a launch over one half.  NULL / 0 when unused. */
+  const int32_t* item_mid;
+  int32_t col_split;
+  int32_t max_items_half[2];
+  int32_t reserved2_;
 } spmf_counts;
 
 int spmf_version(void);
@@ -157,6 +166,23 @@ int64_t spmf_acc_len(const spmf_ctx* ctx, int S); /* floats, all S draws */
 int spmf_prior_async(spmf_ctx* ctx, int S, double prior_weight,
                      const float* const params[SPMF_NVARS], const float* eta, double* parts,
                      float* const grads[SPMF_NVARS], void* stream);
+
+/* Column split of the packed accumulators (multi-GPU: all-reduce one half while
+ * the column pass still produces the other).  With Dh set (a multiple of 32 in
+ * (0, D); 0 or D = none; linear Poisson decoder only) the accumulators of a
+ * draw are laid out [cols < Dh: gA'|gV'|gphi][cols >= Dh: gA'|gV'|gphi][tail];
+ * spmf_acc_split returns the two contiguous element ranges (the second one
+ * includes the fp64 tail) relative to spmf_acc_ptr.  spmf_data_pass_split runs
+ * part 0 (everything up to and including the lower half's column pass) or
+ * part 1 (upper half + pack) of one draw's data pass; the counts must carry
+ * item_mid for the same split.  Order per step:
+ *   data_pass_split(0) -> all-reduce range 0 (async) -> data_pass_split(1)
+ *   -> all-reduce range 1 -> spmf_finish. */
+int spmf_ctx_set_column_split(spmf_ctx* ctx, int Dh);
+int spmf_acc_split(const spmf_ctx* ctx, int64_t off[2], int64_t len[2]);
+int spmf_data_pass_split(spmf_ctx* ctx, const spmf_counts* counts, int S,
+                         const float* const params[SPMF_NVARS], const float* eta, int part,
+                         void* stream);
 
 /* Phase 2: chain the accumulators to d/d(u,v,w,s), add the horseshoe-plus
  * prior (poisson.py:228-377) parts and gradients for all 12 variables, and

@@ -43,6 +43,8 @@ class CountsStruct(C.Structure):
         ("gval", C.c_void_p), ("pc_gval", C.c_void_p),
         ("item_ptr", C.c_void_p), ("items", C.c_void_p),
         ("max_items_per_panel", C.c_int32), ("reserved_", C.c_int32),
+        ("item_mid", C.c_void_p), ("col_split", C.c_int32),
+        ("max_items_half", C.c_int32 * 2), ("reserved2_", C.c_int32),
     ]
 
 
@@ -93,6 +95,10 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "spmf_surrogate_bwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_void_p]),
+    "spmf_ctx_set_column_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "spmf_acc_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "spmf_data_pass_split": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int, PtrArray,
+                                       C.c_void_p, C.c_int, C.c_void_p]),
     "spmf_prior_async": (C.c_int, [C.c_void_p, C.c_int, C.c_double, PtrArray, C.c_void_p, C.c_void_p,
                                    PtrArray, C.c_void_p]),
     "spmf_vi_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,

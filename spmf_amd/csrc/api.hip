@@ -41,6 +41,7 @@ struct spmf_ctx {
   // prior half of the finish on a side stream (spmf_prior_async)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int Dh = 0;                     // column split of the accumulator layout (0 = none)
   int prior_pending = 0;          // S of the launched prior half, 0 = none
   const double* prior_parts = nullptr;
   std::string err;
@@ -258,7 +259,9 @@ int spmf_counts_stats(spmf_ctx* c, int64_t n_rows, const int32_t* row_ptr, const
   return SPMF_OK;
 }
 
-int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, void* stream) {
+// parts: bit 0 = zero, prep, row pass and the column pass of the lower column half (all columns
+// without a split); bit 1 = column pass of the upper half and the fp64 pack
+static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, int parts_mask, void* stream) {
   if (!c || !params || !eta || S < 1) return fail(c, SPMF_E_ARG, "data_pass: bad arguments");
   // likelihood / decoder code of the kernels: 0 Poisson linear, 1 Poisson log_transform, 2 Bernoulli
   const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : ((c->flags & SPMF_FLAG_MIXED) ? 3 : 0));
@@ -274,9 +277,16 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
   hipStream_t st = (hipStream_t)stream;
   const int KP = c->KP, D = c->D;
   const size_t al_ = acc_len(D, KP);
+  const bool split = c->Dh > 0;
+  const AccLayout L{D, KP, split ? c->Dh : D};
+  if (split && ct->n_rows > 0 && ct->nnz > 0 && (!ct->item_mid || ct->col_split != c->Dh))
+    return fail(c, SPMF_E_ARG, "counts: work items are not sorted for this context's column split");
+  if (!split && parts_mask != 3) return fail(c, SPMF_E_ARG, "data_pass_split needs spmf_ctx_set_column_split");
+  if (parts_mask != 3 && S != 1) return fail(c, SPMF_E_UNSUPPORTED, "data_pass_split: one draw per step only");
+  const bool first = parts_mask & 1, second = parts_mask & 2;
   // zero acc | dacc | dprep (contiguous in the carve)
-  launch_zero(c->acc, (size_t)((char*)c->Ap - (char*)c->acc), st);
-  if (c->timing) {
+  if (first) launch_zero(c->acc, (size_t)((char*)c->Ap - (char*)c->acc), st);
+  if (c->timing && first) {
     c->ev_set = (c->ev_set + 1) % spmf_ctx::kSets;
     c->ev = c->evs[c->ev_set];
     c->ev_valid = 0;
@@ -286,12 +296,13 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
     float* acc = c->acc + (size_t)s * al_;
     double* dacc = c->dacc + (size_t)s * kDaccRep * (kDaccHead + KP);
     double* dprep = c->dprep + (size_t)s * (KP + 1);
+    float* gVp = acc + L.gV_off(0);
+    if (first) {
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
     PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt == 1 ? 1 : 0, logt == 3 ? c->ctype : nullptr, logt == 3 ? c->dbias : nullptr};
     launch_prep(KP, pa, st);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
     const float* rscale = (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr;
-    float* gVp = acc + (size_t)D * KP;
     if (ct->n_rows > 0 && !logt) {
       RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 0, 0, nullptr, nullptr};
       launch_row_pass(KP, ra, st);
@@ -303,7 +314,7 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
       if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
       const int act = logt >= 2 ? 1 : 0;
       const float* lbias = logt == 3 ? c->dbias : c->phi;   // mixed: -1e30 masks the Poisson columns
-      float* gphi_acc = acc + (size_t)2 * D * KP;
+      float* gphi_acc = acc + L.gphi_off(0);
       // Z-stationary: Q rows are columns d -> bias_q = phi (Bernoulli logits)
       ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0, act, nullptr, act ? lbias : nullptr, nullptr};
       launch_expdot(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E (or sum softplus)
@@ -323,18 +334,57 @@ int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const
       launch_row_pass(KP, r2, st);
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    }   // first
     if (ct->n_rows > 0 && ct->nnz > 0) {
-      ColArgs ca{D, ct->n_panels, ct->row_base, ct->max_items_per_panel, ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc, gVp, acc + (size_t)2 * D * KP, logt, ct->pc_gval, c->ctype};
-      launch_col_pass(KP, ca, st);
+      for (int hf = 0; hf < 2; ++hf) {
+        if (!(hf == 0 ? first : second)) continue;
+        if (!split && hf == 1) continue;
+        ColArgs ca{D, ct->n_panels, ct->row_base, split ? ct->max_items_half[hf] : ct->max_items_per_panel, ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc + L.gA_off(hf), acc + L.gV_off(hf), acc + L.gphi_off(hf), logt, ct->pc_gval, c->ctype, split ? ct->item_mid : nullptr, split ? hf + 1 : 0};
+        launch_col_pass(KP, ca, st);
+      }
     }
-    PackArgs pk{KP, dacc, acc + (size_t)2 * D * KP + D};
-    launch_pack(pk, st);
-    if (tm) {
-      HIPCHK(c, hipEventRecord(c->ev[3], st));
-      c->ev_valid = 1;
+    if (second) {
+      PackArgs pk{KP, dacc, acc + L.tail_off()};
+      launch_pack(pk, st);
+      if (tm) {
+        HIPCHK(c, hipEventRecord(c->ev[3], st));
+        c->ev_valid = 1;
+      }
     }
   }
   HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, void* stream) {
+  return data_pass_impl(c, ct, S, params, eta, 3, stream);
+}
+
+int spmf_data_pass_split(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, int part, void* stream) {
+  if (part != 0 && part != 1) return fail(c, SPMF_E_ARG, "data_pass_split: part must be 0 or 1");
+  return data_pass_impl(c, ct, S, params, eta, part == 0 ? 1 : 2, stream);
+}
+
+int spmf_ctx_set_column_split(spmf_ctx* c, int Dh) {
+  if (!c) return SPMF_E_ARG;
+  if (Dh == 0 || Dh == c->D) {
+    c->Dh = 0;
+    return SPMF_OK;
+  }
+  if (Dh < 0 || Dh > c->D || (Dh % 32) != 0) return fail(c, SPMF_E_ARG, "column split must be a multiple of 32 inside (0, D)");
+  if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED))
+    return fail(c, SPMF_E_UNSUPPORTED, "column split: linear Poisson decoder only");
+  c->Dh = Dh;
+  return SPMF_OK;
+}
+
+int spmf_acc_split(const spmf_ctx* c, int64_t off[2], int64_t len[2]) {
+  if (!c || !off || !len) return SPMF_E_ARG;
+  const AccLayout L{c->D, c->KP, c->Dh > 0 ? c->Dh : c->D};
+  off[0] = 0;
+  len[0] = L.half_len(0);
+  off[1] = len[0];
+  len[1] = acc_len(c->D, c->KP) - len[0];
   return SPMF_OK;
 }
 
@@ -364,7 +414,7 @@ int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const
       P[i] = params[i] + s * var_size(c, i);
       G[i] = grads[i] + s * var_size(c, i);
     }
-    FinishArgs fa{c->D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, nullptr, nullptr, P, eta, G, parts + (size_t)s * SPMF_NPARTS, nullptr, likelihood_code(c), c->ctype};
+    FinishArgs fa{c->D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, nullptr, nullptr, P, eta, G, parts + (size_t)s * SPMF_NPARTS, nullptr, likelihood_code(c), c->ctype, c->Dh};
     launch_finish(c->KP, fa, 1, c->side);
   }
   HIPCHK(c, hipEventRecord(c->ev_join, c->side));
@@ -401,7 +451,7 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
       P[i] = params[i] + s * var_size(c, i);
       G[i] = grads[i] + s * var_size(c, i);
     }
-    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, likelihood_code(c), c->ctype};
+    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, likelihood_code(c), c->ctype, c->Dh};
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
     launch_finish(KP, fa, joined ? 2 : 0, st);
     if (tm) {

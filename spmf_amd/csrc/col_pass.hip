@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     const float* __restrict__ pc_gval, const float* __restrict__ Vp,
     const float* __restrict__ phi, const float* __restrict__ z, const float* __restrict__ gzs,
     float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi,
-    const uint8_t* __restrict__ ctype) {
+    const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel) {
   constexpr int LPN = KP / 4;
   constexpr int NG = 64 / LPN;                        // items per wave
   constexpr int GRP = LPN < COL_GRP ? LPN : COL_GRP;  // entries gathered back to back
@@ -83,10 +83,14 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     ib = (int)(q % blocks_per_panel);
   }
   if (p >= n_panels) return;                          // block-uniform
-  const int i0 = item_ptr[p] + ib * 4 * NG;
-  if (i0 >= item_ptr[p + 1]) return;                  // block-uniform
+  // item range of this launch: the whole panel, or one column half of it (the host
+  // sorts a panel's items by half first: multi-GPU overlap of the all-reduce)
+  const int ilo = half_sel == 2 ? item_mid[p] : item_ptr[p];
+  const int ihi = half_sel == 1 ? item_mid[p] : item_ptr[p + 1];
+  const int i0 = ilo + ib * 4 * NG;
+  if (i0 >= ihi) return;                              // block-uniform
   const int it = i0 + wid * NG + grp;
-  const bool ok = it < item_ptr[p + 1];
+  const bool ok = it < ihi;
   int cur = 0, end = 0, d = 0;
   if (ok) {
     const int4 im = items[it];
@@ -187,7 +191,8 @@ static void launch_col_t(const ColArgs& a, hipStream_t st) {
 #define SPMF_COL_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((col_pass_kernel<KP, L_>), dim3((unsigned)nb), dim3(256), 0, st, a.D,     \
                      a.n_panels, a.row_base, bpp, a.item_ptr, items, a.pc_row, a.pc_val,       \
-                     a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi, a.ctype)
+                     a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi, a.ctype,          \
+                     a.item_mid, a.half_sel)
   if (a.logt == 3) SPMF_COL_LAUNCH(3);
   else if (a.logt == 2) SPMF_COL_LAUNCH(2);
   else if (a.logt == 1) SPMF_COL_LAUNCH(1);

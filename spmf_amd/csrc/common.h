@@ -22,6 +22,26 @@ constexpr int kDaccRep = 16;
 
 // fp32 accumulator tail: the fp64 scalars as (hi,lo) float pairs.
 __host__ __device__ inline int acc_tail_len(int KP) { return 2 * (kDaccHead + KP); }
+// Packed accumulators of one draw: [H0: gA' | gV' | gphi][H1: gA' | gV' | gphi][tail],
+// H0 = columns [0, Dh), H1 = [Dh, D).  Dh = D (no column split) is the plain
+// [gA' | gV' | gphi | tail].  With a split the two halves are contiguous ranges, so
+// the multi-GPU step can all-reduce H0 while the column pass still produces H1.
+struct AccLayout {
+  int D, KP, Dh;
+  __host__ __device__ int64_t half_len(int h) const {
+    return (int64_t)(h ? D - Dh : Dh) * (2 * KP + 1);
+  }
+  // base pointers such that base[(size_t)d * KP + k] (or base[d] for gphi) addresses
+  // column d of half h directly
+  __host__ __device__ int64_t gA_off(int h) const { return h ? half_len(0) - (int64_t)Dh * KP : 0; }
+  __host__ __device__ int64_t gV_off(int h) const {
+    return h ? half_len(0) + (int64_t)(D - Dh) * KP - (int64_t)Dh * KP : (int64_t)Dh * KP;
+  }
+  __host__ __device__ int64_t gphi_off(int h) const {
+    return h ? half_len(0) + (int64_t)2 * (D - Dh) * KP - Dh : (int64_t)2 * Dh * KP;
+  }
+  __host__ __device__ int64_t tail_off() const { return (int64_t)2 * D * KP + D; }
+};
 __host__ __device__ inline int64_t acc_len(int D, int KP) {
   return (int64_t)2 * D * KP + D + acc_tail_len(KP);
 }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
                                                      const float* __restrict__ eta, MPtrs12 G,
                                                      double* __restrict__ parts,
                                                      double* __restrict__ nnf_out, int logt,
-                                                     const uint8_t* __restrict__ ctype) {
+                                                     const uint8_t* __restrict__ ctype, int Dh) {
   constexpr bool PRIOR = PHASE != 2, DATA = PHASE != 1;
   __shared__ float tile[KP][FTD + 1];
   __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
@@ -93,10 +93,14 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   __shared__ int bern_s[FTD];
   const int t = threadIdx.x;
   const int d0 = blockIdx.x * FTD;
-  const float* gAp = acc;
-  const float* gVp = acc + (size_t)D * KP;
-  const float* gph = acc + (size_t)2 * D * KP;
-  const float* tail = gph + D;
+  // column-split layout (common.h AccLayout): Dh is a multiple of FTD, so a block's
+  // columns lie in one half and the choice of base pointers is block-uniform
+  const AccLayout L{D, KP, Dh};
+  const int hf = d0 >= Dh ? 1 : 0;
+  const float* gAp = acc + L.gA_off(hf);
+  const float* gVp = acc + L.gV_off(hf);
+  const float* gph = acc + L.gphi_off(hf);
+  const float* tail = acc + L.tail_off();
   double part[SPMF_NPARTS_LOCAL];
 #pragma unroll
   for (int i = 0; i < SPMF_NPARTS_LOCAL; ++i) part[i] = 0.0;
@@ -386,7 +390,7 @@ static void launch_finish_t(const FinishArgs& a, int phase, hipStream_t st) {
   hipLaunchKernelGGL((finish_kernel<KP, PH_>), dim3(nb), dim3(256), 0, st, a.D, a.K,             \
                      (double)a.B_global, a.lgamma_sum, (float)a.u_tau_scale,                     \
                      (float)a.s_tau_scale, a.decay, (float)a.prior_weight, a.acc, a.dprep, P,    \
-                     a.eta, G, a.parts, a.n_nonfinite, a.logt, a.ctype)
+                     a.eta, G, a.parts, a.n_nonfinite, a.logt, a.ctype, a.Dh > 0 ? a.Dh : a.D)
   if (phase == 1) SPMF_FIN(1);
   else if (phase == 2) SPMF_FIN(2);
   else SPMF_FIN(0);

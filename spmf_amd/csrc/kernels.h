@@ -45,6 +45,8 @@ struct ColArgs {
   int logt;
   const float* pc_gval;     // log_transform: g(x) per panel-CSC entry
   const uint8_t* ctype;     // likelihood code 3 (mixed): column types
+  const int32_t* item_mid;  // [n_panels] first item of the upper column half, or null
+  int half_sel;             // 0 all items; 1 / 2: lower / upper column half only (needs item_mid)
 };
 
 struct ExpdotArgs {
@@ -97,6 +99,7 @@ struct FinishArgs {
   double* n_nonfinite;  // [1] or null
   int logt;
   const uint8_t* ctype;  // likelihood code 3 (mixed): column types
+  int Dh;                // column split of the accumulator layout (0 / D = none; multiple of 32)
 };
 void launch_finish(int KP, const FinishArgs& a, int phase, hipStream_t st);
 

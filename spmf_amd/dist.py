@@ -59,6 +59,33 @@ class ShardReducer:
         else:
             dist.all_reduce(t, group=self.group)
 
+    # ---- column-split step (PoissonFactorization.energy_and_grads) -----------
+    def start(self, piece):
+        """Begin the sum all-reduce of one contiguous accumulator range; returns a
+        handle for wait().  With RCCL the collective runs on the process group's
+        stream, ordered after what is already queued on the current stream, so the
+        kernels launched next (the upper half's column pass) overlap it."""
+        if not self.active:
+            return None
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_reduce(piece, group=self.group, async_op=True)
+        self._sum(piece)                      # rehearsal transport: synchronous
+        return None
+
+    def wait(self, work):
+        if work is not None:
+            work.wait()                       # the current stream waits, not the host
+
+    def totals(self, rows, lgamma_sum):
+        """Global (rows, lgamma) of the batch, as __call__ returns them."""
+        if self.rows_global is None:
+            tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64,
+                               device=torch.device("cuda", torch.cuda.current_device()))
+            if self.active:
+                self._sum(tot)
+            return int(round(float(tot[0]))), float(tot[1])
+        return self.rows_global, self.lgamma_global
+
     def __call__(self, acc, rows, lgamma_sum):
         """all_reduce hook of PoissonFactorization.energy_and_grads."""
         if self.active:

@@ -122,7 +122,27 @@ class PoissonFactorization:
             _lib.check(h, lib.spmf_ctx_set_prior(
                 h, float(self.u_tau_scale), float(self.s_tau_scale),
                 float(self.symmetry_breaking_decay)), "spmf_ctx_set_prior")
+            if getattr(self, "column_split", 0):
+                _lib.check(h, lib.spmf_ctx_set_column_split(h, int(self.column_split)),
+                           "spmf_ctx_set_column_split")
         return self._ctx
+
+    def enable_column_split(self, Dh=None):
+        """Multi-GPU overlap (include/spmf_hip.h, spmf_ctx_set_column_split): lay
+        the gradient accumulators out as two column halves so the all-reduce of
+        the lower half runs while the column pass still produces the upper one.
+        The batches must be built with the same split
+        (``SparseCounts(..., col_split=model.column_split)``).  Returns Dh."""
+        D = int(self.feature_dim)
+        if Dh is None:
+            Dh = (D // 2) // 32 * 32
+        if Dh <= 0 or Dh >= D or Dh % 32:
+            raise ValueError(f"column split {Dh} must be a multiple of 32 inside (0, {D})")
+        self.column_split = int(Dh)
+        if self._ctx is not None:
+            _lib.check(self._ctx, _lib.load().spmf_ctx_set_column_split(self._ctx, int(Dh)),
+                       "spmf_ctx_set_column_split")
+        return self.column_split
 
     def __del__(self):
         try:
@@ -175,7 +195,8 @@ class PoissonFactorization:
             if hit is not None and hit[0] is x:
                 sc = hit[1]
             else:
-                sc = SparseCounts.from_any(x, self.device, self.panel_rows)
+                sc = SparseCounts.from_any(x, self.device, self.panel_rows,
+                                             getattr(self, "column_split", 0))
                 # device layouts of the most recent batches (an epoch loop over a
                 # fixed list of host batches re-uses them; bounded by stored entries)
                 self._batch_cache[ck] = (x, sc)
@@ -257,10 +278,33 @@ class PoissonFactorization:
         gout = _lib.PtrArray(*[grads[n].data_ptr() for n in VAR_ORDER])
         parts = torch.empty(S, _lib.NPARTS, dtype=torch.float64, device=self.device)
         nnf = torch.empty(S, dtype=torch.float64, device=self.device)
-        _lib.check(h, lib.spmf_data_pass(h, C.byref(cs), S, pin, eta.data_ptr(), stream),
-                   "spmf_data_pass")
         rows_g, lg_g = cs.n_rows, cs.lgamma_sum
-        if all_reduce is not None:
+        split = (all_reduce is not None and S == 1 and getattr(self, "column_split", 0) > 0
+                 and sc.col_split == self.column_split and hasattr(all_reduce, "start"))
+        if split:
+            # column-split step: the all-reduce of the lower column half runs while the
+            # column pass produces the upper half
+            off = (C.c_int64 * 2)()
+            ln = (C.c_int64 * 2)()
+            _lib.check(h, lib.spmf_acc_split(h, off, ln), "spmf_acc_split")
+            _lib.check(h, lib.spmf_data_pass_split(h, C.byref(cs), S, pin, eta.data_ptr(), 0, stream),
+                       "spmf_data_pass_split")
+            acc = _wrap_f32(lib.spmf_acc_ptr(h), off[1] + ln[1], self.device, self._ws)
+            w0 = all_reduce.start(acc[off[0]:off[0] + ln[0]])
+            _lib.check(h, lib.spmf_data_pass_split(h, C.byref(cs), S, pin, eta.data_ptr(), 1, stream),
+                       "spmf_data_pass_split")
+            _lib.check(h, lib.spmf_prior_async(h, S, float(prior_weight), pin, eta.data_ptr(),
+                                               parts.data_ptr(), gout, stream), "spmf_prior_async")
+            w1 = all_reduce.start(acc[off[1]:off[1] + ln[1]])
+            all_reduce.wait(w0)
+            all_reduce.wait(w1)
+            r = all_reduce.totals(cs.n_rows, cs.lgamma_sum)
+            if r is not None:
+                rows_g, lg_g = r
+        else:
+            _lib.check(h, lib.spmf_data_pass(h, C.byref(cs), S, pin, eta.data_ptr(), stream),
+                       "spmf_data_pass")
+        if all_reduce is not None and not split:
             # the prior half of the finish reads no accumulator: it runs on the
             # library's side stream while the collective has the GPU mostly idle
             # (beside the sparse passes it costs them more than it hides: measured)

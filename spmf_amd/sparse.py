@@ -46,7 +46,7 @@ class SparseCounts:
     """One row shard of the count matrix in the layout the kernels read."""
 
     def __init__(self, row_ptr, col_idx, val, n_rows, n_cols,
-                 panel_rows=DEFAULT_PANEL_ROWS):
+                 panel_rows=DEFAULT_PANEL_ROWS, col_split=0):
         dev = val.device
         self.device = dev
         self.n_rows = int(n_rows)
@@ -59,6 +59,9 @@ class SparseCounts:
             raise ValueError("nnz per shard must fit int32")
         self.panel_rows = int(max(1, min(panel_rows, max(self.n_rows, 1))))
         self.n_panels = max(1, -(-self.n_rows // self.panel_rows))
+        # multi-GPU overlap: work items of a panel sorted by column half first
+        # (columns < col_split, then the rest); 0 = no split
+        self.col_split = int(col_split)
         self._build_panel_csc()
         self.row_sum = None
         self.row_lgamma = None
@@ -71,7 +74,7 @@ class SparseCounts:
 
     # ---- construction ----------------------------------------------------
     @classmethod
-    def from_any(cls, x, device=None, panel_rows=DEFAULT_PANEL_ROWS):
+    def from_any(cls, x, device=None, panel_rows=DEFAULT_PANEL_ROWS, col_split=0):
         if isinstance(x, SparseCounts):
             return x
         device = torch.device(device if device is not None else
@@ -82,11 +85,11 @@ class SparseCounts:
             return cls(torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(device),
                        torch.as_tensor(np.asarray(indices, dtype=np.int64)).to(device),
                        torch.as_tensor(np.asarray(data, dtype=np.float32)).to(device),
-                       shape[0], shape[1], panel_rows)
-        return cls.from_dense(x, device, panel_rows)
+                       shape[0], shape[1], panel_rows, col_split)
+        return cls.from_dense(x, device, panel_rows, col_split)
 
     @classmethod
-    def from_dense(cls, x, device=None, panel_rows=DEFAULT_PANEL_ROWS):
+    def from_dense(cls, x, device=None, panel_rows=DEFAULT_PANEL_ROWS, col_split=0):
         device = torch.device(device if device is not None else
                               ("cuda" if torch.cuda.is_available() else "cpu"))
         if hasattr(x, "numpy") and not isinstance(x, torch.Tensor):
@@ -103,7 +106,7 @@ class SparseCounts:
         nz = mask.nonzero(as_tuple=False)      # row-major order
         col = nz[:, 1]
         val = t[mask].to(torch.float32)
-        return cls(row_ptr, col, val, N, D, panel_rows)
+        return cls(row_ptr, col, val, N, D, panel_rows, col_split)
 
     def _build_panel_csc(self):
         dev, N, D, P = self.device, self.n_rows, self.n_cols, self.panel_rows
@@ -150,8 +153,9 @@ class SparseCounts:
         length = torch.minimum(cnt[lid] - k * seg, torch.full_like(k, seg))
         panel = lid // D
         col = lid % D
-        # sort by (panel asc, length desc); ties keep (column, segment) order
-        key = panel * (seg + 1) + (seg - length)
+        # sort by (panel asc, [column half asc,] length desc); ties keep (column, segment) order
+        half = (col >= self.col_split).to(torch.int64) if self.col_split > 0 else torch.zeros_like(col)
+        key = (panel * 2 + half) * (seg + 1) + (seg - length)
         order = torch.sort(key, stable=True).indices
         items = torch.stack([start[order], length[order], col[order],
                              torch.zeros_like(col[order])], 1)
@@ -161,6 +165,9 @@ class SparseCounts:
         ip[1:] = torch.cumsum(per_panel, 0)
         self.item_ptr = ip.to(torch.int32).contiguous()
         self.items_per_panel = per_panel
+        lower = torch.bincount(panel[half == 0], minlength=nP)
+        self.item_mid = (ip[:-1] + lower).to(torch.int32).contiguous()
+        self.items_per_half = torch.stack([lower, per_panel - lower], 0)
 
     # ---- statistics (HIP pre-pass) ---------------------------------------
     def compute_stats(self, ctx_handle, colsum=None, colnnz=None):
@@ -243,6 +250,12 @@ class SparseCounts:
         cs.items = self.items.data_ptr()
         cs.max_items_per_panel = (int(self.items_per_panel[p0:p1].max())
                                   if self.items.numel() else 0)
+        if self.col_split > 0:
+            cs.item_mid = self.item_mid.data_ptr() + 4 * p0
+            cs.col_split = self.col_split
+            for h in range(2):
+                cs.max_items_half[h] = (int(self.items_per_half[h, p0:p1].max())
+                                        if self.items.numel() else 0)
         cs.gval = self.gval.data_ptr() if self.gval is not None else None
         cs.pc_gval = self.pc_gval.data_ptr() if self.pc_gval is not None else None
         return cs

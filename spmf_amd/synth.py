@@ -47,7 +47,7 @@ def linear_structure_chunk(chunk_id, rows, D, density, device, seed=20241218 + 3
 
 
 def linear_structure(rows, D, density, device, first_chunk=0, panel_rows=8192,
-                     chunk_rows=CHUNK_ROWS):
+                     chunk_rows=CHUNK_ROWS, col_split=0):
     """SparseCounts of `rows` rows starting at global chunk `first_chunk`."""
     cnts, cols, vals = [], [], []
     done, cid = 0, first_chunk
@@ -60,7 +60,8 @@ def linear_structure(rows, D, density, device, first_chunk=0, panel_rows=8192,
     cnt = torch.cat(cnts)
     row_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
     row_ptr[1:] = torch.cumsum(cnt, 0)
-    return SparseCounts(row_ptr, torch.cat(cols), torch.cat(vals), rows, D, panel_rows)
+    return SparseCounts(row_ptr, torch.cat(cols), torch.cat(vals), rows, D, panel_rows,
+                        col_split=col_split)
 
 
 def bernoulli_poisson(rows, D, density, device, seed, mean=2.0, panel_rows=8192):

@@ -256,3 +256,56 @@ def test_c_abi_argument_errors():
     # null state for the device-side optimiser
     assert lib.spmf_vi_gate(h, parts.data_ptr(), logq.data_ptr(), None, 1, 1.0, 20.0, None, None) != 0
     torch.cuda.synchronize()
+
+
+class _TwoShardSplitReducer:
+    """Stand-in for dist.ShardReducer in the column-split flow: shard 0 records
+    its two accumulator ranges, shard 1 adds them (a 2-rank all-reduce by hand)."""
+
+    def __init__(self, store, first):
+        self.store, self.first, self.k = store, first, 0
+
+    def start(self, piece):
+        if self.first:
+            self.store.setdefault("pieces", []).append(piece.clone())
+        else:
+            piece += self.store["pieces"][self.k]
+        self.k += 1
+        return None
+
+    def wait(self, work):
+        pass
+
+    def totals(self, rows, lg):
+        if self.first:
+            self.store["rows"], self.store["lg"] = rows, lg
+            return None
+        return rows + self.store["rows"], lg + self.store["lg"]
+
+    def __call__(self, acc, rows, lg):          # unsplit fallback must not be taken here
+        raise AssertionError("column-split flow expected")
+
+
+@pytest.mark.parametrize("K", [4, 32])
+def test_column_split_step_equals_unsplit(K):
+    """spmf_ctx_set_column_split + spmf_data_pass_split: two row shards, each
+    all-reducing its accumulators in two column-half ranges == the oracle on the
+    whole batch; and the split layout with the plain hook-less call is unchanged."""
+    cfg, x, params = make_problem(128, 100, K, 1, 35, 0.2, empty=False)
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    store = {}
+    m0, m1 = build_model(cfg, 32), build_model(cfg, 32)
+    for m in (m0, m1):
+        assert m.enable_column_split(64) == 64
+    m0.energy_and_grads({"counts": x[:64]}, params, all_reduce=_TwoShardSplitReducer(store, True))
+    assert len(store["pieces"]) == 2
+    parts, grads, _ = m1.energy_and_grads({"counts": x[64:]}, params,
+                                          all_reduce=_TwoShardSplitReducer(store, False))
+    assert_close_parts(parts, pref)
+    assert_close_grads(grads, gref)
+    # same model, no reducer: the split layout serves the single-device call too
+    parts1, grads1, _ = m1.energy_and_grads({"counts": x}, params)
+    assert_close_parts(parts1, pref)
+    assert_close_grads(grads1, gref)
+    with pytest.raises(ValueError):
+        m1.enable_column_split(50)

@@ -54,8 +54,11 @@ def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
 
 def test_counts_struct_layout_matches_header():
     from spmf_amd._lib import CountsStruct
-    # 2*int64 + 4*int32 + 7 pointers + double + 2 pointers
-    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8 + 16 + 16 + 8
+    # 2*int64 + 4*int32 + 7 pointers + double + 2 pointers + (2 pointers, 2 int32)
+    # + column split: pointer + 4 int32
+    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8 + 16 + 16 + 8 + 8 + 16
+    assert CountsStruct.item_mid.offset == 136 and CountsStruct.col_split.offset == 144
+    assert CountsStruct.max_items_half.offset == 148
     assert CountsStruct.gval.offset == 96
     assert CountsStruct.max_items_per_panel.offset == 128
     assert CountsStruct.row_ptr.offset == 32
@@ -139,3 +142,25 @@ def test_column_pass_work_items_cover_every_entry_once(seg, monkeypatch):
             seen[start:start + ln] += 1
     assert np.all(seen == 1)
     assert not np.any(items[:, 2] == 4)               # empty column has no item
+
+
+def test_work_items_sorted_by_column_half():
+    """col_split: a panel's items come lower half first (item_mid marks the
+    boundary), each half sorted by length; every entry still covered once."""
+    import spmf_amd.sparse as S
+    rng = np.random.default_rng(4)
+    x = ((rng.random((90, 70)) < 0.3) * (1 + rng.poisson(2.0, size=(90, 70)))).astype(np.float32)
+    sc = S.SparseCounts.from_dense(x, "cpu", 32, col_split=32)
+    items, ip, mid = sc.items.numpy(), sc.item_ptr.numpy(), sc.item_mid.numpy()
+    assert len(mid) == sc.n_panels
+    total = 0
+    for p in range(sc.n_panels):
+        lo, hi = items[ip[p]:mid[p]], items[mid[p]:ip[p + 1]]
+        assert np.all(lo[:, 2] < 32) and np.all(hi[:, 2] >= 32)
+        assert np.all(np.diff(lo[:, 1]) <= 0) and np.all(np.diff(hi[:, 1]) <= 0)
+        total += lo[:, 1].sum() + hi[:, 1].sum()
+        assert sc.items_per_half[0, p] == len(lo) and sc.items_per_half[1, p] == len(hi)
+    assert total == sc.nnz
+    cs = sc.batch_struct(1, 3)
+    assert cs.col_split == 32 and cs.item_mid == sc.item_mid.data_ptr() + 4
+    assert cs.max_items_half[0] == int(sc.items_per_half[0, 1:3].max())
