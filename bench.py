@@ -54,13 +54,16 @@ def algorithmic_bytes(nnz, B, D, K, S):
     return row, col, row + col
 
 
-def cpu_baseline(sc, model, params, K, max_rows=40_000):
+def cpu_baseline(sc, model, params, K, max_rows=40_960):
     """The CPU restatement (oracle/sparse_exact.py, kind "port") timed on the
-    host cores on a bounded row sample of the same workload."""
+    host cores on a bounded row sample of the same workload (whole panels, so the
+    HIP path can be run on exactly the same rows and compared with it)."""
     import numpy as np
     import scipy.sparse as sp
+    import torch
     from oracle import sparse_exact as SE
-    n = min(sc.n_rows, max_rows)
+    npan = max(1, min(sc.n_panels, max_rows // sc.panel_rows))
+    n = min(sc.n_rows, npan * sc.panel_rows)
     hi = int(sc.row_ptr[n])
     X = sp.csr_matrix((sc.val[:hi].cpu().numpy().astype(np.float64),
                        sc.col_idx[:hi].cpu().numpy(),
@@ -70,16 +73,31 @@ def cpu_baseline(sc, model, params, K, max_rows=40_000):
     decay = model.symmetry_breaking_decay ** np.arange(K)
 
     def step():
-        SE.data_term(X, eta, float(model.xi_u_global), model.scale_rows,
-                     one["u"], one["v"], one["w"], one["s"])
+        out = SE.data_term(X, eta, float(model.xi_u_global), model.scale_rows,
+                           one["u"], one["v"], one["w"], one["s"])
         SE.prior_term(one, model.u_tau_scale, model.s_tau_scale, decay)
-    step()
+        return out
+    ref = step()
+    # the checker's other job: the HIP path on the same rows, same draw (data term only)
+    first = {k: v[:1] for k, v in params.items()}
+    parts, grads, _ = model.energy_and_grads({"counts": sc, "panels": (0, npan)}, first,
+                                             prior_weight=0.0)
+    torch.cuda.synchronize()
+    gerr = 0.0
+    for name in ("u", "v", "w", "s"):
+        r = np.asarray(ref["grads"][name], dtype=np.float64)
+        g = grads[name][0].double().cpu().numpy().reshape(r.shape)
+        gerr = max(gerr, float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)))
+    parity = {"rows": int(n),
+              "x_rel": abs(float(parts["x"][0]) - ref["x"]) / abs(ref["x"]),
+              "z_rel": abs(float(parts["z"][0]) - ref["z"]) / abs(ref["z"]),
+              "grad_max_rel": gerr}
     reps, t0 = 0, time.perf_counter()
     while reps < 3 or (time.perf_counter() - t0 < 12.0 and reps < 60):
         step()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
-    return n, hi, dt
+    return n, hi, dt, parity
 
 
 def main():
@@ -339,10 +357,10 @@ def main():
             "elbo_x": float(parts["x"][0]),
         }
         if not args.no_cpu_baseline and world == 1 and not logt and mixed_mask is None:
-            n_s, nnz_s, t_s = cpu_baseline(sc, model, params, K)
+            n_s, nnz_s, t_s, parity = cpu_baseline(sc, model, params, K)
             out["cpu_baseline"] = {
                 "value": 1.0 / (t_s * rows_g / n_s), "unit": "steps/s", "cores": 1,
-                "kind": "port",
+                "kind": "port", "parity_vs_port": parity,
                 "sample": f"first {n_s} rows ({nnz_s} nnz) of the same matrix, fp64 "
                           f"scipy.sparse port (oracle/sparse_exact.py), {t_s:.3f} s per "
                           f"sample step, scaled by rows to the full workload; "
