@@ -157,6 +157,22 @@ def test_cli_end_to_end(tmp_path):
     assert "Feature dim: 9 -> Latent dim 2" in r.stdout
 
 
+def test_cli_log_transform_flag(tmp_path):
+    """-lt (log_transform) through the CLI: dense exp kernels in the training loop, outputs named lt_True."""
+    rng = np.random.default_rng(2)
+    X = rng.poisson(rng.gamma(1.0, 1.0, size=(1, 12)) * rng.gamma(2.0, 0.5, size=(240, 1)))
+    f = tmp_path / "c.csv"
+    np.savetxt(f, X, delimiter=",", fmt="%d")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "factorize_csv.py"),
+                        "-f", str(f), "-e", "4", "-d", "2", "-b", "80", "-lr", "0.02", "-lt"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    enc = np.loadtxt(f"{f}_2D_encoding_lt_True_rn_False.csv", delimiter=",", ndmin=2)
+    assert enc.shape == (2, 12) and np.isfinite(enc).all()
+    rep = np.loadtxt(f"{f}_2D_representation_lt_True_rn_False.csv", delimiter=",", ndmin=2)
+    assert rep.shape == (240, 3) and np.isfinite(rep).all()
+
+
 def test_qualitative_linear_structure_outcome():
     """notebooks/factorize_linear_structure.ipynb:53-66: every third column is
     driven by the latent factors, the rest is Poisson(1) noise.  After fitting,
