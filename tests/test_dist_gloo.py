@@ -57,8 +57,17 @@ def _worker(rank, world, port, q):
     colsum = torch.from_numpy(np.asarray(xs.sum(0)).reshape(-1).copy())
     colnnz = torch.from_numpy(np.asarray((xs > 0).sum(0)).reshape(-1).astype(np.float64))
     rows_g, lg_g = red.reduce_stats(colsum, colnnz, r1 - r0, lg)
+    # the column-split protocol (start / wait / totals) sums the same buffer in two ranges
+    acc2 = acc.clone()
+    half = acc2.numel() // 3
+    w0 = red.start(acc2[:half])
+    w1 = red.start(acc2[half:])
+    red.wait(w0)
+    red.wait(w1)
+    assert red.totals(r1 - r0, lg) == (rows_g, lg_g)
     rg2, lg2 = red(acc, r1 - r0, lg)
     assert (rg2, lg2) == (rows_g, lg_g)
+    assert torch.equal(acc, acc2)
     out = SE.finish_from_acc(acc.numpy(), rows_g, lg_g, eta, one["u"], one["v"], one["w"], one["s"])
     if rank == 0:
         q.put((r0, r1, rows_g, colsum.numpy(), out["x"], out["z"],
