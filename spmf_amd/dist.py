@@ -79,8 +79,9 @@ class ShardReducer:
     def totals(self, rows, lgamma_sum):
         """Global (rows, lgamma) of the batch, as __call__ returns them."""
         if self.rows_global is None:
-            tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64,
-                               device=torch.device("cuda", torch.cuda.current_device()))
+            dev = torch.device("cuda", torch.cuda.current_device()) \
+                if self.active and dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64, device=dev)
             if self.active:
                 self._sum(tot)
             return int(round(float(tot[0]))), float(tot[1])
