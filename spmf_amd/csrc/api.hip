@@ -135,7 +135,8 @@ void spmf_ctx_destroy(spmf_ctx* c) {
 const char* spmf_last_error(const spmf_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
 int spmf_ctx_set_prior(spmf_ctx* c, double u_tau_scale, double s_tau_scale, double decay) {
-  if (!c || !(u_tau_scale > 0) || !(s_tau_scale > 0) || !(decay > 0)) return fail(c, SPMF_E_ARG, "set_prior: scales must be > 0");
+  if (!c || !(u_tau_scale > 0) || !(s_tau_scale > 0) || !(decay > 0)) return fail(c, SPMF_E_ARG,
+      "set_prior: scales must be > 0");
   c->u_tau_scale = u_tau_scale;
   c->s_tau_scale = s_tau_scale;
   c->decay = decay;
@@ -145,7 +146,8 @@ int spmf_ctx_set_prior(spmf_ctx* c, double u_tau_scale, double s_tau_scale, doub
 int spmf_padded_k(const spmf_ctx* c) { return c ? c->KP : 0; }
 
 int spmf_ctx_set_column_types(spmf_ctx* c, const uint8_t* column_is_bernoulli) {
-  if (!c || !(c->flags & SPMF_FLAG_MIXED) || !column_is_bernoulli) return fail(c, SPMF_E_ARG, "set_column_types: needs a ctx created with SPMF_FLAG_MIXED and a [D] device array");
+  if (!c || !(c->flags & SPMF_FLAG_MIXED) || !column_is_bernoulli) return fail(c, SPMF_E_ARG,
+      "set_column_types: needs a ctx created with SPMF_FLAG_MIXED and a [D] device array");
   c->ctype = column_is_bernoulli;
   return SPMF_OK;
 }
@@ -157,7 +159,8 @@ size_t spmf_workspace_bytes(const spmf_ctx* c, int64_t max_rows, int S) {
 
 int spmf_ctx_set_workspace(spmf_ctx* c, void* workspace, size_t bytes) {
   if (!c) return SPMF_E_ARG;
-  if (!workspace || ((uintptr_t)workspace & 255)) return fail(c, SPMF_E_ARG, "workspace must be 256-byte aligned and non-null");
+  if (!workspace || ((uintptr_t)workspace & 255)) return fail(c, SPMF_E_ARG,
+      "workspace must be 256-byte aligned and non-null");
   c->ws = (char*)workspace;
   c->ws_bytes = bytes;
   c->ws_rows = -1;
@@ -170,7 +173,8 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   Carve k = carve(c, rows, S);
   if (k.total > c->ws_bytes) {
     char b[160];
-    snprintf(b, sizeof b, "workspace too small: need %zu bytes for rows=%lld S=%d, have %zu", k.total, (long long)rows, S, c->ws_bytes);
+    snprintf(b, sizeof b, "workspace too small: need %zu bytes for rows=%lld S=%d, have %zu", k.total,
+        (long long)rows, S, c->ws_bytes);
     return fail(c, SPMF_E_WORKSPACE, b);
   }
   c->acc = (float*)(c->ws + k.acc);
@@ -208,7 +212,8 @@ int spmf_ctx_enable_timing(spmf_ctx* c, int on) {
 int spmf_last_timing(spmf_ctx* c, float* ms5) {
   if (!c || !ms5) return SPMF_E_ARG;
   const bool logt = (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) != 0;
-  if (!c->timing || c->ev_count < 1) return fail(c, SPMF_E_ARG, "no timing recorded (enable timing, run data_pass + finish)");
+  if (!c->timing || c->ev_count < 1) return fail(c, SPMF_E_ARG,
+      "no timing recorded (enable timing, run data_pass + finish)");
   // average over the (up to kSets) most recent complete steps
   const int n = c->ev_count < spmf_ctx::kSets ? c->ev_count : spmf_ctx::kSets;
   double acc[4] = {0, 0, 0, 0};
@@ -243,14 +248,18 @@ int spmf_last_timing(spmf_ctx* c, float* ms5) {
 static int check_counts(spmf_ctx* c, const spmf_counts* ct) {
   if (!ct) return fail(c, SPMF_E_ARG, "counts is null");
   if (ct->n_cols != c->D) return fail(c, SPMF_E_ARG, "counts.n_cols != ctx D");
-  if (ct->n_rows < 0 || ct->nnz < 0 || ct->nnz > 2147483647LL) return fail(c, SPMF_E_ARG, "counts: bad n_rows/nnz (nnz must fit int32)");
+  if (ct->n_rows < 0 || ct->nnz < 0 || ct->nnz > 2147483647LL) return fail(c, SPMF_E_ARG,
+      "counts: bad n_rows/nnz (nnz must fit int32)");
   // the kernels gather factor rows with 32-bit byte offsets: B*KP*4 must stay below 4 GiB
-  if (ct->n_rows * (int64_t)c->KP * 4 >= (1LL << 32)) return fail(c, SPMF_E_ARG, "counts: too many rows in one batch for this K (B*KP*4 must be < 4 GiB)");
-  if (!ct->row_ptr || (ct->nnz > 0 && (!ct->col_idx || !ct->val))) return fail(c, SPMF_E_ARG, "counts: null CSR arrays");
+  if (ct->n_rows * (int64_t)c->KP * 4 >= (1LL << 32)) return fail(c, SPMF_E_ARG,
+      "counts: too many rows in one batch for this K (B*KP*4 must be < 4 GiB)");
+  if (!ct->row_ptr || (ct->nnz > 0 && (!ct->col_idx || !ct->val))) return fail(c, SPMF_E_ARG,
+      "counts: null CSR arrays");
   return SPMF_OK;
 }
 
-int spmf_counts_stats(spmf_ctx* c, int64_t n_rows, const int32_t* row_ptr, const int32_t* col_idx, const float* val, double* colsum, double* colnnz, float* row_sum, double* row_lgamma, void* stream) {
+int spmf_counts_stats(spmf_ctx* c, int64_t n_rows, const int32_t* row_ptr, const int32_t* col_idx, const float* val,
+    double* colsum, double* colnnz, float* row_sum, double* row_lgamma, void* stream) {
   if (!c || !row_ptr || n_rows < 0) return fail(c, SPMF_E_ARG, "counts_stats: bad arguments");
   if (n_rows == 0) return SPMF_OK;
   StatsArgs a{n_rows, row_ptr, col_idx, val, colsum, colnnz, row_sum, row_lgamma};
@@ -261,13 +270,16 @@ int spmf_counts_stats(spmf_ctx* c, int64_t n_rows, const int32_t* row_ptr, const
 
 // parts: bit 0 = zero, prep, row pass and the column pass of the lower column half (all columns
 // without a split); bit 1 = column pass of the upper half and the fp64 pack
-static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, int parts_mask, void* stream) {
+static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS],
+    const float* eta, int parts_mask, void* stream) {
   if (!c || !params || !eta || S < 1) return fail(c, SPMF_E_ARG, "data_pass: bad arguments");
   // likelihood / decoder code of the kernels: 0 Poisson linear, 1 Poisson log_transform, 2 Bernoulli
   const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : ((c->flags & SPMF_FLAG_MIXED) ? 3 : 0));
-  if (logt == 3 && !c->ctype) return fail(c, SPMF_E_ARG, "mixed likelihood: spmf_ctx_set_column_types was not called");
+  if (logt == 3 && !c->ctype) return fail(c, SPMF_E_ARG,
+      "mixed likelihood: spmf_ctx_set_column_types was not called");
   int rc = check_counts(c, ct);
-  if (!rc && logt == 1 && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG, "counts: log_transform needs gval / pc_gval");
+  if (!rc && logt == 1 && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG,
+      "counts: log_transform needs gval / pc_gval");
   if (rc) return rc;
   if (ct->n_rows > 0 && ct->nnz > 0 && (!ct->pc_row || !ct->pc_val || !ct->item_ptr || !ct->items || ct->n_panels < 1)) return fail(c, SPMF_E_ARG, "counts: panel-CSC arrays / work items missing");
   for (int i : {0, 1, 2, 7})
@@ -299,24 +311,29 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
     float* gVp = acc + L.gV_off(0);
     if (first) {
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
-    PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c, 1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt == 1 ? 1 : 0, logt == 3 ? c->ctype : nullptr, logt == 3 ? c->dbias : nullptr};
+    PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c,
+        1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt == 1 ? 1 : 0,
+        logt == 3 ? c->ctype : nullptr, logt == 3 ? c->dbias : nullptr};
     launch_prep(KP, pa, st);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
     const float* rscale = (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr;
     if (ct->n_rows > 0 && !logt) {
-      RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 0, 0, nullptr, nullptr};
+      RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
+          dacc, 0, 0, nullptr, nullptr};
       launch_row_pass(KP, ra, st);
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
       // cores, then the stored-cell terms (sweep 2) with the dense row term.
-      RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, logt == 1 ? ct->gval : ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 1, logt, nullptr, c->ctype};
+      RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, logt == 1 ? ct->gval : ct->val, rscale, c->Ap, c->Vp, c->phi,
+          dprep, c->z, c->gzs, dacc, 1, logt, nullptr, c->ctype};
       launch_row_pass(KP, r1, st);
       if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
       const int act = logt >= 2 ? 1 : 0;
       const float* lbias = logt == 3 ? c->dbias : c->phi;   // mixed: -1e30 masks the Poisson columns
       float* gphi_acc = acc + L.gphi_off(0);
       // Z-stationary: Q rows are columns d -> bias_q = phi (Bernoulli logits)
-      ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0, act, nullptr, act ? lbias : nullptr, nullptr};
+      ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0, act, nullptr,
+          act ? lbias : nullptr, nullptr};
       launch_expdot(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E (or sum softplus)
       // W-stationary launch has only D/128 workgroups: split the row (Q) range
       // into chunks until ~4 workgroups per CU are in flight
@@ -327,10 +344,12 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       if (chunks < 1) chunks = 1;
       // W-stationary: P rows are columns d -> bias_p = phi; Bernoulli also needs the
       // column sums of sigmoid for d/dphi (subtracted from the gphi accumulators)
-      ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, chunks, 1, act, act ? lbias : nullptr, nullptr, act ? gphi_acc : nullptr};
+      ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, chunks, 1, act, act ? lbias : nullptr,
+          nullptr, act ? gphi_acc : nullptr};
       launch_expdot(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
-      RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs, dacc, 2, logt, c->gzd, c->ctype};
+      RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
+          dacc, 2, logt, c->gzd, c->ctype};
       launch_row_pass(KP, r2, st);
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
@@ -339,7 +358,10 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       for (int hf = 0; hf < 2; ++hf) {
         if (!(hf == 0 ? first : second)) continue;
         if (!split && hf == 1) continue;
-        ColArgs ca{D, ct->n_panels, ct->row_base, split ? ct->max_items_half[hf] : ct->max_items_per_panel, ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc + L.gA_off(hf), acc + L.gV_off(hf), acc + L.gphi_off(hf), logt, ct->pc_gval, c->ctype, split ? ct->item_mid : nullptr, split ? hf + 1 : 0};
+        ColArgs ca{D, ct->n_panels, ct->row_base, split ? ct->max_items_half[hf] : ct->max_items_per_panel,
+            ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc + L.gA_off(hf),
+            acc + L.gV_off(hf), acc + L.gphi_off(hf), logt, ct->pc_gval, c->ctype, split ? ct->item_mid : nullptr,
+            split ? hf + 1 : 0};
         launch_col_pass(KP, ca, st);
       }
     }
@@ -356,11 +378,13 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
   return SPMF_OK;
 }
 
-int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, void* stream) {
+int spmf_data_pass(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS],
+    const float* eta, void* stream) {
   return data_pass_impl(c, ct, S, params, eta, 3, stream);
 }
 
-int spmf_data_pass_split(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS], const float* eta, int part, void* stream) {
+int spmf_data_pass_split(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS],
+    const float* eta, int part, void* stream) {
   if (part != 0 && part != 1) return fail(c, SPMF_E_ARG, "data_pass_split: part must be 0 or 1");
   return data_pass_impl(c, ct, S, params, eta, part == 0 ? 1 : 2, stream);
 }
@@ -371,7 +395,8 @@ int spmf_ctx_set_column_split(spmf_ctx* c, int Dh) {
     c->Dh = 0;
     return SPMF_OK;
   }
-  if (Dh < 0 || Dh > c->D || (Dh % 32) != 0) return fail(c, SPMF_E_ARG, "column split must be a multiple of 32 inside (0, D)");
+  if (Dh < 0 || Dh > c->D || (Dh % 32) != 0) return fail(c, SPMF_E_ARG,
+      "column split must be a multiple of 32 inside (0, D)");
   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED))
     return fail(c, SPMF_E_UNSUPPORTED, "column split: linear Poisson decoder only");
   c->Dh = Dh;
@@ -392,7 +417,8 @@ static int likelihood_code(const spmf_ctx* c) {
   return (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : ((c->flags & SPMF_FLAG_MIXED) ? 3 : 0));
 }
 
-int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS], void* stream) {
+int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const params[SPMF_NVARS],
+    const float* eta, double* parts, float* const grads[SPMF_NVARS], void* stream) {
   if (!c || !params || !grads || !eta || !parts || S < 1) return fail(c, SPMF_E_ARG, "prior_async: bad arguments");
   for (int i = 0; i < SPMF_NVARS; ++i)
     if (!params[i] || !grads[i]) return fail(c, SPMF_E_ARG, "prior_async: all 12 params/grads must be non-null");
@@ -414,7 +440,8 @@ int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const
       P[i] = params[i] + s * var_size(c, i);
       G[i] = grads[i] + s * var_size(c, i);
     }
-    FinishArgs fa{c->D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, nullptr, nullptr, P, eta, G, parts + (size_t)s * SPMF_NPARTS, nullptr, likelihood_code(c), c->ctype, c->Dh};
+    FinishArgs fa{c->D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, nullptr, nullptr, P,
+        eta, G, parts + (size_t)s * SPMF_NPARTS, nullptr, likelihood_code(c), c->ctype, c->Dh};
     launch_finish(c->KP, fa, 1, c->side);
   }
   HIPCHK(c, hipEventRecord(c->ev_join, c->side));
@@ -424,7 +451,9 @@ int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const
   return SPMF_OK;
 }
 
-int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_global, double prior_weight, const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS], double* n_nonfinite, void* stream) {
+int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_global, double prior_weight,
+    const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS],
+    double* n_nonfinite, void* stream) {
   if (!c || !params || !grads || !eta || !parts || S < 1) return fail(c, SPMF_E_ARG, "finish: bad arguments");
   if (!c->acc || c->ws_S < S) return fail(c, SPMF_E_ARG, "finish: no data pass precedes it for this S");
   for (int i = 0; i < SPMF_NVARS; ++i)
@@ -451,7 +480,9 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
       P[i] = params[i] + s * var_size(c, i);
       G[i] = grads[i] + s * var_size(c, i);
     }
-    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS, n_nonfinite ? n_nonfinite + s : nullptr, likelihood_code(c), c->ctype, c->Dh};
+    FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight,
+        c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS,
+        n_nonfinite ? n_nonfinite + s : nullptr, likelihood_code(c), c->ctype, c->Dh};
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
     launch_finish(KP, fa, joined ? 2 : 0, st);
     if (tm) {
@@ -466,13 +497,16 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
   return SPMF_OK;
 }
 
-int spmf_elbo_fwd_bwd(spmf_ctx* c, const spmf_counts* ct, int S, double prior_weight, const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS], double* n_nonfinite, void* stream) {
+int spmf_elbo_fwd_bwd(spmf_ctx* c, const spmf_counts* ct, int S, double prior_weight,
+    const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS],
+    double* n_nonfinite, void* stream) {
   int rc = spmf_data_pass(c, ct, S, params, eta, stream);
   if (rc) return rc;
   return spmf_finish(c, S, ct->n_rows, ct->lgamma_sum, prior_weight, params, eta, parts, grads, n_nonfinite, stream);
 }
 
-int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* s, const float* eta, float* z_out, void* stream) {
+int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* s, const float* eta, float* z_out,
+    void* stream) {
   if (!c || !u || !s || !eta || !z_out) return fail(c, SPMF_E_ARG, "encode: bad arguments");
   const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0;
   int rc = check_counts(c, ct);
@@ -485,16 +519,22 @@ int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float*
   launch_zero(c->dprep, (c->KP + 1) * sizeof(double), st);
   PrepArgs pa{c->D, c->K, u, nullptr, nullptr, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt, nullptr, nullptr};
   launch_prep(c->KP, pa, st);
-  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr, nullptr};
+  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val,
+      (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs,
+      c->dacc, 1, logt, nullptr, nullptr};
   launch_row_pass(c->KP, ra, st);
-  HIPCHK(c, hipMemcpy2DAsync(z_out, (size_t)c->K * sizeof(float), c->z, (size_t)c->KP * sizeof(float), (size_t)c->K * sizeof(float), (size_t)ct->n_rows, hipMemcpyDeviceToDevice, st));
+  HIPCHK(c, hipMemcpy2DAsync(z_out, (size_t)c->K * sizeof(float), c->z, (size_t)c->KP * sizeof(float),
+      (size_t)c->K * sizeof(float), (size_t)ct->n_rows, hipMemcpyDeviceToDevice, st));
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;
 }
 
-int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* v, const float* w, const float* s, const float* eta, float* rate_out, float* ll_out, void* stream) {
-  if (!c || !u || !v || !w || !s || !eta || !rate_out || !ll_out) return fail(c, SPMF_E_ARG, "dense_ll: bad arguments");
-  if (c->flags & (SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) return fail(c, SPMF_E_UNSUPPORTED, "dense_ll: Bernoulli per-cell outputs are not built");
+int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* v, const float* w,
+    const float* s, const float* eta, float* rate_out, float* ll_out, void* stream) {
+  if (!c || !u || !v || !w || !s || !eta || !rate_out || !ll_out) return fail(c, SPMF_E_ARG,
+      "dense_ll: bad arguments");
+  if (c->flags & (SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) return fail(c, SPMF_E_UNSUPPORTED,
+      "dense_ll: Bernoulli per-cell outputs are not built");
   const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0;
   int rc = check_counts(c, ct);
   if (!rc && logt && ct->nnz > 0 && !ct->gval) rc = fail(c, SPMF_E_ARG, "dense_ll: log_transform needs counts.gval");
@@ -506,7 +546,9 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
   launch_zero(c->dprep, (c->KP + 1) * sizeof(double), st);
   PrepArgs pa{c->D, c->K, u, v, w, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt, nullptr, nullptr};
   launch_prep(c->KP, pa, st);
-  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val, (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs, c->dacc, 1, logt, nullptr, nullptr};
+  RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val,
+      (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs,
+      c->dacc, 1, logt, nullptr, nullptr};
   launch_row_pass(c->KP, ra, st);
   DenseLLArgs da{ct->n_rows, c->D, logt, c->z, c->Vp, c->phi, ct->row_ptr, ct->col_idx, ct->val, rate_out, ll_out};
   launch_dense_ll(c->KP, da, st);
@@ -515,7 +557,8 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
 }
 
 int spmf_nonfinite_reduce(spmf_ctx* c, int64_t n, const float* ll, int pass, double* io, void* stream) {
-  if (!c || !ll || !io || n < 0 || (pass != 0 && pass != 1)) return fail(c, SPMF_E_ARG, "nonfinite_reduce: bad arguments");
+  if (!c || !ll || !io || n < 0 || (pass != 0 && pass != 1)) return fail(c, SPMF_E_ARG,
+      "nonfinite_reduce: bad arguments");
   if (n == 0) return SPMF_OK;
   launch_nonfinite(n, ll, pass, io, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
@@ -523,14 +566,17 @@ int spmf_nonfinite_reduce(spmf_ctx* c, int64_t n, const float* ll, int pass, dou
 }
 
 int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, double* logq, void* stream) {
-  if (!c || !vars || nvars < 1 || nvars > 12 || S < 1 || !logq) return fail(c, SPMF_E_ARG, "surrogate_fwd: bad arguments");
+  if (!c || !vars || nvars < 1 || nvars > 12 || S < 1 || !logq) return fail(c, SPMF_E_ARG,
+      "surrogate_fwd: bad arguments");
   SurTable T;
   int max_n = 0;
   for (int i = 0; i < nvars; ++i) {
     const spmf_sur_var& v = vars[i];
-    if (!v.t0 || !v.t1 || !v.noise || !v.theta || v.n < 1 || v.kind < 0 || v.kind > 2) return fail(c, SPMF_E_ARG, "surrogate_fwd: bad variable");
+    if (!v.t0 || !v.t1 || !v.noise || !v.theta || v.n < 1 || v.kind < 0 || v.kind > 2) return fail(c, SPMF_E_ARG,
+        "surrogate_fwd: bad variable");
     if (v.noise_ld != 0 && v.noise_ld < v.n) return fail(c, SPMF_E_ARG, "surrogate: noise_ld < n");
-    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident, v.noise_ld ? v.noise_ld : (int64_t)v.n};
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident,
+        v.noise_ld ? v.noise_ld : (int64_t)v.n};
     if (v.n > max_n) max_n = v.n;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -540,7 +586,8 @@ int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
   return SPMF_OK;
 }
 
-int spmf_surrogate_bwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, double inv_sb, double cw, void* stream) {
+int spmf_surrogate_bwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, double inv_sb, double cw,
+    void* stream) {
   if (!c || !vars || nvars < 1 || nvars > 12 || S < 1) return fail(c, SPMF_E_ARG, "surrogate_bwd: bad arguments");
   SurTable T;
   int max_n = 0;
@@ -548,7 +595,8 @@ int spmf_surrogate_bwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
     const spmf_sur_var& v = vars[i];
     if (!v.t0 || !v.t1 || !v.noise || !v.gtheta || !v.g0 || !v.g1 || v.n < 1 || v.kind < 0 || v.kind > 2 || (v.kind == 2 && !v.dgda)) return fail(c, SPMF_E_ARG, "surrogate_bwd: bad variable");
     if (v.noise_ld != 0 && v.noise_ld < v.n) return fail(c, SPMF_E_ARG, "surrogate: noise_ld < n");
-    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident, v.noise_ld ? v.noise_ld : (int64_t)v.n};
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident,
+        v.noise_ld ? v.noise_ld : (int64_t)v.n};
     if (v.n > max_n) max_n = v.n;
   }
   launch_surrogate_bwd(T, nvars, max_n, S, (float)inv_sb, (float)cw, (hipStream_t)stream);
@@ -556,8 +604,10 @@ int spmf_surrogate_bwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
   return SPMF_OK;
 }
 
-int spmf_adam_step(spmf_ctx* c, const spmf_adam_var* tensors, int ntensors, double lr, double beta1, double beta2, double eps, int step, double clip, void* stream) {
-  if (!c || !tensors || ntensors < 1 || ntensors > 24 || step < 1) return fail(c, SPMF_E_ARG, "adam_step: bad arguments");
+int spmf_adam_step(spmf_ctx* c, const spmf_adam_var* tensors, int ntensors, double lr, double beta1, double beta2,
+    double eps, int step, double clip, void* stream) {
+  if (!c || !tensors || ntensors < 1 || ntensors > 24 || step < 1) return fail(c, SPMF_E_ARG,
+      "adam_step: bad arguments");
   AdamTable T;
   int max_n = 0;
   for (int i = 0; i < ntensors; ++i) {
@@ -567,12 +617,14 @@ int spmf_adam_step(spmf_ctx* c, const spmf_adam_var* tensors, int ntensors, doub
     if (a.n > max_n) max_n = a.n;
   }
   const double c1 = 1.0 - pow(beta1, step), c2 = 1.0 - pow(beta2, step);
-  launch_adam(T, ntensors, max_n, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)c1, (float)c2, (float)clip, (hipStream_t)stream);
+  launch_adam(T, ntensors, max_n, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)c1, (float)c2,
+      (float)clip, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;
 }
 
-int spmf_vi_gate(spmf_ctx* c, const double* parts, const double* logq, const double* n_nonfinite, int S, double cw, double rows, double* state, void* stream) {
+int spmf_vi_gate(spmf_ctx* c, const double* parts, const double* logq, const double* n_nonfinite, int S, double cw,
+    double rows, double* state, void* stream) {
   if (!c || !parts || !logq || !state || S < 1 || !(rows > 0.0)) return fail(c, SPMF_E_ARG, "vi_gate: bad arguments");
   launch_vi_gate(parts, logq, n_nonfinite, S, cw, rows, state, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
@@ -580,7 +632,8 @@ int spmf_vi_gate(spmf_ctx* c, const double* parts, const double* logq, const dou
 }
 
 int spmf_adam_step_dev(spmf_ctx* c, const spmf_adam_var* tensors, int ntensors, const double* state, void* stream) {
-  if (!c || !tensors || ntensors < 1 || ntensors > 24 || !state) return fail(c, SPMF_E_ARG, "adam_step_dev: bad arguments");
+  if (!c || !tensors || ntensors < 1 || ntensors > 24 || !state) return fail(c, SPMF_E_ARG,
+      "adam_step_dev: bad arguments");
   AdamTable T;
   int max_n = 0;
   for (int i = 0; i < ntensors; ++i) {
