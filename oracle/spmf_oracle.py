@@ -380,9 +380,13 @@ def surrogate_transform(kind, t0, t1, noise):
     return theta, lq.sum((-1, -2))
 
 
-def random_params(cfg: OracleConfig, S: int, seed: int, spread: float = 0.3):
+def random_params(cfg: OracleConfig, S: int, seed: int, spread: float = 0.3,
+                  fp32_exact: bool = False):
     """Seeded positive parameter draws of realistic magnitude for parity
-    tests (NOT the surrogate: just well-conditioned positive tensors)."""
+    tests (NOT the surrogate: just well-conditioned positive tensors).
+    ``fp32_exact`` rounds every value to one a float32 holds exactly, so an
+    fp32 implementation and this fp64 oracle are evaluated at IDENTICAL inputs
+    (otherwise the input rounding, ~6e-8 per value, is part of the difference)."""
     rng = np.random.default_rng(seed)
     D, K = cfg.feature_dim, cfg.latent_dim
     sh = var_shapes(D, K)
@@ -392,4 +396,6 @@ def random_params(cfg: OracleConfig, S: int, seed: int, spread: float = 0.3):
     out = {}
     for n in VAR_ORDER:
         out[n] = base[n] * np.exp(spread * rng.standard_normal((S,) + sh[n]))
+        if fp32_exact:
+            out[n] = out[n].astype(np.float32).astype(np.float64)
     return out

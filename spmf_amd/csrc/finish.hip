@@ -89,6 +89,8 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
   __shared__ float zsum_s[KP], utau_s[KP], dec_s[KP], gutau_s[KP];
   __shared__ double lsc_s[KP];     // log(u_tau_k * decay^k)
+  __shared__ double scd_s[KP];     // u_tau_k * decay^k in fp64 (an fp32 product is a per-k systematic
+                                   // error of the quadratic term: 8e-6 of part 'u' at K ~ 60)
   __shared__ float gred[256];
   __shared__ int bern_s[FTD];
   const int t = threadIdx.x;
@@ -112,7 +114,10 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     utau_s[t] = t < K ? P.p[UTAU_][t] : 1.f;
     dec_s[t] = (float)pow((double)decay, (double)t);   // powf is ~1e-6 off at t~60: a systematic part error
     gutau_s[t] = 0.f;
-    if (PRIOR) lsc_s[t] = log((double)utau_s[t]) + (double)t * log(decay);
+    if (PRIOR) {
+      lsc_s[t] = log((double)utau_s[t]) + (double)t * log(decay);
+      scd_s[t] = (double)utau_s[t] * pow((double)decay, (double)t);
+    }
   }
   if (t < FTD) {
     const int d = d0 + t;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
         // this kernel's time goes to): log sig = log ue + log(utau_k dec_k)
         const double Lue = log((double)ue), Lua = log((double)ua);
         const float sig = ue * sc, is = 1.f / sig, q = u * is;
-        const double qd = (double)u / ((double)ue * (double)sc);
+        const double qd = (double)u / ((double)ue * scd_s[k]);
         part[U_] += kHalfLog2OverPi - (Lue + lsc_s[k]) - 0.5 * qd * qd;
         const float gy = -q * is, gs = (q * q - 1.f) * is;
         G.p[U_][i] = du + pw * gy;

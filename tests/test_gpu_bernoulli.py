@@ -20,7 +20,7 @@ def problem(B, D, K, S, seed, density):
     cfg = O.OracleConfig(latent_dim=K, feature_dim=D, scale_rows=False, likelihood="bernoulli",
                          u_tau_scale=1.0 / math.sqrt(B * D))
     cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 2.0, size=(1, D)))
-    params = O.random_params(cfg, S, seed + 1)
+    params = O.random_params(cfg, S, seed + 1, fp32_exact=True)
     params["v"] = params["v"] * rng.choice([-1.0, 1.0], size=params["v"].shape)   # Identity bijector
     params["w"] = -3.0 * params["w"]
     return cfg, x, params

@@ -21,7 +21,7 @@ def problem(B, D, K, S, seed, density, scale_rows=True):
                          u_tau_scale=1.0 / math.sqrt(B * D))
     cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
     cfg.xi_u_global = float(rng.uniform(4.0, 8.0))
-    params = O.random_params(cfg, S, seed + 1)
+    params = O.random_params(cfg, S, seed + 1, fp32_exact=True)
     # keep exp(<z, eta v>) in a sane range: rescale v so the largest exponent is 8
     T = torch.as_tensor
     z = O.encode(cfg, T(x), T(params["u"]), T(params["s"]))

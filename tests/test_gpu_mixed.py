@@ -21,7 +21,7 @@ def problem(B, D, K, S, seed, density, scale_rows=True):
                          u_tau_scale=1.0 / math.sqrt(B * D), extra={"bernoulli_columns": mask})
     cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 2.0, size=(1, D)))
     cfg.xi_u_global = float(rng.uniform(2.0, 6.0))
-    params = O.random_params(cfg, S, seed + 1)
+    params = O.random_params(cfg, S, seed + 1, fp32_exact=True)
     sign = np.where(mask, rng.choice([-1.0, 1.0], size=D), 1.0)
     params["v"] = params["v"] * sign[None, None, :]
     params["w"] = params["w"] * np.where(mask, -3.0, 1.0)[None, None, :]

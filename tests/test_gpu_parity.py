@@ -27,7 +27,7 @@ def make_problem(B, D, K, S, seed, density, scale_rows=True, empty=True, xmax=2.
                          u_tau_scale=1.0 / math.sqrt(B * D))
     cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
     cfg.xi_u_global = float(rng.uniform(2.0, 6.0))
-    params = O.random_params(cfg, S, seed + 1)
+    params = O.random_params(cfg, S, seed + 1, fp32_exact=True)
     return cfg, x, params
 
 
