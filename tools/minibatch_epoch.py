@@ -1,13 +1,16 @@
-"""C3-shaped minibatch training: one epoch = 41 steps over 3-panel (24576-row) minibatches of the
-resident 1M x 20k matrix, S=1, through vi.StepRunner (eager vs hipGraph replay)."""
+"""Minibatch training epochs through vi.StepRunner (eager vs hipGraph replay): 3-panel (24576-row)
+minibatches of the resident matrix.  usage: minibatch_epoch.py [c3|c2] [S]"""
 import sys, time, contextlib
 import torch
 sys.path.insert(0, ".")
 from spmf_amd import PoissonFactorization, synth, vi
 
-rows, D, K = 1_000_000, 20_000, 32
+cfgs = {"c3": (1_000_000, 20_000, 32, 0.005), "c2": (100_000, 5_000, 16, 0.01)}
+rows, D, K, dens = cfgs[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda", 0)
-sc = synth.linear_structure(rows, D, 0.005, dev)
+sc = synth.linear_structure(rows, D, dens, dev) if D == 20_000 else \
+    synth.bernoulli_poisson(rows, D, dens, dev, 20241218 + 2)
 with contextlib.redirect_stdout(sys.stderr):
     m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1.0 / (rows * D) ** 0.5, device=dev)
 colsum = torch.zeros(D, dtype=torch.float64, device=dev); colnnz = torch.zeros_like(colsum)
@@ -20,7 +23,7 @@ for use_graph in (False, True):
     torch.manual_seed(0)
     opt = vi.AdamHIP(m, m.surrogate_distribution.trainable_variables, 1e-3)
     opt.init_state(3.0)
-    run = vi.StepRunner(m, opt, rows, 1, use_graph=use_graph)
+    run = vi.StepRunner(m, opt, rows, S, use_graph=use_graph)
     for ep in range(5):
         if ep == 2:
             torch.cuda.synchronize(); t0 = time.perf_counter()
