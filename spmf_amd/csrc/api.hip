@@ -42,6 +42,7 @@ struct spmf_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int Dh = 0;                     // column split of the accumulator layout (0 = none)
+  int batched = 0;                // the bound workspace holds per-draw tables (S draws per launch)
   int prior_pending = 0;          // S of the launched prior half, 0 = none
   const double* prior_parts = nullptr;
   std::string err;
@@ -78,19 +79,31 @@ static size_t var_size(const spmf_ctx* c, int i) {
 struct Carve {
   size_t acc, dacc, dprep, Ap, Vp, phi, dbias, z, gzs, gzd, total;
 };
+// Small batches run all S draws in ONE launch per kernel (gridDim.y = S): the per-draw tables and
+// row outputs then exist S times.  Only for the linear Poisson decoder, only while the S table
+// pairs stay L2 sized (beyond that a draw is gather-bound, not launch-bound, and draws run in turn).
+static bool batched_draws(const spmf_ctx* c, int64_t rows, int S) {
+  if (S < 2 || c->Dh > 0) return false;
+  if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) return false;
+  const size_t tables = (size_t)S * 2 * c->D * c->KP * sizeof(float);
+  const size_t rowbuf = (size_t)S * 2 * (size_t)rows * c->KP * sizeof(float);
+  return tables <= (3u << 20) && rowbuf <= (256u << 20);
+}
+
 static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   Carve k;
   size_t o = 0;
   const size_t KP = c->KP, D = c->D;
+  const size_t nd = batched_draws(c, rows, S) ? (size_t)S : 1;   // per-draw copies
   k.acc = o;   o += al((size_t)S * acc_len(c->D, c->KP) * sizeof(float));
   k.dacc = o;  o += al((size_t)S * kDaccRep * (kDaccHead + KP) * sizeof(double));
   k.dprep = o; o += al((size_t)S * (KP + 1) * sizeof(double));
-  k.Ap = o;    o += al(D * KP * sizeof(float));
-  k.Vp = o;    o += al(D * KP * sizeof(float));
-  k.phi = o;   o += al(D * sizeof(float));
+  k.Ap = o;    o += al(nd * D * KP * sizeof(float));
+  k.Vp = o;    o += al(nd * D * KP * sizeof(float));
+  k.phi = o;   o += al(nd * D * sizeof(float));
   k.dbias = o; o += al(D * sizeof(float));
-  k.z = o;     o += al((size_t)rows * KP * sizeof(float));
-  k.gzs = o;   o += al((size_t)rows * KP * sizeof(float));
+  k.z = o;     o += al(nd * (size_t)rows * KP * sizeof(float));
+  k.gzs = o;   o += al(nd * (size_t)rows * KP * sizeof(float));
   k.gzd = o;   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) o += al((size_t)rows * KP * sizeof(float));
   k.total = o;
   return k;
@@ -189,13 +202,18 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   c->gzd = (float*)(c->ws + k.gzd);
   c->ws_rows = rows;
   c->ws_S = S;
+  c->batched = batched_draws(c, rows, S) ? 1 : 0;
   return SPMF_OK;
 }
 
 float* spmf_acc_ptr(const spmf_ctx* c) { return c ? c->acc : nullptr; }
 int64_t spmf_acc_len(const spmf_ctx* c, int S) { return c ? (int64_t)S * acc_len(c->D, c->KP) : 0; }
-const float* spmf_z_ptr(const spmf_ctx* c) { return c ? c->z : nullptr; }
-const float* spmf_gz_ptr(const spmf_ctx* c) { return c ? c->gzs : nullptr; }
+const float* spmf_z_ptr(const spmf_ctx* c) {
+  return c ? c->z + (c->batched ? (size_t)(c->ws_S - 1) * c->ws_rows * c->KP : 0) : nullptr;
+}
+const float* spmf_gz_ptr(const spmf_ctx* c) {
+  return c ? c->gzs + (c->batched ? (size_t)(c->ws_S - 1) * c->ws_rows * c->KP : 0) : nullptr;
+}
 
 int spmf_ctx_enable_timing(spmf_ctx* c, int on) {
   if (!c) return SPMF_E_ARG;
@@ -303,23 +321,26 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
     c->ev = c->evs[c->ev_set];
     c->ev_valid = 0;
   }
-  for (int s = 0; s < S; ++s) {
-    const bool tm = c->timing && s == S - 1;
+  // batched: one pass of the loop launches every kernel once for all S draws (gridDim.y)
+  const int nbat = c->batched ? S : 1;
+  const int64_t dacc_stride = (int64_t)kDaccRep * (kDaccHead + KP);
+  for (int s = 0; s < S; s += nbat) {
+    const bool tm = c->timing && s + nbat == S;
     float* acc = c->acc + (size_t)s * al_;
-    double* dacc = c->dacc + (size_t)s * kDaccRep * (kDaccHead + KP);
+    double* dacc = c->dacc + (size_t)s * dacc_stride;
     double* dprep = c->dprep + (size_t)s * (KP + 1);
     float* gVp = acc + L.gV_off(0);
     if (first) {
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
     PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c,
         1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt == 1 ? 1 : 0,
-        logt == 3 ? c->ctype : nullptr, logt == 3 ? c->dbias : nullptr};
+        logt == 3 ? c->ctype : nullptr, logt == 3 ? c->dbias : nullptr, nbat};
     launch_prep(KP, pa, st);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
     const float* rscale = (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr;
     if (ct->n_rows > 0 && !logt) {
       RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
-          dacc, 0, 0, nullptr, nullptr};
+          dacc, 0, 0, nullptr, nullptr, nbat, D, dacc_stride};
       launch_row_pass(KP, ra, st);
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
@@ -361,12 +382,12 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         ColArgs ca{D, ct->n_panels, ct->row_base, split ? ct->max_items_half[hf] : ct->max_items_per_panel,
             ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc + L.gA_off(hf),
             acc + L.gV_off(hf), acc + L.gphi_off(hf), logt, ct->pc_gval, c->ctype, split ? ct->item_mid : nullptr,
-            split ? hf + 1 : 0};
+            split ? hf + 1 : 0, nbat, ct->n_rows, (int64_t)al_};
         launch_col_pass(KP, ca, st);
       }
     }
     if (second) {
-      PackArgs pk{KP, dacc, acc + L.tail_off()};
+      PackArgs pk{KP, dacc, acc + L.tail_off(), nbat, dacc_stride, (int64_t)al_};
       launch_pack(pk, st);
       if (tm) {
         HIPCHK(c, hipEventRecord(c->ev[3], st));
@@ -433,15 +454,11 @@ int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const
   launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
   HIPCHK(c, hipEventRecord(c->ev_fork, st));
   HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-  for (int s = 0; s < S; ++s) {
-    const float* P[SPMF_NVARS];
-    float* G[SPMF_NVARS];
-    for (int i = 0; i < SPMF_NVARS; ++i) {
-      P[i] = params[i] + s * var_size(c, i);
-      G[i] = grads[i] + s * var_size(c, i);
-    }
-    FinishArgs fa{c->D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, nullptr, nullptr, P,
-        eta, G, parts + (size_t)s * SPMF_NPARTS, nullptr, likelihood_code(c), c->ctype, c->Dh};
+  {
+    // one launch for all S draws (gridDim.y)
+    FinishArgs fa{c->D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, nullptr, nullptr,
+        params, eta, grads, parts, nullptr, likelihood_code(c), c->ctype, c->Dh, S, 0, {}};
+    for (int i = 0; i < SPMF_NVARS; ++i) fa.vstride[i] = (int64_t)var_size(c, i);
     launch_finish(c->KP, fa, 1, c->side);
   }
   HIPCHK(c, hipEventRecord(c->ev_join, c->side));
@@ -472,17 +489,13 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
     launch_zero(parts, (size_t)S * SPMF_NPARTS * sizeof(double), st);
     launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
   }
-  for (int s = 0; s < S; ++s) {
-    const bool tm = c->timing && s == S - 1;
-    const float* P[SPMF_NVARS];
-    float* G[SPMF_NVARS];
-    for (int i = 0; i < SPMF_NVARS; ++i) {
-      P[i] = params[i] + s * var_size(c, i);
-      G[i] = grads[i] + s * var_size(c, i);
-    }
+  {
+    // one launch for all S draws (gridDim.y)
+    const bool tm = c->timing;
     FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight,
-        c->acc + (size_t)s * al_, c->dprep + (size_t)s * (KP + 1), P, eta, G, parts + (size_t)s * SPMF_NPARTS,
-        n_nonfinite ? n_nonfinite + s : nullptr, likelihood_code(c), c->ctype, c->Dh};
+        c->acc, c->dprep, params, eta, grads, parts, n_nonfinite, likelihood_code(c), c->ctype, c->Dh, S,
+        (int64_t)al_, {}};
+    for (int i = 0; i < SPMF_NVARS; ++i) fa.vstride[i] = (int64_t)var_size(c, i);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
     launch_finish(KP, fa, joined ? 2 : 0, st);
     if (tm) {

@@ -60,7 +60,18 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     const float* __restrict__ pc_gval, const float* __restrict__ Vp,
     const float* __restrict__ phi, const float* __restrict__ z, const float* __restrict__ gzs,
     float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi,
-    const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel) {
+    const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel,
+    int64_t Brows, int64_t acc_stride) {
+  if (gridDim.y > 1) {   // S draws per launch
+    const size_t sd = blockIdx.y;
+    Vp += sd * (size_t)D * KP;
+    phi += sd * (size_t)D;
+    z += sd * (size_t)Brows * KP;
+    gzs += sd * (size_t)Brows * KP;
+    gAp += sd * (size_t)acc_stride;
+    gVp += sd * (size_t)acc_stride;
+    gphi += sd * (size_t)acc_stride;
+  }
   constexpr int LPN = KP / 4;
   constexpr int NG = 64 / LPN;                        // items per wave
   constexpr int GRP = LPN < COL_GRP ? LPN : COL_GRP;  // entries gathered back to back
@@ -189,10 +200,11 @@ static void launch_col_t(const ColArgs& a, hipStream_t st) {
   const int64_t nb = a.n_panels < 8 ? (int64_t)a.n_panels * bpp : nt * bpp * 8;
   const int4* items = reinterpret_cast<const int4*>(a.items);
 #define SPMF_COL_LAUNCH(L_)                                                                    \
-  hipLaunchKernelGGL((col_pass_kernel<KP, L_>), dim3((unsigned)nb), dim3(256), 0, st, a.D,     \
+  hipLaunchKernelGGL((col_pass_kernel<KP, L_>), dim3((unsigned)nb, a.S > 1 ? a.S : 1),         \
+                     dim3(256), 0, st, a.D,                                                    \
                      a.n_panels, a.row_base, bpp, a.item_ptr, items, a.pc_row, a.pc_val,       \
                      a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi, a.ctype,          \
-                     a.item_mid, a.half_sel)
+                     a.item_mid, a.half_sel, a.B, a.acc_stride)
   if (a.logt == 3) SPMF_COL_LAUNCH(3);
   else if (a.logt == 2) SPMF_COL_LAUNCH(2);
   else if (a.logt == 1) SPMF_COL_LAUNCH(1);

@@ -32,6 +32,9 @@ struct Ptrs12 {
 struct MPtrs12 {
   float* p[12];
 };
+struct VStride {
+  int64_t v[12];
+};
 
 enum { V_ = 0, W_, U_, UETA_, UTAU_, SETA_, STAU_, S_, UETAA_, UTAUA_, SETAA_, STAUA_ };
 
@@ -83,8 +86,21 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
                                                      const float* __restrict__ eta, MPtrs12 G,
                                                      double* __restrict__ parts,
                                                      double* __restrict__ nnf_out, int logt,
-                                                     const uint8_t* __restrict__ ctype, int Dh) {
+                                                     const uint8_t* __restrict__ ctype, int Dh,
+                                                     int64_t acc_stride, VStride VS) {
   constexpr bool PRIOR = PHASE != 2, DATA = PHASE != 1;
+  if (gridDim.y > 1) {   // S draws per launch: everything per draw moves by its stride
+    const size_t sd = blockIdx.y;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      P.p[i] += sd * (size_t)VS.v[i];
+      G.p[i] += sd * (size_t)VS.v[i];
+    }
+    if (acc) acc += sd * (size_t)acc_stride;
+    if (dprep) dprep += sd * (size_t)(KP + 1);
+    parts += sd * 14;
+    if (nnf_out) nnf_out += sd;
+  }
   __shared__ float tile[KP][FTD + 1];
   __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
   __shared__ float zsum_s[KP], utau_s[KP], dec_s[KP], gutau_s[KP];
@@ -366,7 +382,10 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   }
 }
 
-__global__ void pack_kernel(int KP, const double* __restrict__ dacc, float* __restrict__ tail) {
+__global__ void pack_kernel(int KP, const double* __restrict__ dacc, float* __restrict__ tail,
+                            int64_t dacc_stride, int64_t acc_stride) {
+  dacc += (size_t)blockIdx.y * dacc_stride;     // draw of this block
+  tail += (size_t)blockIdx.y * acc_stride;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kDaccHead + KP) {
     double v = 0.0;
@@ -379,7 +398,8 @@ __global__ void pack_kernel(int KP, const double* __restrict__ dacc, float* __re
 
 void launch_pack(const PackArgs& a, hipStream_t st) {
   const int n = kDaccHead + a.KP;
-  hipLaunchKernelGGL(pack_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a.KP, a.dacc, a.tail);
+  hipLaunchKernelGGL(pack_kernel, dim3((n + 63) / 64, a.S > 1 ? a.S : 1), dim3(64), 0, st, a.KP,
+                     a.dacc, a.tail, a.dacc_stride, a.acc_stride);
 }
 
 template <int KP>
@@ -391,11 +411,15 @@ static void launch_finish_t(const FinishArgs& a, int phase, hipStream_t st) {
     G.p[i] = a.grads[i];
   }
   const int nb = (a.D + FTD - 1) / FTD;
+  VStride VS;
+  for (int i = 0; i < 12; ++i) VS.v[i] = a.vstride[i];
 #define SPMF_FIN(PH_)                                                                            \
-  hipLaunchKernelGGL((finish_kernel<KP, PH_>), dim3(nb), dim3(256), 0, st, a.D, a.K,             \
+  hipLaunchKernelGGL((finish_kernel<KP, PH_>), dim3(nb, a.S > 1 ? a.S : 1), dim3(256), 0, st,    \
+                     a.D, a.K,                                                                   \
                      (double)a.B_global, a.lgamma_sum, (float)a.u_tau_scale,                     \
                      (float)a.s_tau_scale, a.decay, (float)a.prior_weight, a.acc, a.dprep, P,    \
-                     a.eta, G, a.parts, a.n_nonfinite, a.logt, a.ctype, a.Dh > 0 ? a.Dh : a.D)
+                     a.eta, G, a.parts, a.n_nonfinite, a.logt, a.ctype, a.Dh > 0 ? a.Dh : a.D,   \
+                     a.acc_stride, VS)
   if (phase == 1) SPMF_FIN(1);
   else if (phase == 2) SPMF_FIN(2);
   else SPMF_FIN(0);

@@ -13,6 +13,9 @@ struct PrepArgs {
   int logt;       // log_transform: A' = w1*u (g(x) is data side), V' = eta*v^T
   const uint8_t* ctype;  // mixed likelihood: 1 = Bernoulli column (may be null)
   float* dbias;          // mixed likelihood: dense-kernel logit bias per column (may be null)
+  // S > 1: the launch covers S draws (gridDim.y); pointers are those of draw 0, draw s adds
+  // s * D*K to u / v, s * D to w, s * 2D to s, s * D*KP to Ap / Vp, s * D to phi, s * (KP+1) to dprep
+  int S;
 };
 void launch_prep(int KP, const PrepArgs& a, hipStream_t st);
 
@@ -30,6 +33,10 @@ struct RowArgs {
   int logt;            // log_transform rate r = exp(<z,V'>) - 1 + phi
   const float* gzd;    // mode 2: per-row dense term sum_d E_bd V'_d  [B,KP]
   const uint8_t* ctype;  // likelihood code 3 (mixed): column types
+  // S > 1 (mode 0 only): S draws per launch (gridDim.y); draw s adds s * D*KP to Ap / Vp, s * D to
+  // phi, s * (KP+1) to dprep, s * B*KP to z / gzs, s * dacc_stride to dacc
+  int S, D;
+  int64_t dacc_stride;
 };
 void launch_row_pass(int KP, const RowArgs& a, hipStream_t st);
 
@@ -47,6 +54,10 @@ struct ColArgs {
   const uint8_t* ctype;     // likelihood code 3 (mixed): column types
   const int32_t* item_mid;  // [n_panels] first item of the upper column half, or null
   int half_sel;             // 0 all items; 1 / 2: lower / upper column half only (needs item_mid)
+  // S > 1: S draws per launch (gridDim.y); draw s adds s * D*KP to Vp, s * D to phi, s * B*KP to
+  // z / gzs and s * acc_stride to gAp / gVp / gphi
+  int S;
+  int64_t B, acc_stride;
 };
 
 struct ExpdotArgs {
@@ -81,6 +92,8 @@ struct PackArgs {
   int KP;
   const double* dacc;
   float* tail;  // acc tail: 2*(kDaccHead+KP) floats
+  int S;        // draws (gridDim.y): draw s adds s * dacc_stride / s * acc_stride
+  int64_t dacc_stride, acc_stride;
 };
 void launch_pack(const PackArgs& a, hipStream_t st);
 void launch_zero(void* p, size_t bytes, hipStream_t st);   // zero fill as a kernel (see stats.hip)
@@ -100,6 +113,11 @@ struct FinishArgs {
   int logt;
   const uint8_t* ctype;  // likelihood code 3 (mixed): column types
   int Dh;                // column split of the accumulator layout (0 / D = none; multiple of 32)
+  // S > 1: S draws per launch (gridDim.y); draw s adds s * vstride[i] to params[i] / grads[i],
+  // s * acc_stride to acc, s * (KP+1) to dprep, s * 14 to parts, s to n_nonfinite
+  int S;
+  int64_t acc_stride;
+  int64_t vstride[12];
 };
 void launch_finish(int KP, const FinishArgs& a, int phase, hipStream_t st);
 

@@ -38,6 +38,18 @@ __global__ __launch_bounds__(256) void prep_kernel(int D, int K, const float* __
   __shared__ double red[16];
   const int t = threadIdx.x;
   const int d0 = blockIdx.x * TD;
+  {   // draw of this block (gridDim.y draws per launch)
+    const size_t sd = blockIdx.y;
+    u += sd * (size_t)D * K;
+    if (v) v += sd * (size_t)K * D;
+    if (w) w += sd * (size_t)D;
+    s += sd * (size_t)2 * D;
+    Ap += sd * (size_t)D * KP;
+    Vp += sd * (size_t)D * KP;
+    phi += sd * (size_t)D;
+    dprep += sd * (size_t)(KP + 1);
+    if (dbias) dbias += sd * (size_t)D;
+  }
   double phi_local = 0.0;
   if (t < TD) {
     const int d = d0 + t;
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(256) void prep_kernel(int D, int K, const float* __
 template <int KP>
 static void launch_prep_t(const PrepArgs& a, hipStream_t st) {
   const int nb = (a.D + TD - 1) / TD;
-  hipLaunchKernelGGL(prep_kernel<KP>, dim3(nb), dim3(256), 0, st, a.D, a.K, a.u, a.v, a.w, a.s,
+  hipLaunchKernelGGL(prep_kernel<KP>, dim3(nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, a.D, a.K, a.u, a.v, a.w, a.s,
                      a.eta, a.Ap, a.Vp, a.phi, a.dprep, a.logt, a.ctype, a.dbias);
 }
 

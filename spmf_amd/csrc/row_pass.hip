@@ -144,7 +144,17 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
     const float* __restrict__ Ap, const float* __restrict__ Vp, const float* __restrict__ phi,
     const double* __restrict__ dprep, float* __restrict__ z, float* __restrict__ gzs,
     double* __restrict__ dacc, int mode, const float* __restrict__ gzd,
-    const uint8_t* __restrict__ ctype) {
+    const uint8_t* __restrict__ ctype, int Dcols, int64_t dacc_stride) {
+  if (gridDim.y > 1) {   // S draws per launch: tables, outputs and accumulators of draw blockIdx.y
+    const size_t sd = blockIdx.y;
+    Ap += sd * (size_t)Dcols * KP;
+    Vp += sd * (size_t)Dcols * KP;
+    phi += sd * (size_t)Dcols;
+    dprep += sd * (size_t)(KP + 1);
+    z += sd * (size_t)B * KP;
+    gzs += sd * (size_t)B * KP;
+    dacc += sd * (size_t)dacc_stride;
+  }
   const bool encode_only = mode == 1;
   constexpr int LPN = KP / 4;
   RowCtx<KP, LIK> cx;
@@ -306,9 +316,9 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
   int64_t want = (a.B + 3) / 4;  // 4 waves (rows in flight) per 256-thread block
   int nb = (int)(want < 1 ? 1 : (want > ROW_MAX_BLOCKS ? ROW_MAX_BLOCKS : want));
 #define SPMF_ROW_LAUNCH(L_)                                                                    \
-  hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb), dim3(256), 0, st, a.B, a.row_ptr,    \
-                     a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, a.gzs, a.dacc, \
-                     a.mode, a.gzd, a.ctype)
+  hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, \
+                     a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, \
+                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride)
   if (a.logt == 3) SPMF_ROW_LAUNCH(3);
   else if (a.logt == 2) SPMF_ROW_LAUNCH(2);
   else if (a.logt == 1) SPMF_ROW_LAUNCH(1);

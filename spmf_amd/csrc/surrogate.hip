@@ -62,6 +62,31 @@ __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
   const SurVar v = T.v[blockIdx.y];
   const int base = blockIdx.x * (256 * kEPT);
   if (base >= v.n) return;   // block-uniform
+  // per-element quantities that do not depend on the draw (softplus, lgamma, logs are the
+  // expensive part): once, not once per draw
+  float c0[kEPT], c1[kEPT], c2[kEPT];
+  bool soft[kEPT];
+#pragma unroll
+  for (int e = 0; e < kEPT; ++e) {
+    const int i = base + e * 256 + threadIdx.x;
+    c0[e] = c1[e] = c2[e] = 0.f;
+    soft[e] = false;
+    if (i < v.n) {
+      const float t0 = v.t0[i], t1 = v.t1[i];
+      if (v.kind == 2) {
+        const float a = softplusf(t0), b = softplusf(t1);
+        c0[e] = a;
+        c1[e] = b;
+        c2[e] = a * logf(b) - lgammaf(a);       // draw-independent part of log q_y
+      } else {
+        const float sg = softplusf(t1);
+        c0[e] = t0;
+        c1[e] = sg;
+        c2[e] = -logf(sg) - 0.91893853320467274178f;
+      }
+      soft[e] = v.kind != 1 && !(v.ident && v.ident[i]);
+    }
+  }
   for (int s = 0; s < S; ++s) {
     double lq = 0.0;
     const float* __restrict__ nzp = v.noise + (size_t)s * v.ld;
@@ -70,20 +95,17 @@ __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
     for (int e = 0; e < kEPT; ++e) {
       const int i = base + e * 256 + threadIdx.x;
       if (i < v.n) {
-        const float t0 = v.t0[i], t1 = v.t1[i];
         const float nz = nzp[i];
         float y, l;
         if (v.kind == 2) {
-          const float a = softplusf(t0), b = softplusf(t1);
-          y = b / nz;
-          l = a * logf(b) - lgammaf(a) - (a + 1.f) * logf(y) - b / y;
+          y = c1[e] / nz;
+          l = c2[e] - (c0[e] + 1.f) * logf(y) - c1[e] / y;
         } else {
-          const float sg = softplusf(t1);
-          y = t0 + sg * nz;
-          l = -0.5f * nz * nz - logf(sg) - 0.91893853320467274178f;
+          y = c0[e] + c1[e] * nz;
+          l = -0.5f * nz * nz + c2[e];
         }
         float th = y;
-        if (v.kind != 1 && !(v.ident && v.ident[i])) {
+        if (soft[e]) {
           th = softplusf(y);
           l -= logsigmoidf_(y);
         }
