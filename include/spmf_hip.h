@@ -43,6 +43,12 @@
 extern "C" {
 #endif
 
+/* Every function below is exported; nothing else is (the library is built with
+ * -fvisibility=hidden). */
+#if defined(SPMF_BUILD)
+#pragma GCC visibility push(default)
+#endif
+
 #define SPMF_NVARS 12
 #define SPMF_NPARTS 14
 #define SPMF_PART_Z 12
@@ -113,6 +119,13 @@ typedef struct spmf_counts {
 
 int spmf_version(void);
 
+/* sizeof(spmf_counts) / sizeof(spmf_sur_var) / sizeof(spmf_adam_var) as this
+ * library was built: a binding (ctypes, cgo, JNI ...) asserts its own mirror of
+ * the struct against it before the first call. */
+size_t spmf_sizeof_counts(void);
+size_t spmf_sizeof_sur_var(void);
+size_t spmf_sizeof_adam_var(void);
+
 /* K = latent_dim, D = feature_dim (poisson.py:58,102-104). */
 int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out);
 void spmf_ctx_destroy(spmf_ctx* ctx);
@@ -146,8 +159,9 @@ int spmf_counts_stats(spmf_ctx* ctx, int64_t n_rows, const int32_t* row_ptr,
  * and eta[D] (eta_i, poisson.py:88-91,142-149; ones when unscaled).  Leaves
  * per-draw accumulators in the workspace:
  *   acc[S][acc_len] fp32 = [ gA'(D*KP) | gV'(D*KP) | gphi(D) | tail ]
- * where the tail carries the fp64 scalars (sum x log r, sum z^2, sum_b z_b,
- * non-finite count) as (hi,lo) float pairs so ONE fp32 sum-all-reduce of
+ * where the tail carries the fp64 scalars (sum x log r, sum z^2, non-finite
+ * count, dense sum, saturated count, one spare, sum_b z_b[KP]) as (hi,lo)
+ * float pairs so ONE fp32 sum-all-reduce of
  * acc over row shards finishes the reduction. */
 int spmf_data_pass(spmf_ctx* ctx, const spmf_counts* counts, int S,
                    const float* const params[SPMF_NVARS], const float* eta,
@@ -192,9 +206,12 @@ int spmf_data_pass_split(spmf_ctx* ctx, const spmf_counts* counts, int S,
  *   (fp32) and holds d(x + z + prior_weight * sum of prior parts)/d(param):
  *   prior_weight = 1 is the reference's energy (poisson.py:577 passes the
  *   literal 1.); a minibatch driver passes B/N.
- *   n_nonfinite[S] (fp64, may be NULL): stored cells whose log-pmf was not
- *   finite; the sparse fast path assumes 0 (poisson.py:606-616 is then the
- *   identity). */
+ *   n_nonfinite[2*S] (fp64, may be NULL): [s] = stored cells of draw s whose
+ *   log-pmf was not finite; the sparse fast path assumes 0 (poisson.py:606-616
+ *   is then the identity).  [S+s] = cells of draw s (all B*D of them) whose
+ *   log_transform exponent exceeded 70 and was saturated there: fp32 cannot
+ *   hold exp(y) beyond y ~ 88 where the fp64 reference still can, so the decoder
+ *   is evaluated as exp(min(y,70)) - 1; 0 means the decoder was exact. */
 int spmf_finish(spmf_ctx* ctx, int S, int64_t n_rows_global,
                 double lgamma_sum_global, double prior_weight,
                 const float* const params[SPMF_NVARS], const float* eta,
@@ -212,10 +229,12 @@ int spmf_elbo_fwd_bwd(spmf_ctx* ctx, const spmf_counts* counts, int S,
 int spmf_encode(spmf_ctx* ctx, const spmf_counts* counts, const float* u,
                 const float* s, const float* eta, float* z_out, void* stream);
 
-/* log_likelihood_components (poisson.py:156-184) for ONE draw, dense like the
- * reference: rate[B,D] and the Poisson log-pmf ll[B,D] of every cell (fp32,
- * row-major).  Output bound (8 B per cell); not on the hot path.  Serves the
- * class surface and the non-finite replacement rule. */
+/* log_likelihood_components (poisson.py:156-184, bernoulli.py:126-155) for ONE
+ * draw, dense like the reference: rate[B,D] and the log-pmf ll[B,D] of every
+ * cell (fp32, row-major): Poisson(rate), or for a Bernoulli context / the
+ * Bernoulli columns of a mixed one rate = the logit and ll = x*logit -
+ * softplus(logit).  Output bound (8 B per cell); not on the hot path.  Serves
+ * the class surface and the non-finite replacement rule. */
 int spmf_dense_ll(spmf_ctx* ctx, const spmf_counts* counts, const float* u,
                   const float* v, const float* w, const float* s,
                   const float* eta, float* rate_out, float* ll_out, void* stream);
@@ -228,6 +247,29 @@ int spmf_dense_ll(spmf_ctx* ctx, const spmf_counts* counts, const float* u,
  *           io[2] += number of non-finite cells. */
 int spmf_nonfinite_reduce(spmf_ctx* ctx, int64_t n, const float* ll, int pass,
                           double* io, void* stream);
+
+/* Third reduction of the rule: io[3] = min(io[3], index_base + i) over the
+ * cells i of ll[0..n) whose value equals the global minimum io[0] (initialise
+ * io[3] = +inf): the linear index (draw * B*D + row * D + column, built by the
+ * caller through index_base) of the minimum's cell, where d(min_val) flows. */
+int spmf_nonfinite_argmin(spmf_ctx* ctx, int64_t n, const float* ll, double index_base,
+                          double* io, void* stream);
+
+/* Apply the rule (poisson.py:606-616) to the packed accumulators that
+ * spmf_data_pass left for S draws of `counts`, VALUE AND GRADIENT, so that a
+ * following spmf_finish returns the energy the reference computes when stored
+ * cells have a non-finite log-pmf (rate 0 under a positive count):
+ *   'x'_s  += nnf_s * (io[0] - 10) + sum over those cells of lgamma(x+1)
+ *   draw s* (the draw of the minimum's cell io[3]): gA' / gV' / gphi gain
+ *   (sum_s nnf_s) * d ll(cell) / d theta   -- clip is the identity on finite
+ *   cells, replaced cells are worth min_val, whose derivative is that of the
+ *   minimum's cell (tf.reduce_min).
+ * io = double[4]: [0] global minimum over all S*B*D cells (spmf_nonfinite_reduce
+ * pass 0 over spmf_dense_ll output), [3] its cell (spmf_nonfinite_argmin).
+ * Single shard only: with row shards the minimum needs its own (min) all-reduce. */
+int spmf_nonfinite_patch(spmf_ctx* ctx, const spmf_counts* counts, int S,
+                         const float* const params[SPMF_NVARS], const float* eta,
+                         const double* io, void* stream);
 
 /* ---- VI step around the energy: surrogate posterior and optimiser ------- */
 /* One latent variable of the mean-field surrogate (poisson.py:403-569).
@@ -316,6 +358,10 @@ const float* spmf_gz_ptr(const spmf_ctx* ctx);
  * (log_transform only, else 0).  For bench.py's roofline. */
 int spmf_ctx_enable_timing(spmf_ctx* ctx, int on);
 int spmf_last_timing(spmf_ctx* ctx, float* ms6);
+
+#if defined(SPMF_BUILD)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

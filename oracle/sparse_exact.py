@@ -134,8 +134,12 @@ def prior_term(p, u_tau_scale, s_tau_scale, decay):
 # row-sharded all-reduce path can be tested on CPU with gloo).
 # Layout (include/spmf_hip.h, spmf_data_pass):
 #   acc = [ gA'(D*KP) | gV'(D*KP) | gphi(D) | tail ],  KP = K padded to 4,8,..
-#   tail = (hi,lo) float pairs of [sum x log r, sum z^2, nonfinite, 0, zsum[KP]]
+#   tail = (hi,lo) float pairs of [sum x log r, sum z^2, nonfinite, dense sum,
+#                                  saturated cells, 0, zsum[KP]]
 # --------------------------------------------------------------------------
+TAIL_HEAD = 6     # scalars in front of zsum (spmf_amd/csrc/common.h kDaccHead)
+
+
 def padded_k(K):
     kp = 4
     while kp < K:
@@ -167,7 +171,7 @@ def shard_accumulators(X, eta, xi_global, scale_rows, u, v, w, s):
     gAp = np.zeros((D, KP)); gAp[:, :K] = X.T @ (gz * xi[:, None])
     gphi = np.asarray(C.sum(0)).reshape(D)
     zsum = np.zeros(KP); zsum[:K] = z.sum(0)
-    scal = np.concatenate([[(X.data * np.log(r)).sum(), (z * z).sum(), 0.0, 0.0], zsum])
+    scal = np.concatenate([[(X.data * np.log(r)).sum(), (z * z).sum(), 0.0, 0.0, 0.0, 0.0], zsum])
     hi = scal.astype(np.float32)
     lo = (scal - hi.astype(np.float64)).astype(np.float32)
     tail = np.stack([hi, lo], 1).reshape(-1)
@@ -185,7 +189,7 @@ def finish_from_acc(acc, B_global, lgamma_sum, eta, u, v, w, s):
     gVp = acc[D * KP:2 * D * KP].reshape(D, KP)[:, :K]
     gphi_acc = acc[2 * D * KP:2 * D * KP + D]
     tail = acc[2 * D * KP + D:].reshape(-1, 2).sum(1)
-    llx, zsq, zsum = tail[0], tail[1], tail[4:4 + K]
+    llx, zsq, zsum = tail[0], tail[1], tail[TAIL_HEAD:TAIL_HEAD + K]
     T = s[0] + s[1]
     w1, w2 = s[0] / T, s[1] / T
     Vp = (v * eta[None, :]).T

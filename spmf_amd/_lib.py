@@ -67,6 +67,9 @@ class AdamVar(C.Structure):
 #: every symbol include/spmf_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "spmf_version": (C.c_int, []),
+    "spmf_sizeof_counts": (C.c_size_t, []),
+    "spmf_sizeof_sur_var": (C.c_size_t, []),
+    "spmf_sizeof_adam_var": (C.c_size_t, []),
     "spmf_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint,
                                   C.POINTER(C.c_void_p)]),
     "spmf_ctx_destroy": (None, [C.c_void_p]),
@@ -91,6 +94,10 @@ SIGNATURES = {
     "spmf_dense_ll": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct)] + [C.c_void_p] * 8),
     "spmf_nonfinite_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p]),
+    "spmf_nonfinite_argmin": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
+                                        C.c_void_p, C.c_void_p]),
+    "spmf_nonfinite_patch": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int, PtrArray,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "spmf_surrogate_fwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "spmf_surrogate_bwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
@@ -133,6 +140,12 @@ def load():
         fn = getattr(lib, name)        # AttributeError -> missing export
         fn.restype = res
         fn.argtypes = args
+    # the ctypes mirrors must have the library's own struct sizes
+    for fn, st in ((lib.spmf_sizeof_counts, CountsStruct), (lib.spmf_sizeof_sur_var, SurVar),
+                   (lib.spmf_sizeof_adam_var, AdamVar)):
+        if fn() != C.sizeof(st):
+            raise SpmfError(f"{st.__name__}: ctypes mirror is {C.sizeof(st)} bytes, the library's "
+                            f"struct {fn()} (include/spmf_hip.h and spmf_amd/_lib.py disagree)")
     _lib = lib
     return lib
 

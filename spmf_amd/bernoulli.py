@@ -8,7 +8,9 @@ Differences from PoissonFactorization, as in the reference:
 The stored-cell term x*logit is linear (sparse row/column passes without any
 division or log); the sum over ALL cells of softplus(logit) and its gradients
 run on the f32 matrix cores (dense.hip, sigmoid/softplus variant).
-Only the linear decoder is built (log_transform=True raises).
+Only the linear decoder is built (log_transform=True raises).  The dense
+per-cell outputs of log_likelihood_components (:126-155) come from
+spmf_dense_ll (dense_ll.hip).
 """
 from __future__ import annotations
 
@@ -52,6 +54,6 @@ class BernoulliFactorization(PoissonFactorization):
         self.bijectors["v"] = "identity"
         self.bijectors["w"] = "identity"
 
-    def log_likelihood_components(self, *args, **kwargs):
-        raise NotImplementedError(
-            "dense per-cell Bernoulli outputs are not built in the HIP path")
+    # log_likelihood_components (bernoulli.py:126-155) is the base class method: the
+    # context's likelihood code makes spmf_dense_ll return the logits as 'rate' and
+    # x*logit - softplus(logit) as 'log_likelihood'.

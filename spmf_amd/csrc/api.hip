@@ -111,7 +111,10 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
 
 extern "C" {
 
-int spmf_version(void) { return 1; }
+int spmf_version(void) { return 2; }
+size_t spmf_sizeof_counts(void) { return sizeof(spmf_counts); }
+size_t spmf_sizeof_sur_var(void) { return sizeof(spmf_sur_var); }
+size_t spmf_sizeof_adam_var(void) { return sizeof(spmf_adam_var); }
 
 int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   if (!out) return SPMF_E_ARG;
@@ -546,9 +549,9 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
     const float* s, const float* eta, float* rate_out, float* ll_out, void* stream) {
   if (!c || !u || !v || !w || !s || !eta || !rate_out || !ll_out) return fail(c, SPMF_E_ARG,
       "dense_ll: bad arguments");
-  if (c->flags & (SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) return fail(c, SPMF_E_UNSUPPORTED,
-      "dense_ll: Bernoulli per-cell outputs are not built");
-  const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : 0;
+  const int lik = likelihood_code(c);
+  if (lik == 3 && !c->ctype) return fail(c, SPMF_E_ARG, "dense_ll: spmf_ctx_set_column_types was not called");
+  const int logt = lik == 1 ? 1 : 0;
   int rc = check_counts(c, ct);
   if (!rc && logt && ct->nnz > 0 && !ct->gval) rc = fail(c, SPMF_E_ARG, "dense_ll: log_transform needs counts.gval");
   if (rc) return rc;
@@ -563,7 +566,8 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
       (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs,
       c->dacc, 1, logt, nullptr, nullptr};
   launch_row_pass(c->KP, ra, st);
-  DenseLLArgs da{ct->n_rows, c->D, logt, c->z, c->Vp, c->phi, ct->row_ptr, ct->col_idx, ct->val, rate_out, ll_out};
+  DenseLLArgs da{ct->n_rows, c->D, lik, c->z, c->Vp, c->phi, c->ctype, ct->row_ptr, ct->col_idx, ct->val, rate_out,
+      ll_out};
   launch_dense_ll(c->KP, da, st);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;
@@ -574,6 +578,33 @@ int spmf_nonfinite_reduce(spmf_ctx* c, int64_t n, const float* ll, int pass, dou
       "nonfinite_reduce: bad arguments");
   if (n == 0) return SPMF_OK;
   launch_nonfinite(n, ll, pass, io, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_nonfinite_argmin(spmf_ctx* c, int64_t n, const float* ll, double index_base, double* io, void* stream) {
+  if (!c || !ll || !io || n < 0 || !(index_base >= 0.0)) return fail(c, SPMF_E_ARG, "nonfinite_argmin: bad arguments");
+  if (n == 0) return SPMF_OK;
+  launch_nonfinite_argmin(n, ll, index_base, io, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_nonfinite_patch(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS],
+    const float* eta, const double* io, void* stream) {
+  if (!c || !params || !eta || !io || S < 1) return fail(c, SPMF_E_ARG, "nonfinite_patch: bad arguments");
+  int rc = check_counts(c, ct);
+  if (rc) return rc;
+  if (!c->acc || c->ws_S < S || c->ws_rows != ct->n_rows) return fail(c, SPMF_E_ARG,
+      "nonfinite_patch: no data pass over this batch and S precedes it");
+  for (int i : {0, 1, 2, 7})
+    if (!params[i]) return fail(c, SPMF_E_ARG, "nonfinite_patch: params v,w,u,s must be non-null");
+  const int logt = likelihood_code(c);
+  if (logt == 1 && ct->nnz > 0 && !ct->gval) return fail(c, SPMF_E_ARG, "nonfinite_patch: log_transform needs counts.gval");
+  NfPatchArgs a{c->D, c->K, logt, ct->row_ptr, ct->col_idx, ct->val,
+      (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, params[2], params[0], params[1], params[7], eta,
+      c->ctype, c->acc, (int64_t)acc_len(c->D, c->KP), c->Dh > 0 ? c->Dh : c->D, io, ct->n_rows, S};
+  launch_nonfinite_patch(c->KP, a, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;
 }

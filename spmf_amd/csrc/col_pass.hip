@@ -155,10 +155,14 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
             gph += xv[j];
           } else {
             const float y = group_sum<LPN>(dot4(zz[j], vp));
-            const float ey = LIK == 1 ? expf(y) : 1.f;
+            const float ey = LIK == 1 ? expf(fminf(y, kYSat)) : 1.f;   // saturating: common.h kYSat
             const float r = (LIK == 1 ? ey - 1.f : y) + ph;
-            // r <= 0 / NaN cells were counted by the row pass; +inf gives 0
-            const float xr = r > 0.f ? xv[j] * __builtin_amdgcn_rcpf(r) : 0.f;
+            // r <= 0 / NaN cells were counted by the row pass; the replacement rule
+            // (poisson.py:606-616) drops such a cell whole, so it gets weight +1 to cancel
+            // the -1 that the closed-form sum over ALL cells gives it (finish kernel)
+            // (padded slots carry x = 0 and must stay weightless)
+            const float xr = (r > 0.f && r < INFINITY) ? xv[j] * __builtin_amdgcn_rcpf(r)
+                                                       : (xv[j] > 0.f ? 1.f : 0.f);
             gV = fma4(LIK == 1 ? xr * ey : xr, zz[j], gV);
             gA = fma4(gv[j], gg[j], gA);
             gph += xr;

@@ -13,8 +13,17 @@ constexpr double kLog2 = 0.69314718055994530942;
 
 // Layout of the fp64 scalar block a data pass accumulates per draw.
 //   [0] sum_nnz x*log r   [1] sum z^2   [2] non-finite stored cells
-//   [3] reserved          [4 .. 4+KP)   sum_b z_b
-constexpr int kDaccHead = 4;
+//   [3] dense sum (sum E / sum softplus)   [4] saturated cells (log_transform)
+//   [5] reserved          [6 .. 6+KP)   sum_b z_b
+constexpr int kDaccHead = 6;
+// log_transform decoder (poisson.py:52-53): f(y) = exp(y) - 1 is evaluated as
+// exp(min(y, kYSat)) - 1.  fp32 cannot hold exp(y) beyond y ~ 88.7 (the fp64
+// reference overflows at 709); saturating keeps every sum and gradient of a
+// step finite (70: D * e^70 * |V'| stays far below FLT_MAX for any supported D),
+// so a batch with a few runaway cells still trains -- its gradient pushes their
+// exponents down -- instead of being skipped.  The cells with y > kYSat are
+// counted (dacc[4]); while that count is 0 the decoder is exact.
+constexpr float kYSat = 70.0f;
 // the block sums land in one of kDaccRep replicas (blockIdx % kDaccRep) so the
 // fp64 atomics of thousands of blocks do not serialise on 4+KP addresses;
 // the pack kernel folds the replicas.

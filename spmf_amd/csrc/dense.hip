@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
       for (int i = 0; i < 16; ++i) acc[b][m][i] = 0.f;
   }
   double es = 0.0;
+  float satc = 0.f;       // ACT 0: cells whose exponent was saturated (exact: < 2^24 per lane)
 
   // stage loader: 256 threads move the QT*KD floats of a tile in QT/32 parts
   // (one 32-row part per sub-tile of the compute loop: only PER4 registers live)
@@ -230,14 +231,19 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int q = q0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float e = (q < NQ && p < NP) ? __expf(xcur[b][i]) : 0.f;
+            const bool in = q < NQ && p < NP;
+            const float xv = xcur[b][i];
+            const float e = in ? __expf(fminf(xv, kYSat)) : 0.f;   // saturating: common.h kYSat
+            satc += (in && xv > kYSat) ? 1.f : 0.f;
             xcur[b][i] = e;
             part += e;
           }
         } else {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const float e = __expf(xcur[b][i]);
+            const float xv = xcur[b][i];
+            const float e = __expf(fminf(xv, kYSat));
+            satc += xv > kYSat ? 1.f : 0.f;
             xcur[b][i] = e;
             part += e;
           }
@@ -288,6 +294,10 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
   if (esum) {
     const double tot = block_sum(es, red);
     if (t == 0) atomicAdd(esum, tot);
+    if (ACT == 0) {                                       // esum[1] = dacc[4]: saturated cells
+      const double ts = block_sum((double)satc, red);
+      if (t == 0 && ts != 0.0) atomicAdd(esum + 1, ts);
+    }
   }
 }
 

@@ -378,7 +378,10 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     }
     atomicAdd(&parts[13], llx - (logt == 2 ? 0.0 : lgamma_sum) - sum_r);
     atomicAdd(&parts[12], Bglob * (double)K * kHalfLog2OverPi - 0.5 * zsq);
-    if (nnf_out) *nnf_out = unpack(tail, 2);
+    if (nnf_out) {
+      nnf_out[0] = unpack(tail, 2);
+      nnf_out[gridDim.y] = unpack(tail, 4);     // [S + s]: saturated cells (log_transform)
+    }
   }
 }
 

@@ -76,8 +76,9 @@ void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st);
 
 struct DenseLLArgs {
   int64_t B;
-  int D, logt;
+  int D, logt;       // logt = likelihood code 0..3
   const float *z, *Vp, *phi;
+  const uint8_t* ctype;
   const int32_t* row_ptr;
   const int32_t* col;
   const float* val;
@@ -86,6 +87,24 @@ struct DenseLLArgs {
 void launch_dense_ll(int KP, const DenseLLArgs& a, hipStream_t st);
 // pass 0: io[0] = min(io[0], finite ll); pass 1: io[1] += clipped/replaced sum, io[2] += #non-finite
 void launch_nonfinite(int64_t n, const float* ll, int pass, double* io, hipStream_t st);
+void launch_nonfinite_argmin(int64_t n, const float* ll, double index_base, double* io, hipStream_t st);
+struct NfPatchArgs {
+  int D, K, logt;
+  const int32_t* row_ptr;
+  const int32_t* col;
+  const float* val;
+  const float* row_scale;          // may be null
+  const float *u, *v, *w, *s;      // draw 0; draw q adds q * D*K / K*D / D / 2D
+  const float* eta;
+  const uint8_t* ctype;
+  float* acc;                      // packed accumulators of draw 0
+  int64_t acc_stride;
+  int Dh;                          // column split of the accumulator layout (D = none)
+  const double* io;                // [0] global minimum, [3] linear index of its cell
+  int64_t rows_batch;
+  int S;
+};
+void launch_nonfinite_patch(int KP, const NfPatchArgs& a, hipStream_t st);
 void launch_col_pass(int KP, const ColArgs& a, hipStream_t st);
 
 struct PackArgs {

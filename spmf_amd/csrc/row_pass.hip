@@ -74,7 +74,7 @@ struct RowCtx {
 
   // rates, log-likelihood and gz partial over one chunk
   __device__ __forceinline__ void sweep2(int c, float x, int nchunk, const float4& z,
-                                         float4& gz, float& ll, double& nnf) const {
+                                         float4& gz, float& ll, double& nnf, double& nlg) const {
     float4 vv[LPN];
     float rmine = 0.f;
 #pragma unroll
@@ -112,13 +112,20 @@ struct RowCtx {
         }
       } else {
         // linear decoder: r = <z,V'> + phi; log_transform: r = exp(<z,V'>) - 1 + phi
-        const float ey = LIK == 1 ? expf(rmine) : 1.f;
+        const float ey = LIK == 1 ? expf(fminf(rmine, kYSat)) : 1.f;
         const float r = (LIK == 1 ? ey - 1.f : rmine) + phi[cs];
         if (r > 0.f && r < INFINITY) {
           ll = fmaf(xs, logf(r), ll);
           cc = xs * ey * __builtin_amdgcn_rcpf(r);   // d(x log r)/d<z,V'>
         } else {
+          // the replacement rule (poisson.py:606-616) swaps the WHOLE log-pmf of this
+          // cell for min-10: its lgamma(x+1), part of the pre-summed constant, has to
+          // be taken back out (spmf_nonfinite_patch)
           nnf += 1.0;
+          nlg += (double)lgammaf(xs + 1.f);
+          // ... and its share of the closed-form / dense "-sum over all cells of r"
+          // cancelled: weight +1 here against the -1 every cell gets there
+          cc = ey;
         }
       }
     }
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
   if (!encode_only && (mode != 2 || LIK == 3 || !gzd))
     veta4 = make_float4((float)dprep[sub * 4 + 0], (float)dprep[sub * 4 + 1],
                         (float)dprep[sub * 4 + 2], (float)dprep[sub * 4 + 3]);
-  double ll_acc = 0.0, zsq_acc = 0.0, nnf_acc = 0.0;
+  double ll_acc = 0.0, zsq_acc = 0.0, nnf_acc = 0.0, nlg_acc = 0.0;
   float4 zsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // Software pipeline across rows: the pointers of row b+2*nwaves and the first
@@ -231,8 +238,8 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
         zacc = gather4<LPN>(z, (int)b, sub);
       }
       if (!encode_only) {
-      cx.sweep2(c0, x0, n0, zacc, gz, llrow, nnf_acc);
-      if (n1 > 0) cx.sweep2(c1, x1, n1, zacc, gz, llrow, nnf_acc);
+      cx.sweep2(c0, x0, n0, zacc, gz, llrow, nnf_acc, nlg_acc);
+      if (n1 > 0) cx.sweep2(c1, x1, n1, zacc, gz, llrow, nnf_acc, nlg_acc);
       }
     } else {
       // ---- long row: stream the row twice (second read is L2 served) -----
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
         const int idx = base + lane;
         const int c = idx < end ? col[idx] : 0;
         const float x = idx < end ? val[idx] : 0.f;
-        cx.sweep2(c, x, min(64, end - base), zacc, gz, llrow, nnf_acc);
+        cx.sweep2(c, x, min(64, end - base), zacc, gz, llrow, nnf_acc, nlg_acc);
       }
     }
     // rotate the pipeline registers
@@ -296,11 +303,13 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
   const double ll_b = block_sum(ll_acc, red);
   const double zq_b = block_sum(zsq_acc, red);
   const double nf_b = block_sum(nnf_acc, red);
+  const double nl_b = block_sum(nlg_acc, red);
   dacc += (size_t)(blockIdx.x % kDaccRep) * (kDaccHead + KP);
   if (threadIdx.x == 0) {
     atomicAdd(&dacc[0], ll_b);
     atomicAdd(&dacc[1], zq_b);
     if (nf_b != 0.0) atomicAdd(&dacc[2], nf_b);
+    if (nl_b != 0.0) atomicAdd(&dacc[5], nl_b);
   }
   __syncthreads();
   if (threadIdx.x < KP) {

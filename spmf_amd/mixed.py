@@ -59,6 +59,7 @@ class MixedFactorization(PoissonFactorization):
         self.bijectors["v"] = "softplus | identity (per column)"
         self.bijectors["w"] = "softplus | identity (per column)"
 
-    def log_likelihood_components(self, *args, **kwargs):
-        raise NotImplementedError(
-            "dense per-cell outputs are not built for the mixed likelihood")
+    def _after_aux_ctx(self, h):
+        self._handle()                       # makes sure the column-type vector exists
+        _lib.check(h, _lib.load().spmf_ctx_set_column_types(h, self._ctype_dev.data_ptr()),
+                   "spmf_ctx_set_column_types")

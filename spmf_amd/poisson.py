@@ -103,29 +103,53 @@ class PoissonFactorization:
     # ------------------------------------------------------------------
     # native context
     # ------------------------------------------------------------------
+    def _new_ctx(self):
+        if self.device.type != "cuda":
+            raise SpmfError(
+                "the HIP hot path needs a GPU device (no CPU fallback)")
+        lib = _lib.load()
+        flags = (_lib.FLAG_SCALE_ROWS if self.scale_rows else 0) | (
+            _lib.FLAG_LOG_TRANSFORM if self.log_transform else 0) | self._likelihood_flag
+        h = C.c_void_p()
+        rc = lib.spmf_ctx_create(self.device.index or 0, int(self.latent_dim),
+                                 int(self.feature_dim), flags, C.byref(h))
+        if rc != 0:
+            raise SpmfError(
+                f"spmf_ctx_create failed (rc={rc}); latent_dim must be in "
+                f"1..64, got K={self.latent_dim}, D={self.feature_dim}")
+        _lib.check(h, lib.spmf_ctx_set_prior(
+            h, float(self.u_tau_scale), float(self.s_tau_scale),
+            float(self.symmetry_breaking_decay)), "spmf_ctx_set_prior")
+        return h
+
     def _handle(self):
         if self._ctx is None:
-            if self.device.type != "cuda":
-                raise SpmfError(
-                    "the HIP hot path needs a GPU device (no CPU fallback)")
-            lib = _lib.load()
-            flags = (_lib.FLAG_SCALE_ROWS if self.scale_rows else 0) | (
-                _lib.FLAG_LOG_TRANSFORM if self.log_transform else 0) | self._likelihood_flag
-            h = C.c_void_p()
-            rc = lib.spmf_ctx_create(self.device.index or 0, int(self.latent_dim),
-                                     int(self.feature_dim), flags, C.byref(h))
-            if rc != 0:
-                raise SpmfError(
-                    f"spmf_ctx_create failed (rc={rc}); latent_dim must be in "
-                    f"1..64, got K={self.latent_dim}, D={self.feature_dim}")
-            self._ctx = h
-            _lib.check(h, lib.spmf_ctx_set_prior(
-                h, float(self.u_tau_scale), float(self.s_tau_scale),
-                float(self.symmetry_breaking_decay)), "spmf_ctx_set_prior")
+            self._ctx = self._new_ctx()
             if getattr(self, "column_split", 0):
-                _lib.check(h, lib.spmf_ctx_set_column_split(h, int(self.column_split)),
-                           "spmf_ctx_set_column_split")
+                _lib.check(self._ctx, _lib.load().spmf_ctx_set_column_split(
+                    self._ctx, int(self.column_split)), "spmf_ctx_set_column_split")
         return self._ctx
+
+    def _aux(self, rows):
+        """A second context with its own workspace for the dense fallback of the
+        replacement rule: its launches must not re-carve the main workspace, whose
+        accumulators the patch + finish that follow still need."""
+        lib = _lib.load()
+        if getattr(self, "_aux_ctx", None) is None:
+            self._aux_ctx = self._new_ctx()
+            self._aux_ws = None
+            self._after_aux_ctx(self._aux_ctx)
+        need = lib.spmf_workspace_bytes(self._aux_ctx, int(rows), 1)
+        if self._aux_ws is None or self._aux_ws.numel() < need + 256:
+            self._aux_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            off = (-self._aux_ws.data_ptr()) % 256
+            _lib.check(self._aux_ctx, lib.spmf_ctx_set_workspace(
+                self._aux_ctx, self._aux_ws.data_ptr() + off, self._aux_ws.numel() - off),
+                "spmf_ctx_set_workspace")
+        return self._aux_ctx
+
+    def _after_aux_ctx(self, h):
+        """Hook for subclasses that configure a context further (column types)."""
 
     def enable_column_split(self, Dh=None):
         """Multi-GPU overlap (include/spmf_hip.h, spmf_ctx_set_column_split): lay
@@ -146,9 +170,10 @@ class PoissonFactorization:
 
     def __del__(self):
         try:
-            if self._ctx is not None:
-                _lib.load().spmf_ctx_destroy(self._ctx)
-                self._ctx = None
+            for name in ("_ctx", "_aux_ctx"):
+                if getattr(self, name, None) is not None:
+                    _lib.load().spmf_ctx_destroy(getattr(self, name))
+                    setattr(self, name, None)
         except Exception:
             pass
 
@@ -166,8 +191,16 @@ class PoissonFactorization:
     def _eta_device(self):
         """eta_i as a [D] fp32 device vector (ones when unscaled)."""
         e = self.eta_i
-        key = id(e) if not isinstance(e, (int, float)) else float(e)
-        if self._eta_key != key or self._eta_dev is None:
+        scalar = isinstance(e, (int, float))
+        # arrays are compared by identity against a held reference (an id() alone
+        # can be recycled once the old array is freed)
+        if scalar:
+            same = isinstance(self._eta_key, float) and self._eta_key == float(e)
+        else:
+            same = self._eta_key is e
+        same = same and self._eta_dev is not None
+        key = float(e) if scalar else e
+        if not same:
             D = self.feature_dim
             if isinstance(e, (int, float)):
                 t = torch.full((D,), float(e), dtype=torch.float32, device=self.device)
@@ -255,7 +288,8 @@ class PoissonFactorization:
     # ------------------------------------------------------------------
     # the hot path
     # ------------------------------------------------------------------
-    def energy_and_grads(self, data, params, all_reduce=None, prior_weight=1.0):
+    def energy_and_grads(self, data, params, all_reduce=None, prior_weight=1.0,
+                         nonfinite="count"):
         """All 14 energy parts (poisson.py:582-621) and d(sum of parts)/d(param)
         for every one of the 12 variables, for S draws, on the GPU.
 
@@ -266,7 +300,16 @@ class PoissonFactorization:
         the data pass and the finish kernel -- the single collective of the
         row-sharded multi-GPU path; it must also return the global
         (rows, lgamma_sum) via its return value or None for single shard.
+
+        ``nonfinite``: what happens when stored cells have a non-finite
+        log-pmf (rate 0 under a positive count).  "count" (default, no host
+        read-back): they are left out of 'x' and its gradient and counted in
+        n_nonfinite.  "rule": the reference's replacement rule
+        (poisson.py:606-616), value AND gradient -- one host read of the count
+        per call, the dense fallback only when it is non-zero (single shard).
         """
+        if nonfinite not in ("count", "rule"):
+            raise ValueError("nonfinite must be 'count' or 'rule'")
         lib, h = _lib.load(), self._handle()
         sc, cs = self._batch(data)
         S, P = self._pack_params(params)
@@ -277,7 +320,9 @@ class PoissonFactorization:
         grads = {n: torch.empty_like(P[n]) for n in VAR_ORDER}
         gout = _lib.PtrArray(*[grads[n].data_ptr() for n in VAR_ORDER])
         parts = torch.empty(S, _lib.NPARTS, dtype=torch.float64, device=self.device)
-        nnf = torch.empty(S, dtype=torch.float64, device=self.device)
+        # [0:S] non-finite stored cells, [S:2S] saturated cells (log_transform)
+        nnf2 = torch.empty(2 * S, dtype=torch.float64, device=self.device)
+        nnf = nnf2[:S]
         rows_g, lg_g = cs.n_rows, cs.lgamma_sum
         split = (all_reduce is not None and S == 1 and getattr(self, "column_split", 0) > 0
                  and sc.col_split == self.column_split and hasattr(all_reduce, "start"))
@@ -318,24 +363,30 @@ class PoissonFactorization:
         _lib.check(h, lib.spmf_finish(h, S, int(rows_g), float(lg_g), float(prior_weight), pin, eta.data_ptr(),
                                       parts.data_ptr(), gout, nnf.data_ptr(), stream),
                    "spmf_finish")
+        if nonfinite == "rule" and float(nnf.sum()) > 0.0:
+            if all_reduce is not None:
+                raise NotImplementedError(
+                    "the non-finite replacement rule needs a min all-reduce across row "
+                    "shards: single shard only (n_nonfinite reports the cells)")
+            io = self._nonfinite_scan(sc, cs, data, S, P)
+            _lib.check(h, lib.spmf_nonfinite_patch(h, C.byref(cs), S, pin, eta.data_ptr(),
+                                                   io.data_ptr(), stream), "spmf_nonfinite_patch")
+            _lib.check(h, lib.spmf_finish(h, S, int(rows_g), float(lg_g), float(prior_weight), pin,
+                                          eta.data_ptr(), parts.data_ptr(), gout, nnf.data_ptr(),
+                                          stream), "spmf_finish")
         pd = {n: parts[:, i] for i, n in enumerate(PART_ORDER)}
         self._last_parts = parts                      # [S,14] block (spmf_vi_gate input)
+        self.last_saturated = nnf2[S:]                # cells with exp() saturated (common.h kYSat)
         return pd, grads, nnf
 
     def unormalized_log_prob_parts(self, data, prior_weight=1., **params):
         """Energy function (poisson.py:582-621): dict of [S] tensors keyed
-        v,w,u,...,z,x.  Raises if a stored cell has a non-finite log-pmf: the
-        sparse fast path covers the case where the clip/replace rule
-        (:606-616) is the identity."""
+        v,w,u,...,z,x.  When a stored cell has a non-finite log-pmf the
+        clip/replace rule (:606-616) is applied (dense fallback); otherwise it
+        is the identity and the sparse fast path is the whole evaluation."""
         squeeze = params["u"].dim() == 2 if isinstance(params.get("u"), torch.Tensor) \
             else np.ndim(params["u"]) == 2
-        parts, _, nnf = self.energy_and_grads(data, params)
-        if float(nnf.sum()) != 0.0 or not bool(torch.isfinite(parts["x"]).all()):
-            # some cell's log-pmf is not finite: the sparse fast path does not
-            # apply; evaluate the replacement rule (poisson.py:606-616) over
-            # the dense per-cell log-pmf (values only).
-            parts = dict(parts)
-            parts["x"] = self._nonfinite_rule_x(data, params)
+        parts, _, nnf = self.energy_and_grads(data, params, nonfinite="rule")
         out = {}
         for k, v in parts.items():
             if k not in ("x", "z"):
@@ -404,37 +455,47 @@ class PoissonFactorization:
                 "se": float(2.0 * torch.sqrt(n * elpd_i.var(unbiased=True))),
                 "lppd": float(lppd_i.sum()), "pwaic": float(pwaic_i.sum())}
 
-    def _nonfinite_rule_x(self, data, params):
-        """'x' part under the non-finite replacement rule (poisson.py:606-616)
-        from the dense per-cell log-pmf: global min over [S,B,D] finite cells,
-        clip to [min-10, 0], non-finite cells -> min-10.  Values only."""
-        lib, h = _lib.load(), self._handle()
-        sc, cs = self._batch(data)
-        S, P = self._pack_params(params, names=("s", "u", "v", "w"))
-        self._ensure_workspace(cs.n_rows, 1)
+    def _nonfinite_scan(self, sc, cs, data, S, P, max_cells=1 << 27):
+        """Dense part of the replacement rule (poisson.py:606-616): the minimum
+        of the per-cell log-pmf over ALL S*B*D cells (finite ones; the
+        reference's where(finite, ll, 0) also puts a 0 into it) and the linear
+        index of the cell that attains it.  Evaluated by spmf_dense_ll over row
+        chunks of whole panels (at most ``max_cells`` cells at a time), so the
+        dense [B,D] block never has to exist.  Returns io = double[4] on the
+        device: [0] minimum, [3] its cell (+inf if the minimum is the 0)."""
+        lib = _lib.load()
         eta = self._eta_device()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        B, D = cs.n_rows, self.feature_dim
-        rate = torch.empty(B, D, dtype=torch.float32, device=self.device)
-        ll = torch.empty(B, D, dtype=torch.float32, device=self.device)
-        io = torch.zeros(S, 3, dtype=torch.float64, device=self.device)
-        gmin = torch.zeros(3, dtype=torch.float64, device=self.device)
+        D = self.feature_dim
+        pr = data.get("panels") if isinstance(data, dict) else None
+        p0, p1 = (pr or (0, None))
+        p1 = sc.n_panels if p1 is None else min(int(p1), sc.n_panels)
+        step = max(1, max_cells // max(1, sc.panel_rows * D))
+        h = self._aux(min(cs.n_rows, step * sc.panel_rows))
+        io = torch.zeros(4, dtype=torch.float64, device=self.device)
+        io[3] = float("inf")
+        buf_rows = min(cs.n_rows, step * sc.panel_rows)
+        rate = torch.empty(buf_rows * D, dtype=torch.float32, device=self.device)
+        ll = torch.empty(buf_rows * D, dtype=torch.float32, device=self.device)
+        key = (sc._xi_key, sc._g_key)
 
-        def dense(i):
-            _lib.check(h, lib.spmf_dense_ll(
-                h, C.byref(cs), P["u"][i].data_ptr(), P["v"][i].data_ptr(),
-                P["w"][i].data_ptr(), P["s"][i].data_ptr(), eta.data_ptr(),
-                rate.data_ptr(), ll.data_ptr(), stream), "spmf_dense_ll")
-        for i in range(S):                       # pass 0: one min over ALL draws
-            dense(i)
-            _lib.check(h, lib.spmf_nonfinite_reduce(h, B * D, ll.data_ptr(), 0,
-                                                    gmin.data_ptr(), stream), "nonfinite")
-        for i in range(S):                       # pass 1: clipped / replaced sums
-            dense(i)
-            io[i, 0] = gmin[0]
-            _lib.check(h, lib.spmf_nonfinite_reduce(h, B * D, ll.data_ptr(), 1,
-                                                    io[i].data_ptr(), stream), "nonfinite")
-        return io[:, 1].clone()
+        def sweep(fn):
+            for i in range(S):
+                for q0 in range(int(p0), p1, step):
+                    q1 = min(q0 + step, p1)
+                    sub = sc.__dict__.setdefault("_struct_cache", {}).setdefault(
+                        ((q0, q1),) + key, sc.batch_struct(q0, q1))
+                    _lib.check(h, lib.spmf_dense_ll(
+                        h, C.byref(sub), P["u"][i].data_ptr(), P["v"][i].data_ptr(),
+                        P["w"][i].data_ptr(), P["s"][i].data_ptr(), eta.data_ptr(),
+                        rate.data_ptr(), ll.data_ptr(), stream), "spmf_dense_ll")
+                    r0 = (q0 - int(p0)) * sc.panel_rows
+                    fn(sub.n_rows * D, float(i) * cs.n_rows * D + float(r0) * D)
+        sweep(lambda n, base: _lib.check(h, lib.spmf_nonfinite_reduce(
+            h, n, ll.data_ptr(), 0, io.data_ptr(), stream), "spmf_nonfinite_reduce"))
+        sweep(lambda n, base: _lib.check(h, lib.spmf_nonfinite_argmin(
+            h, n, ll.data_ptr(), base, io.data_ptr(), stream), "spmf_nonfinite_argmin"))
+        return io
 
     def unormalized_log_prob(self, data=None, prior_weight=1., **params):
         """poisson.py:575-580 -- NB: like the reference this ignores
@@ -541,6 +602,11 @@ class PoissonFactorization:
         self.set_calibration_expectations()
 
     def set_calibration_expectations(self, samples=32):
+        if self.device.type != "cuda":
+            # sampling the surrogate runs in the HIP kernels: without a device the
+            # expectations stay unset (encode()/encoding_matrix() then ask for them)
+            self.calibrated_expectations = {}
+            return
         self.calibrated_expectations = \
             self.surrogate_distribution.expectations(samples)
 

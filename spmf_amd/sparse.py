@@ -188,34 +188,62 @@ class SparseCounts:
             self.row_sum.data_ptr(), self.row_lgamma.data_ptr(), stream)
         _lib.check(ctx_handle, rc, "spmf_counts_stats")
 
+    # The spmf_counts descriptors cached per (panel range, xi key, g key) hold RAW
+    # device pointers to row_scale / gval / pc_gval.  Two models with different
+    # xi_u_global or eta may share one SparseCounts (key A -> key B -> key A), so the
+    # tensors of every key that still has a cached descriptor (or a captured graph)
+    # are kept alive here, and evicting a key drops its descriptors with it.
+    _MAX_XI_KEYS = 8
+    _MAX_G_KEYS = 2          # gval + pc_gval are nnz sized
+
+    def _drop_structs(self, pos, key):
+        cache = self.__dict__.get("_struct_cache")
+        if cache:
+            for k in [k for k in cache if k[pos] == key]:
+                del cache[k]
+
     def set_row_scale(self, xi_u_global, scale_rows):
         """xi_b = rowsum_b / xi_u_global (poisson.py:644-649)."""
         key = (float(xi_u_global), bool(scale_rows))
         if key == self._xi_key:
             return
-        if scale_rows:
-            self.row_scale = (self.row_sum / float(xi_u_global)).contiguous()
-        else:
-            self.row_scale = None
+        held = self.__dict__.setdefault("_row_scales", {})
+        if key not in held:
+            held[key] = ((self.row_sum / float(xi_u_global)).contiguous()
+                         if scale_rows else None)
+            while len(held) > self._MAX_XI_KEYS:
+                old = next(iter(held))
+                del held[old]
+                self._drop_structs(1, old)
+        self.row_scale = held[key]
         self._xi_key = key
 
     def set_log_transform(self, eta_dev):
         """g(x) = log(x/eta_d + 1) per stored entry (encoder_function,
         poisson.py:41-42), in CSR and panel-CSC order.  Data side: depends on
         the counts and the fixed column scales only."""
-        key = (eta_dev.data_ptr(), int(eta_dev._version))
+        held = self.__dict__.setdefault("_gvals", {})
+        # identity of the eta tensor (a strong reference is kept, so its id cannot be
+        # recycled while the entry lives) + its in-place version counter
+        key = (id(eta_dev), int(eta_dev._version))
         if self._g_key == key:
             return
-        eta = eta_dev.to(self.device, torch.float32)
-        self.gval = torch.log1p(self.val / eta[self.col_idx.to(torch.int64)]).contiguous()
-        nP, D = self.n_panels, self.n_cols
-        ptr = self.pc_ptr.view(nP, D + 1).to(torch.int64)
-        cnt = (ptr[:, 1:] - ptr[:, :-1]).reshape(-1)
-        cols = torch.repeat_interleave(
-            torch.arange(nP * D, device=self.device, dtype=torch.int64) % D, cnt)
-        self.pc_gval = torch.log1p(self.pc_val / eta[cols]).contiguous()
+        if key not in held:
+            eta = eta_dev.to(self.device, torch.float32)
+            gval = torch.log1p(self.val / eta[self.col_idx.to(torch.int64)]).contiguous()
+            nP, D = self.n_panels, self.n_cols
+            ptr = self.pc_ptr.view(nP, D + 1).to(torch.int64)
+            cnt = (ptr[:, 1:] - ptr[:, :-1]).reshape(-1)
+            cols = torch.repeat_interleave(
+                torch.arange(nP * D, device=self.device, dtype=torch.int64) % D, cnt)
+            pc_gval = torch.log1p(self.pc_val / eta[cols]).contiguous()
+            held[key] = (eta_dev, gval, pc_gval)
+            while len(held) > self._MAX_G_KEYS:
+                old = next(iter(held))
+                del held[old]
+                self._drop_structs(2, old)
+        _, self.gval, self.pc_gval = held[key]
         self._g_key = key
-        self.__dict__.pop("_struct_cache", None)
 
     # ---- batches ---------------------------------------------------------
     def n_batches(self, batch_rows):

@@ -11,7 +11,6 @@ import torch
 from .sparse import SparseCounts
 
 CHUNK_ROWS = 125_000
-MAX_GENE_MEAN = 4.0
 
 
 def linear_structure_chunk(chunk_id, rows, D, density, device, seed=20241218 + 3,
@@ -82,11 +81,16 @@ def bernoulli_poisson(rows, D, density, device, seed, mean=2.0, panel_rows=8192)
 
 
 def scrna_like(rows, D, device, seed, first_chunk=0, panel_rows=8192, chunk_rows=25_000,
-               target_density=0.03):
+               target_density=0.03, max_gene_mean=None, size_clip=None):
     """C4-style scRNA-seq-shaped counts: per-gene mean ~
     LogNormal(-3.5, 1.5), per-cell size factor ~ LogNormal(0, 0.5),
     X ~ Poisson(size * mean), gene means rescaled so the stored density is
-    ~`target_density`.  Generated dense chunk by chunk on the device."""
+    ~`target_density`.  Generated dense chunk by chunk on the device.
+    No clamping by default (round 1 capped the gene means at 4 and clipped the
+    size factors at 2 sigma so that exp(<z, eta v>) could not overflow fp32 at
+    the surrogate's initial values; the kernels now saturate the exponent
+    instead -- csrc/common.h kYSat); ``max_gene_mean`` / ``size_clip`` (in
+    sigmas) bring the old generator back."""
     gg = torch.Generator(device=device)
     gg.manual_seed(seed)
     mean = torch.exp(-3.5 + 1.5 * torch.randn(D, device=device, generator=gg))
@@ -95,25 +99,27 @@ def scrna_like(rows, D, device, seed, first_chunk=0, panel_rows=8192, chunk_rows
     lo, hi = 1e-3, 1e3
     for _ in range(40):
         mid = (lo * hi) ** 0.5
-        dens = (1 - torch.exp(-(sf[:, None] * (mean[None, :] * mid).clamp_max(MAX_GENE_MEAN)))
-                ).mean().item()
+        m_ = mean[None, :] * mid
+        if max_gene_mean is not None:
+            m_ = m_.clamp_max(max_gene_mean)
+        dens = (1 - torch.exp(-(sf[:, None] * m_))).mean().item()
         if dens < target_density:
             lo = mid
         else:
             hi = mid
-    # cap the hottest genes: with raw column-mean scaling (eta = mean) the
-    # log_transform rate exp(<z, eta v>) of a gene with mean in the hundreds
-    # overflows fp32 at the surrogate's initial values (the reference is fp64)
-    mean = (mean * ((lo * hi) ** 0.5)).clamp_max(MAX_GENE_MEAN)
+    mean = mean * ((lo * hi) ** 0.5)
+    if max_gene_mean is not None:
+        mean = mean.clamp_max(max_gene_mean)
     cnts, cols, vals = [], [], []
     done, cid = 0, first_chunk
     while done < rows:
         n = min(chunk_rows, rows - done)
         g = torch.Generator(device=device)
         g.manual_seed(seed * 1000 + 7 + cid)
-        # size factors clipped at 2 sigma: an un-clipped LogNormal tail row (x12 counts)
-        # drives exp(<z, eta v>) past the fp32 range at the surrogate's initial values
-        size = torch.exp((0.5 * torch.randn(n, device=device, generator=g)).clamp_(-1.0, 1.0))
+        lsz = 0.5 * torch.randn(n, device=device, generator=g)
+        if size_clip is not None:
+            lsz = lsz.clamp_(-0.5 * size_clip, 0.5 * size_clip)
+        size = torch.exp(lsz)
         x = torch.poisson(size[:, None] * mean[None, :], generator=g)
         mask = x > 0
         cnts.append(mask.sum(1))

@@ -18,8 +18,8 @@ generators (``randn`` / ``_standard_gamma`` and its implicit-reparameterisation
 derivative -- RNG plumbing), everything else -- the transform to theta, log q,
 the energy and its gradient, the chain back to the trainables and the Adam
 update -- are HIP kernels behind the C-ABI (surrogate.hip + the hot path).
-``Surrogate.rsample`` / ``elbo_step_reference`` keep a plain torch-autograd
-restatement of the same step; the tests use it as the fp32 reference.
+(The plain torch-autograd restatement of the same step that the tests compare
+against lives in tests/_vi_reference.py, not in the product.)
 """
 from __future__ import annotations
 
@@ -68,9 +68,11 @@ class Surrogate:
     ``reconstitute`` assigns them by position (poisson.py:711-717)."""
 
     def __init__(self, model):
+        import weakref
         D, K = model.feature_dim, model.latent_dim
         dev = model.device
         self.device = dev
+        self._model_ref = weakref.ref(model)      # no cycle: the model owns the surrogate
         self.kinds: Dict[str, str] = {}
         self.trainable_variables: List[torch.Tensor] = []
         self._index = {}
@@ -118,41 +120,6 @@ class Surrogate:
     def params_of(self, n):
         i = self._index[n]
         return self.trainable_variables[i], self.trainable_variables[i + 1]
-
-    def rsample(self, S, generator=None):
-        """-> (theta: name -> [S,*shape] with autograd graph, logq [S])."""
-        theta, logq = {}, 0.0
-        for n in VAR_ORDER:
-            t0, t1 = self.params_of(n)
-            shape = (S,) + tuple(t0.shape)
-            if self.kinds[n] in ("normal", "normal_identity"):
-                sigma = _sp(t1)
-                eps = torch.randn(shape, device=self.device, dtype=torch.float32,
-                                  generator=generator)
-                y = t0 + sigma * eps
-                lq = -0.5 * eps ** 2 - torch.log(sigma) - 0.5 * math.log(2 * math.pi)
-            else:
-                a, b = _sp(t0), _sp(t1)
-                g = torch._standard_gamma(a.expand(shape).contiguous()) \
-                    if generator is None else \
-                    torch.distributions.Gamma(a.expand(shape), 1.0).rsample()
-                # implicit reparameterisation gradient d g / d a
-                g = _GammaReparam.apply(g.detach(), a.expand(shape))
-                g = g.clamp_min(1e-30)
-                y = b / g
-                lq = (a * torch.log(b) - torch.lgamma(a) - (a + 1.0) * torch.log(y) - b / y)
-            if self.kinds[n] == "normal_identity":
-                th = y                                          # no Jacobian
-            elif n in self.ident_mask:                          # per-element bijector
-                im = self.ident_mask[n].bool()
-                th = torch.where(im, y, _sp(y))
-                lq = lq - torch.where(im, torch.zeros_like(y), torch.nn.functional.logsigmoid(y))
-            else:
-                th = _sp(y)
-                lq = lq - torch.nn.functional.logsigmoid(y)
-            theta[n] = th
-            logq = logq + lq.sum((-1, -2))
-        return theta, logq
 
     # ---- HIP path -------------------------------------------------------
     _KIND = {"normal": 0, "normal_identity": 1, "invgamma": 2}
@@ -229,49 +196,23 @@ class Surrogate:
                                              stream), "spmf_surrogate_bwd")
         return grads
 
+    def _model(self):
+        m = self._model_ref() if self._model_ref is not None else None
+        if m is None:
+            raise RuntimeError("the surrogate's model is gone")
+        return m
+
     @torch.no_grad()
     def sample(self, n=1):
-        th, _ = self.rsample(n)
-        return {k: v.detach() for k, v in th.items()}
+        """n draws theta ~ q (dict name -> [n,*shape]); surrogate_distribution.sample(n)
+        of the reference's callers (bin/factorize_csv.py:155)."""
+        n = int(n)
+        theta, _ = self.forward_hip(self._model(), n, self.draw_noise(n))
+        return theta
 
     @torch.no_grad()
     def expectations(self, samples=32):
-        th, _ = self.rsample(samples)
-        return {k: v.mean(0) for k, v in th.items()}
-
-
-class _GammaReparam(torch.autograd.Function):
-    """g ~ Gamma(a, 1) with d g/d a from torch._standard_gamma_grad."""
-
-    @staticmethod
-    def forward(ctx, g, a):
-        ctx.save_for_backward(g, a)
-        return g
-
-    @staticmethod
-    def backward(ctx, grad):
-        g, a = ctx.saved_tensors
-        return None, grad * torch._standard_gamma_grad(a.contiguous(), g.contiguous())
-
-
-class Adam:
-    """tf.keras-style Adam on a list of tensors (beta1 .9, beta2 .999, eps 1e-7)."""
-
-    def __init__(self, params, lr, beta1=0.9, beta2=0.999, eps=1e-7):
-        self.params, self.lr, self.b1, self.b2, self.eps = params, lr, beta1, beta2, eps
-        self.m = [torch.zeros_like(p) for p in params]
-        self.v = [torch.zeros_like(p) for p in params]
-        self.t = 0
-
-    @torch.no_grad()
-    def step(self, grads):
-        self.t += 1
-        c1 = 1.0 - self.b1 ** self.t
-        c2 = 1.0 - self.b2 ** self.t
-        for p, g, m, v in zip(self.params, grads, self.m, self.v):
-            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
-            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
-            p.addcdiv_(m / c1, (v / c2).sqrt_().add_(self.eps), value=-self.lr)
+        return {k: v.mean(0) for k, v in self.sample(samples).items()}
 
 
 class AdamHIP:
@@ -340,17 +281,39 @@ class AdamHIP:
                    "spmf_adam_step")
 
 
-def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None):
+def batch_rows_global(cs, all_reduce):
+    """Rows of the batch over ALL row shards.  With a reducer the data parts that
+    come out of spmf_finish are global sums, so the batch weight c = B/N, the
+    loss divisor and 1/(S*B) must use the global row count, not the shard's."""
+    if all_reduce is None:
+        return int(cs.n_rows)
+    totals = getattr(all_reduce, "totals", None)
+    if totals is None:
+        raise ValueError("a sharded VI step needs the batch's global row count: the "
+                         "all_reduce hook must provide totals(rows, lgamma_sum) "
+                         "(spmf_amd.dist.ShardReducer does)")
+    return int(totals(cs.n_rows, cs.lgamma_sum)[0])
+
+
+def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None, nonfinite=None):
     """One stochastic ELBO evaluation + gradient wrt the surrogate trainables,
-    all arithmetic in HIP kernels.  Returns (loss, grads list, n_nonfinite)."""
+    all arithmetic in HIP kernels.  Returns (loss, grads list, n_nonfinite).
+    ``dataset_rows`` is the size of the whole dataset (all shards).
+    ``nonfinite``: "rule" applies the reference's replacement rule
+    (poisson.py:606-616) with its gradient when stored cells have a non-finite
+    log-pmf (single shard; default there), "count" only counts them (the
+    caller then skips the batch; default with row shards)."""
+    if nonfinite is None:
+        nonfinite = "rule" if all_reduce is None else "count"
     sur = model.surrogate_distribution
     S = int(sample_size)
     noise = sur.draw_noise(S)
     theta, logq = sur.forward_hip(model, S, noise)
     sc, cs = model._batch(batch)
-    B = cs.n_rows
+    B = batch_rows_global(cs, all_reduce)
     c = float(B) / float(dataset_rows)
-    parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=all_reduce, prior_weight=c)
+    parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=all_reduce, prior_weight=c,
+                                           nonfinite=nonfinite)
     rows = B
     prior = sum(parts[n] for n in VAR_ORDER)
     energy = parts["x"] + parts["z"] + c * prior           # [S] float64
@@ -454,27 +417,6 @@ class StepRunner:
         self.replays += 1
 
 
-def elbo_step_reference(model, batch, dataset_rows, sample_size, all_reduce=None, generator=None):
-    """Plain torch-autograd restatement of elbo_step (sampling, log q and the
-    chain rule in torch ops); the fp32 reference the tests compare against.
-    Returns (loss float tensor, grads list) -- no optimiser update."""
-    sur = model.surrogate_distribution
-    theta, logq = sur.rsample(sample_size, generator)
-    det = {k: v.detach() for k, v in theta.items()}
-    sc, cs = model._batch(batch)
-    B = cs.n_rows
-    c = float(B) / float(dataset_rows)
-    parts, g, nnf = model.energy_and_grads(batch, det, all_reduce=all_reduce, prior_weight=c)
-    prior = sum(parts[n] for n in VAR_ORDER)
-    energy = parts["x"] + parts["z"] + c * prior           # [S] float64
-    loss = -(energy - c * logq.detach().double()).mean() / B
-    # surrogate for autograd: d loss / d trainables
-    lin = sum((g[n] * theta[n]).sum() for n in VAR_ORDER)
-    sur_loss = -(lin - c * logq.sum()) / (sample_size * B)
-    grads = torch.autograd.grad(sur_loss, sur.trainable_variables)
-    return loss, list(grads), nnf
-
-
 def _clip(grads, clip_value):
     if clip_value is None:
         return grads
@@ -511,11 +453,21 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
             tot, nb, skipped = st[10], int(st[11]), int(st[12])
             if verbose and skipped:
                 print(f"Batch loss NaN, skipping ({skipped} batches)")
+            if skipped:
+                # the device-gated loop cannot apply the replacement rule (it needs a
+                # host decision); from here on run the eager loop, which trains THROUGH
+                # non-finite cells like the reference (poisson.py:606-616)
+                device_loop = False
+                opt.t = int(st[7])
+                if nb == 0:
+                    continue                      # nothing applied yet: next epoch, eagerly
         else:
             for batch in iter(batched_data_factory()):
                 loss, grads, nnf = elbo_step(model, batch, dataset_size, sample_size, all_reduce)
                 lv = float(loss)
-                if not math.isfinite(lv) or float(nnf.sum()) > 0:
+                # single shard: non-finite cells were handled by the rule; with row
+                # shards they are only counted and the batch is skipped
+                if not math.isfinite(lv) or (all_reduce is not None and float(nnf.sum()) > 0):
                     if verbose:
                         print("Batch loss NaN, skipping")
                     continue
@@ -523,7 +475,11 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
                 tot += lv
                 nb += 1
         if nb == 0:
-            break
+            # every batch of the epoch was skipped (non-finite loss): returning
+            # quietly would look like a converged fit
+            raise FloatingPointError(
+                f"epoch {ep}: all batches were skipped (non-finite loss); nothing was "
+                "trained -- check the column scales / initial values for overflow")
         ep_loss = tot / nb
         losses.append(ep_loss)
         if verbose and ep % check_every == 0:
@@ -555,6 +511,22 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
     return losses
 
 
+def batch_rows(model, b):
+    """Rows of one batch object WITHOUT building its device layout: a dense
+    [B,D] array, a sparse matrix, a SparseCounts, or a panel range
+    ``{'counts': sc, 'panels': (p0, p1)}`` of a resident SparseCounts (whose
+    own n_rows is the whole shard, not the batch)."""
+    x = b[model.count_key] if isinstance(b, dict) else b
+    pr = b.get("panels") if isinstance(b, dict) else None
+    if pr is not None and hasattr(x, "panel_rows"):
+        p0, p1 = pr
+        p1 = x.n_panels if p1 is None else min(int(p1), x.n_panels)
+        return max(0, min(p1 * x.panel_rows, x.n_rows) - int(p0) * x.panel_rows)
+    if isinstance(x, (tuple, list)) and len(x) == 4:      # (indptr, indices, data, shape)
+        return int(x[3][0])
+    return int(x.n_rows) if hasattr(x, "n_rows") else int(x.shape[0])
+
+
 def calibrate_advi(model, num_steps=100, num_epochs=None, learning_rate=0.1, abs_tol=1e-10,
                    rel_tol=1e-8, clip_value=5.0, max_decay_steps=25, lr_decay_factor=0.99,
                    check_every=1, set_expectations=True, sample_size=4, data=None, **kwargs):
@@ -564,10 +536,7 @@ def calibrate_advi(model, num_steps=100, num_epochs=None, learning_rate=0.1, abs
     if data is None:
         raise ValueError("calibrate_advi needs the dataset the model was built with")
     factory = data if callable(data) else (lambda: data)
-    n = 0
-    for b in iter(factory()):
-        x = b[model.count_key] if isinstance(b, dict) else b
-        n += x.n_rows if hasattr(x, "n_rows") else x.shape[0]
+    n = sum(batch_rows(model, b) for b in iter(factory()))
     return fit(model, factory, dataset_size=n, sample_size=sample_size,
                num_steps=num_steps, num_epochs=num_epochs, rel_tol=rel_tol, abs_tol=abs_tol,
                learning_rate=learning_rate, clip_value=clip_value,

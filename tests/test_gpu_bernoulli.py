@@ -37,11 +37,11 @@ def test_bernoulli_energy_and_grads(B, D, K, S, density):
     parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
     assert float(nnf.sum()) == 0
     for k, r in pref.items():
-        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=2e-5, atol=2e-5,
+        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                    err_msg=k)
     for k, r in gref.items():
         g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 2e-5 * np.abs(r.numpy()).max(), k
+        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
 
 
 def test_bernoulli_surrogate_and_fit_smoke():
@@ -74,8 +74,8 @@ def test_bernoulli_randomised_sweep():
         tag = f"case {case}: B={B} D={D} K={K} S={S} dens={density}"
         assert float(nnf.sum()) == 0, tag
         for k, r in pref.items():
-            np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=2e-5, atol=2e-5,
+            np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                        err_msg=f"{tag} {k}")
         for k, r in gref.items():
             g = grads[k].cpu().double().numpy().reshape(r.shape)
-            assert np.abs(g - r.numpy()).max() <= 2e-5 * max(np.abs(r.numpy()).max(), 1e-30), (tag, k)
+            assert np.abs(g - r.numpy()).max() <= 1e-5 * max(np.abs(r.numpy()).max(), 1e-30), (tag, k)

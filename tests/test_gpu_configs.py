@@ -142,3 +142,263 @@ def test_c3_full_size_properties():
     for k in grads:
         a, b = g2[k].double(), grads[k].double()
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), k
+
+
+# --------------------------------------------------------------------------
+# C4: scRNA-seq-shaped 500k x 30k, ~3 % nnz, K = 64, log_transform + row
+# normalisation, column_norms = column means
+# (bin/factorize_scrnaseq_counts.py:48-50,93-99; poisson.py:41-42,52-53,156-184)
+# --------------------------------------------------------------------------
+def _csr_of(sc, n=None):
+    n = sc.n_rows if n is None else n
+    hi = int(sc.row_ptr[n])
+    return sp.csr_matrix((sc.val[:hi].cpu().numpy().astype(np.float64), sc.col_idx[:hi].cpu().numpy(),
+                          sc.row_ptr[:n + 1].cpu().numpy()), shape=(n, sc.n_cols))
+
+
+def _take_rows(sc, idx):
+    """SparseCounts of the selected rows of a resident shard (device-side gather)."""
+    from spmf_amd import SparseCounts
+    dev = sc.device
+    rp = sc.row_ptr.long()
+    lens = rp[idx + 1] - rp[idx]
+    ptr = torch.zeros(idx.numel() + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(lens, 0)
+    within = torch.arange(int(ptr[-1]), device=dev) - torch.repeat_interleave(ptr[:-1], lens)
+    src = torch.repeat_interleave(rp[idx], lens) + within
+    return SparseCounts(ptr, sc.col_idx[src], sc.val[src], idx.numel(), sc.n_cols)
+
+
+def _c4_model(sc, rows_total, K=64):
+    """PoissonFactorization set up as the scRNA script does: log_transform,
+    column_norms = plain column means (floored), xi = their sum."""
+    from spmf_amd import PoissonFactorization
+    D = sc.n_cols
+    dev = sc.device
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(rows_total * D),
+                             log_transform=True, device=dev)
+    colsum = torch.zeros(D, dtype=torch.float64, device=dev)
+    colnnz = torch.zeros(D, dtype=torch.float64, device=dev)
+    sc.compute_stats(m._handle(), colsum, colnnz)
+    m.eta_i = (colsum / sc.n_rows).clamp_min(1e-3).reshape(1, D)
+    m.xi_u_global = float((colsum / sc.n_rows).sum())
+    return m
+
+
+def _rel_grads(got, ref, tol, tag=""):
+    for k, r in ref.items():
+        g = got[k].detach().cpu().double().numpy().reshape(np.shape(r))
+        err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
+        assert err <= tol, (tag, k, err)
+
+
+@pytest.mark.timeout(900)
+def test_c4_slice_20000x30000_K64_log_transform_vs_dense_oracle():
+    """One 20 000-row slice of the C4 generator (un-clamped), K = 64,
+    log_transform + row scaling, against the dense fp64 oracle fed in row
+    chunks (tests/_chunked_oracle.py) at the 1e-5 contract tolerance."""
+    from _chunked_oracle import data_term, prior_term
+    from spmf_amd import synth
+    dev = torch.device("cuda")
+    B, D, K = 20_000, 30_000, 64
+    sc = synth.scrna_like(B, D, dev, 20241218 + 4, chunk_rows=10_000)
+    assert 0.02 < sc.nnz / (B * D) < 0.04
+    m = _c4_model(sc, 500_000, K)
+    torch.manual_seed(41)
+    params = m.surrogate_distribution.sample(1)
+    # off the symmetric initial point; v scaled so that the exponents <z, eta v> are O(1..10)
+    for k in ("u", "v"):
+        params[k] = params[k] * torch.exp(0.5 * torch.randn_like(params[k]))
+    z = m.encode(sc, u=params["u"][0], s=params["s"][0]).double()
+    W = (params["v"][0].double() * m._eta_device().double()[None, :])     # [K,D]
+    ymax = float((z @ W).max())
+    params["v"] = params["v"] * (12.0 / ymax)
+    parts, grads, nnf = m.energy_and_grads({"counts": sc}, params)
+    assert float(nnf.sum()) == 0 and float(m.last_saturated.sum()) == 0
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, log_transform=True,
+                         u_tau_scale=m.u_tau_scale)
+    cfg.eta_i = m._eta_device().double().cpu().reshape(1, D)      # the fp32 values the kernels use
+    cfg.xi_u_global = float(m.xi_u_global)
+    p64 = {k: v.double().cpu().numpy() for k, v in params.items()}
+    ref = data_term(cfg, _csr_of(sc), p64, chunk=1024)
+    assert abs(float(parts["x"]) - ref["x"]) <= 1e-5 * abs(ref["x"])
+    assert abs(float(parts["z"]) - ref["z"]) <= 1e-5 * abs(ref["z"])
+    pparts, pg = prior_term(cfg, p64)
+    for k, r in pparts.items():
+        assert abs(float(parts[k]) - r) <= 1e-5 * abs(r), k
+    tot = {k: pg[k] + ref["grads"].get(k, 0.0) for k in pg}
+    _rel_grads(grads, tot, 1e-5, "c4")
+
+
+@pytest.mark.timeout(900)
+def test_c4_full_size_properties_and_saturation():
+    """C4 at its full size (500k x 30k, K = 64, log_transform): finiteness at the
+    surrogate's INITIAL values on the un-clamped generator (hot genes x deep cells
+    overflow exp() in fp32: saturated and counted, not skipped), the z-prior
+    identity, the dense exp sum against an independent fp64 evaluation on sampled
+    rows, and additivity over row shards."""
+    from spmf_amd import synth
+    dev = torch.device("cuda")
+    N, D, K = 500_000, 30_000, 64
+    sc = synth.scrna_like(N, D, dev, 20241218 + 4)
+    assert 0.02 < sc.nnz / (N * D) < 0.04
+    m = _c4_model(sc, N, K)
+    torch.manual_seed(43)
+    params = m.surrogate_distribution.sample(1)
+    parts, grads, nnf = m.energy_and_grads({"counts": sc}, params)
+    sat0 = float(m.last_saturated.sum())
+    assert float(nnf.sum()) == 0
+    for k, v in parts.items():
+        assert bool(torch.isfinite(v).all()), k           # finite with or without saturation
+    for k, g in grads.items():
+        assert bool(torch.isfinite(g).all()), k
+    # the same point with the exponents scaled down below the saturation level
+    z = m.encode(sc, u=params["u"][0], s=params["s"][0]).double()
+    eta = m._eta_device().double()
+    W = params["v"][0].double() * eta[None, :]
+    zmax = z.max(0).values
+    ybound = float((zmax[None, :] @ W).max())              # >= every exponent (all terms >= 0)
+    if ybound > 60.0:
+        params["v"] = params["v"] * (60.0 / ybound)
+        W = params["v"][0].double() * eta[None, :]
+    else:
+        assert sat0 == 0.0
+    parts, grads, nnf = m.energy_and_grads({"counts": sc}, params)
+    assert float(nnf.sum()) == 0 and float(m.last_saturated.sum()) == 0
+    zref = N * K * 0.5 * math.log(2 / math.pi) - 0.5 * float((z * z).sum())
+    assert abs(float(parts["z"]) - zref) <= 1e-5 * abs(zref)
+    # 'x' = sum_nnz [x log r - lgamma] - sum_all r ; check sum_all r on sampled rows in fp64
+    s = params["s"][0].double()
+    w = params["w"][0].double().reshape(-1)
+    phi = eta * (s[1] / (s[0] + s[1])) * w
+    idx = torch.arange(0, N, 997, device=dev)
+    E = torch.exp(z[idx] @ W)                              # [n_sample, D] fp64
+    sum_r_s = float((E - 1.0).sum()) + idx.numel() * float(phi.sum())
+    # the same rows through the library: batch of the sampled rows only
+    ss = _take_rows(sc, idx)
+    ps, _, nnf_s = m.energy_and_grads({"counts": ss}, params)
+    lg = float(ss.row_lgamma.sum())
+    lens = (ss.row_ptr[1:] - ss.row_ptr[:-1]).long()
+    rr = torch.repeat_interleave(torch.arange(ss.n_rows, device=dev), lens)
+    cc = ss.col_idx.long()
+    r_st = torch.exp((z[idx][rr] * W.T[cc]).sum(1)) - 1.0 + phi[cc]
+    ll_nnz = float((ss.val.double() * torch.log(r_st)).sum())
+    xref = ll_nnz - lg - sum_r_s
+    assert abs(float(ps["x"]) - xref) <= 1e-5 * abs(xref)
+    # additivity over two row shards
+    half = sc.n_panels // 2
+    other = {}
+
+    def hook0(acc, rows_, lg_):
+        other["acc"], other["rows"], other["lg"] = acc.clone(), rows_, lg_
+        return None
+    m.energy_and_grads({"counts": sc, "panels": (0, half)}, params, all_reduce=hook0)
+
+    def hook1(acc, rows_, lg_):
+        acc += other["acc"]
+        return rows_ + other["rows"], lg_ + other["lg"]
+    p2, g2, _ = m.energy_and_grads({"counts": sc, "panels": (half, sc.n_panels)}, params,
+                                   all_reduce=hook1)
+    for k in parts:
+        assert abs(float(p2[k]) - float(parts[k])) <= 1e-5 * abs(float(parts[k])), k
+    for k in grads:
+        a, b = g2[k].double(), grads[k].double()
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), k
+
+
+# --------------------------------------------------------------------------
+# C5: 200k x 10k mixed Poisson / Bernoulli columns, K = 32 (build-defined
+# semantics: mederrata_spmf/mixed.py is empty; bernoulli.py:126-216 per column)
+# --------------------------------------------------------------------------
+def _c5_model(sc, mask, rows_total, K=32):
+    from spmf_amd import MixedFactorization
+    m = MixedFactorization(mask, latent_dim=K, feature_dim=sc.n_cols,
+                           u_tau_scale=1 / math.sqrt(rows_total * sc.n_cols), device=sc.device)
+    m.compute_scales(lambda: [{"counts": sc}])
+    return m
+
+
+@pytest.mark.timeout(900)
+def test_c5_slice_20000x10000_K32_mixed_vs_dense_oracle():
+    from _chunked_oracle import data_term, prior_term
+    from spmf_amd import synth
+    dev = torch.device("cuda")
+    B, D, K = 20_000, 10_000, 32
+    sc, mask = synth.mixed_c5(B, D, dev, 20241218 + 5)
+    m = _c5_model(sc, mask, 200_000, K)
+    torch.manual_seed(51)
+    params = m.surrogate_distribution.sample(1)
+    for k in ("u", "v"):
+        params[k] = params[k] * 30 * torch.exp(0.5 * torch.randn_like(params[k]))
+    parts, grads, nnf = m.energy_and_grads({"counts": sc}, params)
+    assert float(nnf.sum()) == 0
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, likelihood="mixed",
+                         u_tau_scale=m.u_tau_scale, extra={"bernoulli_columns": mask})
+    cfg.eta_i = m._eta_device().double().cpu().reshape(1, D)
+    cfg.xi_u_global = float(m.xi_u_global)
+    p64 = {k: v.double().cpu().numpy() for k, v in params.items()}
+    ref = data_term(cfg, _csr_of(sc), p64, chunk=2048)
+    assert abs(float(parts["x"]) - ref["x"]) <= 1e-5 * abs(ref["x"])
+    assert abs(float(parts["z"]) - ref["z"]) <= 1e-5 * abs(ref["z"])
+    pparts, pg = prior_term(cfg, p64)
+    for k, r in pparts.items():
+        assert abs(float(parts[k]) - r) <= 1e-5 * abs(r), k
+    tot = {k: pg[k] + ref["grads"].get(k, 0.0) for k in pg}
+    _rel_grads(grads, tot, 1e-5, "c5")
+
+
+@pytest.mark.timeout(900)
+def test_c5_full_size_properties():
+    from spmf_amd import synth
+    dev = torch.device("cuda")
+    N, D, K = 200_000, 10_000, 32
+    sc, mask = synth.mixed_c5(N, D, dev, 20241218 + 5)
+    m = _c5_model(sc, mask, N, K)
+    torch.manual_seed(53)
+    params = m.surrogate_distribution.sample(1)
+    params["u"] = params["u"] * 20
+    params["v"] = params["v"] * 20
+    parts, grads, nnf = m.energy_and_grads({"counts": sc}, params)
+    assert float(nnf.sum()) == 0
+    for k, v in parts.items():
+        assert bool(torch.isfinite(v).all()), k
+    for k, g in grads.items():
+        assert bool(torch.isfinite(g).all()), k
+    z = m.encode(sc, u=params["u"][0], s=params["s"][0]).double()
+    zref = N * K * 0.5 * math.log(2 / math.pi) - 0.5 * float((z * z).sum())
+    assert abs(float(parts["z"]) - zref) <= 1e-5 * abs(zref)
+    # sampled rows through an independent fp64 dense evaluation of the mixed log-pmf
+    eta = m._eta_device().double()
+    W = params["v"][0].double() * eta[None, :]
+    s = params["s"][0].double()
+    w = params["w"][0].double().reshape(-1)
+    phi = eta * (s[1] / (s[0] + s[1])) * w
+    idx = torch.arange(0, N, 499, device=dev)
+    ss = _take_rows(sc, idx)
+    ps, _, _ = m.energy_and_grads({"counts": ss}, params)
+    xd = ss.to_dense().double()
+    rate = z[idx] @ W + phi[None, :]
+    mk = torch.as_tensor(mask, device=dev)
+    ll_b = xd * rate - torch.nn.functional.softplus(rate)
+    ll_p = torch.xlogy(xd, torch.where(mk, torch.ones_like(rate), rate)) - rate - torch.lgamma(xd + 1)
+    xref = float(torch.where(mk[None, :], ll_b, ll_p).sum())
+    assert abs(float(ps["x"]) - xref) <= 1e-5 * abs(xref)
+    # additivity over two row shards
+    half = sc.n_panels // 2
+    other = {}
+
+    def hook0(acc, rows_, lg_):
+        other["acc"], other["rows"], other["lg"] = acc.clone(), rows_, lg_
+        return None
+    m.energy_and_grads({"counts": sc, "panels": (0, half)}, params, all_reduce=hook0)
+
+    def hook1(acc, rows_, lg_):
+        acc += other["acc"]
+        return rows_ + other["rows"], lg_ + other["lg"]
+    p2, g2, _ = m.energy_and_grads({"counts": sc, "panels": (half, sc.n_panels)}, params,
+                                   all_reduce=hook1)
+    for k in parts:
+        assert abs(float(p2[k]) - float(parts[k])) <= 1e-5 * abs(float(parts[k])), k
+    for k in grads:
+        a, b = g2[k].double(), grads[k].double()
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), k

@@ -27,7 +27,7 @@ def _data(N=600, D=24, seed=3):
 
 def test_elbo_step_gradients_match_oracle_autograd():
     from spmf_amd import PoissonFactorization
-    from spmf_amd.vi import elbo_step_reference
+    from _vi_reference import elbo_step_reference, rsample
     X = _data(200, 12)
     N, D = X.shape
     K, S = 3, 2
@@ -39,7 +39,7 @@ def test_elbo_step_gradients_match_oracle_autograd():
     # same draw again on the reference side: re-seed and rebuild theta with autograd
     torch.manual_seed(5)
     sur = m.surrogate_distribution
-    theta, logq = sur.rsample(S)
+    theta, logq = rsample(sur, S)
     cfg = O.OracleConfig(latent_dim=K, feature_dim=D, u_tau_scale=m.u_tau_scale)
     th64 = {k: v.double().cpu() for k, v in theta.items()}
     parts = O.unormalized_log_prob_parts(cfg, X, th64)
@@ -47,10 +47,10 @@ def test_elbo_step_gradients_match_oracle_autograd():
     c = 1.0   # full batch: B/N = 1
     ref_loss = -(parts["x"] + parts["z"] + c * prior - c * logq.double().cpu()).mean() / N
     ref_grads = torch.autograd.grad(ref_loss, sur.trainable_variables)
-    assert abs(float(loss) - float(ref_loss.detach())) <= 2e-5 * abs(float(ref_loss.detach()))
+    assert abs(float(loss) - float(ref_loss.detach())) <= 1e-5 * abs(float(ref_loss.detach()))
     for g, r in zip(grads, ref_grads):
         r = r.to(g)
-        assert (g - r).abs().max() <= 2e-4 * max(float(r.abs().max()), 1e-12)
+        assert (g - r).abs().max() <= 1e-5 * max(float(r.abs().max()), 1e-12)
 
 
 @pytest.mark.parametrize("bernoulli", [False, True])
@@ -59,6 +59,7 @@ def test_hip_vi_step_matches_torch_autograd_reference(bernoulli):
     restatement of the same step, on identical base noise."""
     from spmf_amd import BernoulliFactorization, PoissonFactorization
     from spmf_amd import vi
+    from _vi_reference import Adam as RefAdam, GammaReparam
     X = _data(300, 15)
     if bernoulli:
         X = (X > 1).astype(np.float64)
@@ -82,7 +83,7 @@ def test_hip_vi_step_matches_torch_autograd_reference(bernoulli):
         nz, _ = noise[n]
         if sur.kinds[n] == "invgamma":
             a, b = sp(t0), sp(t1)
-            g = vi._GammaReparam.apply(nz, a.expand(nz.shape))
+            g = GammaReparam.apply(nz, a.expand(nz.shape))
             y = b / g
             lq = a * torch.log(b) - torch.lgamma(a) - (a + 1) * torch.log(y) - b / y
         else:
@@ -98,7 +99,7 @@ def test_hip_vi_step_matches_torch_autograd_reference(bernoulli):
         lq_ref = lq_ref + lq.sum((-1, -2))
     for n in vi.VAR_ORDER:
         np.testing.assert_allclose(theta[n].cpu().numpy(), th_ref[n].detach().cpu().numpy(),
-                                   rtol=2e-5, atol=1e-7, err_msg=n)
+                                   rtol=1e-5, atol=1e-7, err_msg=n)
     np.testing.assert_allclose(logq.cpu().numpy(), lq_ref.detach().double().cpu().numpy(), rtol=1e-5)
     # backward: same energy gradient fed to both
     c, B = 0.5, N
@@ -108,11 +109,11 @@ def test_hip_vi_step_matches_torch_autograd_reference(bernoulli):
     ref_loss = -(lin - c * lq_ref.sum()) / (S * B)
     ref_grads = torch.autograd.grad(ref_loss, sur.trainable_variables)
     for i, (a, r) in enumerate(zip(grads, ref_grads)):
-        assert (a - r).abs().max() <= 5e-5 * max(float(r.abs().max()), 1e-12), i
+        assert (a - r).abs().max() <= 1e-5 * max(float(r.abs().max()), 1e-12), i
     # Adam: one fused step == the tensor-op Adam
     p0 = [p.detach().clone() for p in sur.trainable_variables]
     ref_params = [p.detach().clone().requires_grad_(False) for p in p0]
-    ref_opt = vi.Adam(ref_params, 0.01)
+    ref_opt = RefAdam(ref_params, 0.01)
     ref_opt.step([gg.clamp(-3.0, 3.0) for gg in ref_grads])
     opt = vi.AdamHIP(m, sur.trainable_variables, 0.01)
     opt.step(list(ref_grads), clip_value=3.0)

@@ -50,7 +50,7 @@ def test_log_transform_energy_and_grads(B, D, K, S, density, scale_rows):
                                    err_msg=k)
     for k, r in gref.items():
         g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 2e-5 * np.abs(r.numpy()).max(), k
+        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
     T = torch.as_tensor
     z = m.encode(x, u=T(params["u"]), s=T(params["s"])).cpu().numpy()
     zr = O.encode(cfg, T(x), T(params["u"]), T(params["s"])).numpy()
@@ -76,11 +76,11 @@ def test_log_transform_randomised_sweep():
         tag = f"case {case}: B={B} D={D} K={K} S={S} dens={density} sr={sr}"
         assert float(nnf.sum()) == 0, tag
         for k, r in pref.items():
-            np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=2e-5, atol=2e-5,
+            np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                        err_msg=f"{tag} {k}")
         for k, r in gref.items():
             g = grads[k].cpu().double().numpy().reshape(r.shape)
-            assert np.abs(g - r.numpy()).max() <= 2e-5 * max(np.abs(r.numpy()).max(), 1e-30), (tag, k)
+            assert np.abs(g - r.numpy()).max() <= 1e-5 * max(np.abs(r.numpy()).max(), 1e-30), (tag, k)
 
 
 def test_log_transform_fit_smoke():

@@ -40,11 +40,11 @@ def test_mixed_energy_and_grads(B, D, K, S, density, sr):
     parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
     assert float(nnf.sum()) == 0
     for k, r in pref.items():
-        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=2e-5, atol=2e-5,
+        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                    err_msg=k)
     for k, r in gref.items():
         g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 2e-5 * np.abs(r.numpy()).max(), k
+        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
 
 
 def test_mixed_fit_smoke():

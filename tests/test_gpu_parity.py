@@ -37,7 +37,7 @@ def build_model(cfg, panel_rows=64):
         latent_dim=cfg.latent_dim, feature_dim=cfg.feature_dim,
         u_tau_scale=cfg.u_tau_scale, s_tau_scale=cfg.s_tau_scale,
         symmetry_breaking_decay=cfg.symmetry_breaking_decay,
-        scale_rows=cfg.scale_rows, column_norms=cfg.eta_i,
+        scale_rows=cfg.scale_rows, log_transform=cfg.log_transform, column_norms=cfg.eta_i,
         initialize_distributions=False, device="cuda", panel_rows=panel_rows)
     m.xi_u_global = cfg.xi_u_global
     return m

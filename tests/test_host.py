@@ -30,7 +30,36 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.spmf_version() == 1
+    assert lib.spmf_version() == 2
+
+
+def test_library_exports_only_the_c_abi(lib):
+    """-fvisibility=hidden + the linker export map: the dynamic symbol table holds
+    the header's functions and nothing else (no launch wrappers, no kernel handles)."""
+    import subprocess
+    from spmf_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True,
+                         text=True, check=True).stdout
+    names = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert names == set(_lib.SIGNATURES), names ^ set(_lib.SIGNATURES)
+
+
+def test_struct_sizes_agree_between_library_ctypes_and_integration_stub(lib):
+    """spmf_sizeof_*: the library's own struct sizes == the ctypes mirrors in
+    spmf_amd/_lib.py == the stub INTEGRATION.md tells a maintainer to copy."""
+    from spmf_amd import _lib
+    assert lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct) == 160
+    assert lib.spmf_sizeof_sur_var() == C.sizeof(_lib.SurVar)
+    assert lib.spmf_sizeof_adam_var() == C.sizeof(_lib.AdamVar)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class SpmfCounts\(C\.Structure\):.*?\n(    _fields_ = \[.*?\])\n", doc, re.S)
+    assert m, "INTEGRATION.md: SpmfCounts stub not found"
+    ns = {"C": C}
+    exec("class SpmfCounts(C.Structure):\n" + m.group(1), ns)
+    stub = ns["SpmfCounts"]
+    assert C.sizeof(stub) == lib.spmf_sizeof_counts()
+    assert [(n, getattr(stub, n).offset) for n, *_ in stub._fields_] == \
+        [(n, getattr(_lib.CountsStruct, n).offset) for n, *_ in _lib.CountsStruct._fields_]
 
 
 def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
@@ -44,7 +73,7 @@ def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
     n2 = lib.spmf_workspace_bytes(h, 2000, 1)
     assert n2 - n1 == 2 * 1000 * 16 * 4
     # acc_len = 2*D*KP + D + 2*(4+KP)
-    assert lib.spmf_acc_len(h, 3) == 3 * (2 * 1000 * 16 + 1000 + 2 * (4 + 16))
+    assert lib.spmf_acc_len(h, 3) == 3 * (2 * 1000 * 16 + 1000 + 2 * (6 + 16))
     lib.spmf_ctx_destroy(h)
     h3 = C.c_void_p()
     assert lib.spmf_ctx_create(0, 3, 10, 0, C.byref(h3)) == 0

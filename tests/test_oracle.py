@@ -265,3 +265,35 @@ def test_sparse_exact_equals_dense_property(B, D, K, seed, density, xmax, scale_
         ref = groups["data"][n][0].numpy()
         np.testing.assert_allclose(out["grads"][n], ref, rtol=1e-9,
                                    atol=1e-10 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("likelihood,logt", [("poisson", False), ("poisson", True), ("mixed", False)])
+def test_chunked_oracle_driver_equals_one_piece(likelihood, logt):
+    """tests/_chunked_oracle.py (used by the C4 / C5 workload parity tests) adds the
+    same oracle up over row chunks: parts and gradients equal the one-piece call."""
+    import scipy.sparse as sp
+    from _chunked_oracle import data_term, prior_term
+    rng = np.random.default_rng(5)
+    B, D, K = 53, 17, 3
+    x = ((rng.random((B, D)) < 0.3) * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    extra = {}
+    if likelihood == "mixed":
+        mask = np.arange(D) % 2 == 1
+        x[:, mask] = x[:, mask] > 0
+        extra = {"bernoulli_columns": mask}
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, log_transform=logt, likelihood=likelihood,
+                         extra=extra)
+    cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = 5.0
+    params = O.random_params(cfg, 1, 3)
+    parts, grads, split = O.energy_and_grads(cfg, x, params)
+    got = data_term(cfg, sp.csr_matrix(x), params, chunk=16)
+    assert abs(got["x"] - float(parts["x"])) <= 1e-12 * abs(float(parts["x"]))
+    assert abs(got["z"] - float(parts["z"])) <= 1e-12 * abs(float(parts["z"]))
+    for k in ("u", "v", "w", "s"):
+        np.testing.assert_allclose(got["grads"][k], split["data"][k].numpy(), rtol=1e-10, atol=1e-12)
+    pp, pg = prior_term(cfg, params)
+    for k, v in pp.items():
+        assert abs(v - float(parts[k])) <= 1e-12 * abs(float(parts[k]))
+    for k in O.VAR_ORDER:
+        np.testing.assert_allclose(pg[k], split["prior"][k].numpy(), rtol=1e-10, atol=1e-12)
