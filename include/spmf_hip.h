@@ -255,6 +255,13 @@ int spmf_nonfinite_reduce(spmf_ctx* ctx, int64_t n, const float* ll, int pass,
 int spmf_nonfinite_argmin(spmf_ctx* ctx, int64_t n, const float* ll, double index_base,
                           double* io, void* stream);
 
+/* out[0] += sum of lgamma(x+1) over the stored Poisson cells of `counts` whose entry
+ * in rate[n_rows, D] (spmf_dense_ll's output for the same counts) is not a positive
+ * finite number: the cells the rule replaces.  Their lgamma is part of the batch's
+ * pre-summed constant (counts.lgamma_sum) and spmf_nonfinite_patch takes it back out. */
+int spmf_nonfinite_lgamma(spmf_ctx* ctx, const spmf_counts* counts, const float* rate,
+                          double* out, void* stream);
+
 /* Apply the rule (poisson.py:606-616) to the packed accumulators that
  * spmf_data_pass left for S draws of `counts`, VALUE AND GRADIENT, so that a
  * following spmf_finish returns the energy the reference computes when stored
@@ -265,11 +272,12 @@ int spmf_nonfinite_argmin(spmf_ctx* ctx, int64_t n, const float* ll, double inde
  *   cells, replaced cells are worth min_val, whose derivative is that of the
  *   minimum's cell (tf.reduce_min).
  * io = double[4]: [0] global minimum over all S*B*D cells (spmf_nonfinite_reduce
- * pass 0 over spmf_dense_ll output), [3] its cell (spmf_nonfinite_argmin).
+ * pass 0 over spmf_dense_ll output), [3] its cell (spmf_nonfinite_argmin);
+ * nlg = double[S]: spmf_nonfinite_lgamma per draw.
  * Single shard only: with row shards the minimum needs its own (min) all-reduce. */
 int spmf_nonfinite_patch(spmf_ctx* ctx, const spmf_counts* counts, int S,
                          const float* const params[SPMF_NVARS], const float* eta,
-                         const double* io, void* stream);
+                         const double* io, const double* nlg, void* stream);
 
 /* ---- VI step around the energy: surrogate posterior and optimiser ------- */
 /* One latent variable of the mean-field surrogate (poisson.py:403-569).

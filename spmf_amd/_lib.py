@@ -96,8 +96,10 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     "spmf_nonfinite_argmin": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
                                         C.c_void_p, C.c_void_p]),
+    "spmf_nonfinite_lgamma": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "spmf_nonfinite_patch": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int, PtrArray,
-                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spmf_surrogate_fwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "spmf_surrogate_bwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,

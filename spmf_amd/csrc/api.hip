@@ -590,9 +590,21 @@ int spmf_nonfinite_argmin(spmf_ctx* c, int64_t n, const float* ll, double index_
   return SPMF_OK;
 }
 
+int spmf_nonfinite_lgamma(spmf_ctx* c, const spmf_counts* ct, const float* rate, double* out, void* stream) {
+  if (!c || !rate || !out) return fail(c, SPMF_E_ARG, "nonfinite_lgamma: bad arguments");
+  int rc = check_counts(c, ct);
+  if (rc) return rc;
+  if (ct->n_rows == 0 || ct->nnz == 0) return SPMF_OK;
+  DenseLLArgs da{ct->n_rows, c->D, likelihood_code(c), nullptr, nullptr, nullptr, c->ctype, ct->row_ptr, ct->col_idx,
+      ct->val, const_cast<float*>(rate), nullptr};
+  launch_nonfinite_lgamma(da, out, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
 int spmf_nonfinite_patch(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS],
-    const float* eta, const double* io, void* stream) {
-  if (!c || !params || !eta || !io || S < 1) return fail(c, SPMF_E_ARG, "nonfinite_patch: bad arguments");
+    const float* eta, const double* io, const double* nlg, void* stream) {
+  if (!c || !params || !eta || !io || !nlg || S < 1) return fail(c, SPMF_E_ARG, "nonfinite_patch: bad arguments");
   int rc = check_counts(c, ct);
   if (rc) return rc;
   if (!c->acc || c->ws_S < S || c->ws_rows != ct->n_rows) return fail(c, SPMF_E_ARG,
@@ -603,7 +615,7 @@ int spmf_nonfinite_patch(spmf_ctx* c, const spmf_counts* ct, int S, const float*
   if (logt == 1 && ct->nnz > 0 && !ct->gval) return fail(c, SPMF_E_ARG, "nonfinite_patch: log_transform needs counts.gval");
   NfPatchArgs a{c->D, c->K, logt, ct->row_ptr, ct->col_idx, ct->val,
       (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, params[2], params[0], params[1], params[7], eta,
-      c->ctype, c->acc, (int64_t)acc_len(c->D, c->KP), c->Dh > 0 ? c->Dh : c->D, io, ct->n_rows, S};
+      c->ctype, c->acc, (int64_t)acc_len(c->D, c->KP), c->Dh > 0 ? c->Dh : c->D, io, nlg, ct->n_rows, S};
   launch_nonfinite_patch(c->KP, a, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;

@@ -74,7 +74,17 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
   // P fragments: B operand of product 1, step s: B[k][j=c] = P[p][h*KH + s]
   float pb[PB][KH];
   float bp[PB];
-  f32x16 acc[PB][MT];
+  // Two-level accumulation: `acc` is the MFMA accumulator of the current run of FOLD
+  // Q tiles (FOLD*128 terms per output, all of one sign), `tot` the sum of the
+  // finished runs.  One fp32 chain over all NQ terms (30 000 at C4) has a rounding
+  // error of ~sqrt(NQ)*2^-24 of the SUM, which the difference with the stored-cell
+  // term then amplifies (6.9e-5 of max|du| on a C4 slice); runs of 512 bring the
+  // chain error down to ~sqrt(512)*2^-24.
+  // (not in the KD = 32 sigmoid form: it runs two waves per SIMD on a 256-register
+  // budget that the second accumulator set would spill)
+  constexpr int FOLD = 4;
+  constexpr bool TWO_LEVEL = !(KD == 32 && ACT == 1);
+  f32x16 acc[PB][MT], tot[TWO_LEVEL ? PB : 1][TWO_LEVEL ? MT : 1];
   float colsum[PB];
 #pragma unroll
   for (int b = 0; b < PB; ++b) {
@@ -91,7 +101,10 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[b][m][i] = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        acc[b][m][i] = 0.f;
+        if (TWO_LEVEL) tot[b][m][i] = 0.f;
+      }
   }
   double es = 0.0;
   float satc = 0.f;       // ACT 0: cells whose exponent was saturated (exact: < 2^24 per lane)
@@ -263,8 +276,26 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
       if (more) swrite(buf ^ 1, sub);
     }
     es += (double)es_tile;
+    if (TWO_LEVEL && ((tile - tile0) % FOLD) == FOLD - 1) {      // block-uniform: close the run
+#pragma unroll
+      for (int b = 0; b < PB; ++b)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            tot[b][m][i] += acc[b][m][i];
+            acc[b][m][i] = 0.f;
+          }
+    }
     __syncthreads();
   }
+#pragma unroll
+  for (int b = 0; b < PB; ++b)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (TWO_LEVEL) acc[b][m][i] += tot[b][m][i];
   // ---- store: lane holds features (i&3)+8(i>>2)+4h (+32m) of row p --------
 #pragma unroll
   for (int b = 0; b < PB; ++b) {

@@ -165,11 +165,40 @@ __global__ __launch_bounds__(256) void nonfinite_argmin_kernel(int64_t n, const 
   }
 }
 
+// sum of lgamma(x+1) over the stored (Poisson) cells of a dense_ll chunk whose rate is
+// not a positive finite number -- the cells the rule replaces: their lgamma sits in
+// the batch's pre-summed constant and has to be taken back out.  out[0] += sum.
+__global__ __launch_bounds__(256) void nonfinite_lgamma_kernel(int64_t B, int D, int logt,
+                                                               const uint8_t* __restrict__ ctype,
+                                                               const int32_t* __restrict__ row_ptr,
+                                                               const int32_t* __restrict__ col,
+                                                               const float* __restrict__ val,
+                                                               const float* __restrict__ rate,
+                                                               double* __restrict__ out) {
+  __shared__ double red[16];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  double acc = 0.0;
+  for (int64_t b = wave; b < B; b += nwaves) {
+    const int start = row_ptr[b], end = row_ptr[b + 1];
+    for (int i = start + lane; i < end; i += 64) {
+      const int d = col[i];
+      if (logt == 2 || (logt == 3 && ctype[d])) continue;      // Bernoulli cell: no lgamma term
+      const float r = rate[(size_t)b * D + d];
+      const float x = val[i];
+      if (x > 0.f && !(r > 0.f && r < INFINITY)) acc += (double)lgammaf(x + 1.f);
+    }
+  }
+  const double t = block_sum(acc, red);
+  if (threadIdx.x == 0 && t != 0.0) atomicAdd(out, t);
+}
+
 // The replacement rule's effect on the sparse fast path's accumulators
 // (poisson.py:606-616).  The fast path left every non-finite stored cell out of
 // sum x log r.  Under the rule each of them is worth min_val = m (the global
 // minimum - 10) INSTEAD of its whole log-pmf, so per draw s
-//     'x'_s += nnf_s * m + sum_{non-finite cells} lgamma(x+1)
+//     'x'_s += nnf_s * m + sum_{non-finite cells} lgamma(x+1)     (nlg_s[s])
 // (the lgamma of those cells sits in the pre-summed constant; their rate is 0),
 // and since m moves with the minimum's cell (s*, b*, d*), the gradient gains
 //     N * d ll(s*, b*, d*) / d theta_{s*},   N = sum_s nnf_s,
@@ -184,7 +213,8 @@ __global__ __launch_bounds__(256) void nonfinite_patch_kernel(
     const float* __restrict__ val, const float* __restrict__ row_scale, const float* __restrict__ u,
     const float* __restrict__ v, const float* __restrict__ w, const float* __restrict__ s,
     const float* __restrict__ eta, const uint8_t* __restrict__ ctype, float* __restrict__ acc,
-    int64_t acc_stride, int Dh, const double* __restrict__ io, int64_t rows_batch, int S) {
+    int64_t acc_stride, int Dh, const double* __restrict__ io, const double* __restrict__ nlg_s,
+    int64_t rows_batch, int S) {
   const int sd = blockIdx.x;
   const int t = threadIdx.x;
   const AccLayout L{D, KP, Dh};
@@ -198,8 +228,7 @@ __global__ __launch_bounds__(256) void nonfinite_patch_kernel(
   const double m = io[0] - 10.0;
   if (t == 0) {
     const double nnf = (double)tail[4] + (double)tail[5];
-    const double nlg = (double)tail[10] + (double)tail[11];
-    const double v0 = (double)tail[0] + (double)tail[1] + nnf * m + nlg;
+    const double v0 = (double)tail[0] + (double)tail[1] + nnf * m + nlg_s[sd];
     const float hi = (float)v0;
     tail[0] = hi;
     tail[1] = (float)(v0 - (double)hi);
@@ -281,11 +310,18 @@ void launch_nonfinite_argmin(int64_t n, const float* ll, double index_base, doub
   hipLaunchKernelGGL(nonfinite_argmin_kernel, dim3(nb), dim3(256), 0, st, n, ll, index_base, io);
 }
 
+void launch_nonfinite_lgamma(const DenseLLArgs& a, double* out, hipStream_t st) {
+  int64_t want = (a.B + 3) / 4;
+  int nb = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  hipLaunchKernelGGL(nonfinite_lgamma_kernel, dim3(nb), dim3(256), 0, st, a.B, a.D, a.logt, a.ctype,
+                     a.row_ptr, a.col, a.val, a.rate, out);
+}
+
 void launch_nonfinite_patch(int KP, const NfPatchArgs& a, hipStream_t st) {
 #define SPMF_NFP(KP_)                                                                            \
   hipLaunchKernelGGL(nonfinite_patch_kernel<KP_>, dim3(a.S), dim3(256), 0, st, a.D, a.K, a.logt,  \
                      a.row_ptr, a.col, a.val, a.row_scale, a.u, a.v, a.w, a.s, a.eta, a.ctype,     \
-                     a.acc, a.acc_stride, a.Dh, a.io, a.rows_batch, a.S)
+                     a.acc, a.acc_stride, a.Dh, a.io, a.nlg, a.rows_batch, a.S)
   switch (KP) {
     case 4: SPMF_NFP(4); break;
     case 8: SPMF_NFP(8); break;

@@ -101,10 +101,12 @@ struct NfPatchArgs {
   int64_t acc_stride;
   int Dh;                          // column split of the accumulator layout (D = none)
   const double* io;                // [0] global minimum, [3] linear index of its cell
+  const double* nlg;               // [S] sum of lgamma(x+1) over each draw's replaced cells
   int64_t rows_batch;
   int S;
 };
 void launch_nonfinite_patch(int KP, const NfPatchArgs& a, hipStream_t st);
+void launch_nonfinite_lgamma(const DenseLLArgs& a, double* out, hipStream_t st);   // uses B, D, logt, ctype, CSR, rate
 void launch_col_pass(int KP, const ColArgs& a, hipStream_t st);
 
 struct PackArgs {

@@ -368,9 +368,10 @@ class PoissonFactorization:
                 raise NotImplementedError(
                     "the non-finite replacement rule needs a min all-reduce across row "
                     "shards: single shard only (n_nonfinite reports the cells)")
-            io = self._nonfinite_scan(sc, cs, data, S, P)
+            io, nlg = self._nonfinite_scan(sc, cs, data, S, P)
             _lib.check(h, lib.spmf_nonfinite_patch(h, C.byref(cs), S, pin, eta.data_ptr(),
-                                                   io.data_ptr(), stream), "spmf_nonfinite_patch")
+                                                   io.data_ptr(), nlg.data_ptr(), stream),
+                       "spmf_nonfinite_patch")
             _lib.check(h, lib.spmf_finish(h, S, int(rows_g), float(lg_g), float(prior_weight), pin,
                                           eta.data_ptr(), parts.data_ptr(), gout, nnf.data_ptr(),
                                           stream), "spmf_finish")
@@ -461,8 +462,9 @@ class PoissonFactorization:
         reference's where(finite, ll, 0) also puts a 0 into it) and the linear
         index of the cell that attains it.  Evaluated by spmf_dense_ll over row
         chunks of whole panels (at most ``max_cells`` cells at a time), so the
-        dense [B,D] block never has to exist.  Returns io = double[4] on the
-        device: [0] minimum, [3] its cell (+inf if the minimum is the 0)."""
+        dense [B,D] block never has to exist.  Returns (io, nlg): io = double[4]
+        on the device, [0] minimum, [3] its cell (+inf if the minimum is the 0);
+        nlg = double[S], per draw the sum of lgamma(x+1) over the replaced cells."""
         lib = _lib.load()
         eta = self._eta_device()
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -474,6 +476,7 @@ class PoissonFactorization:
         h = self._aux(min(cs.n_rows, step * sc.panel_rows))
         io = torch.zeros(4, dtype=torch.float64, device=self.device)
         io[3] = float("inf")
+        nlg = torch.zeros(S, dtype=torch.float64, device=self.device)
         buf_rows = min(cs.n_rows, step * sc.panel_rows)
         rate = torch.empty(buf_rows * D, dtype=torch.float32, device=self.device)
         ll = torch.empty(buf_rows * D, dtype=torch.float32, device=self.device)
@@ -490,12 +493,17 @@ class PoissonFactorization:
                         P["w"][i].data_ptr(), P["s"][i].data_ptr(), eta.data_ptr(),
                         rate.data_ptr(), ll.data_ptr(), stream), "spmf_dense_ll")
                     r0 = (q0 - int(p0)) * sc.panel_rows
-                    fn(sub.n_rows * D, float(i) * cs.n_rows * D + float(r0) * D)
-        sweep(lambda n, base: _lib.check(h, lib.spmf_nonfinite_reduce(
-            h, n, ll.data_ptr(), 0, io.data_ptr(), stream), "spmf_nonfinite_reduce"))
-        sweep(lambda n, base: _lib.check(h, lib.spmf_nonfinite_argmin(
+                    fn(sub, i, sub.n_rows * D, float(i) * cs.n_rows * D + float(r0) * D)
+
+        def first(sub, i, n, base):
+            _lib.check(h, lib.spmf_nonfinite_reduce(h, n, ll.data_ptr(), 0, io.data_ptr(), stream),
+                       "spmf_nonfinite_reduce")
+            _lib.check(h, lib.spmf_nonfinite_lgamma(h, C.byref(sub), rate.data_ptr(),
+                                                    nlg[i:].data_ptr(), stream), "spmf_nonfinite_lgamma")
+        sweep(first)
+        sweep(lambda sub, i, n, base: _lib.check(h, lib.spmf_nonfinite_argmin(
             h, n, ll.data_ptr(), base, io.data_ptr(), stream), "spmf_nonfinite_argmin"))
-        return io
+        return io, nlg
 
     def unormalized_log_prob(self, data=None, prior_weight=1., **params):
         """poisson.py:575-580 -- NB: like the reference this ignores

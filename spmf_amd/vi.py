@@ -423,6 +423,41 @@ def _clip(grads, clip_value):
     return [g.clamp(-clip_value, clip_value) for g in grads]
 
 
+class PlateauController:
+    """The epoch-level control of the legacy driver, as its recorded stdout shows it
+    (notebooks/factorizing_random_noise.ipynb:122-420: "Saved a checkpoint", "We are
+    in a loss plateau learning rate: ...", "Restoring from a checkpoint", "We have
+    reset 25 times so quitting"; bayesianquilts itself is out of tree
+    [UNVERIFIED-3P]).  Host logic only, no device work:
+
+      update(epoch_loss) ->
+        "improved"   new best: the caller checkpoints the trainables
+        "converged"  the improvement fell under abs_tol / rel_tol: stop
+        "plateau"    no improvement: lr *= lr_decay_factor, the caller restores
+                     the best checkpoint
+        "quit"       like "plateau", and max_decay_steps resets have happened: stop
+    """
+
+    def __init__(self, learning_rate, rel_tol=1e-6, abs_tol=1e-10, max_decay_steps=25,
+                 lr_decay_factor=0.99):
+        self.lr = float(learning_rate)
+        self.rel_tol, self.abs_tol = rel_tol, abs_tol
+        self.max_decay_steps, self.lr_decay_factor = int(max_decay_steps), lr_decay_factor
+        self.best = math.inf
+        self.decays = 0
+
+    def update(self, ep_loss):
+        if ep_loss < self.best:
+            gain = self.best - ep_loss
+            stop = gain < self.abs_tol or (math.isfinite(self.best) and
+                                           gain / abs(self.best) < self.rel_tol)
+            self.best = ep_loss
+            return "converged" if stop else "improved"
+        self.decays += 1
+        self.lr *= self.lr_decay_factor
+        return "quit" if self.decays >= self.max_decay_steps else "plateau"
+
+
 def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=8,
         sample_batches=1, num_steps=100, num_epochs=None, rel_tol=1e-6, abs_tol=1e-10,
         learning_rate=0.01, clip_value=10.0, max_decay_steps=25, lr_decay_factor=0.99,
@@ -435,7 +470,8 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
     sur = model.surrogate_distribution
     opt = AdamHIP(model, sur.trainable_variables, learning_rate)
     epochs = num_epochs if num_epochs is not None else num_steps
-    losses, best, best_state, decays = [], math.inf, None, 0
+    losses, best_state = [], None
+    ctl = PlateauController(learning_rate, rel_tol, abs_tol, max_decay_steps, lr_decay_factor)
     device_loop = all_reduce is None
     if device_loop:
         opt.init_state(clip_value)
@@ -484,28 +520,25 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
         losses.append(ep_loss)
         if verbose and ep % check_every == 0:
             print(f"Epoch: {ep} average-batch loss: {ep_loss}")
-        if ep_loss < best:
-            if best - ep_loss < abs_tol or (math.isfinite(best) and
-                                            (best - ep_loss) / abs(best) < rel_tol):
-                best = ep_loss
-                break
-            best = ep_loss
+        action = ctl.update(ep_loss)
+        if action == "converged":
+            break
+        if action == "improved":
             best_state = [p.detach().clone() for p in sur.trainable_variables]
-        else:
-            decays += 1
-            opt.set_lr(opt.lr * lr_decay_factor)
+            continue
+        opt.set_lr(ctl.lr)
+        if verbose:
+            print(f"We are in a loss plateau learning rate: {opt.lr}")
+        if best_state is not None:
+            with torch.no_grad():
+                for p, b in zip(sur.trainable_variables, best_state):
+                    p.copy_(b)
             if verbose:
-                print(f"We are in a loss plateau learning rate: {opt.lr}")
-            if best_state is not None:
-                with torch.no_grad():
-                    for p, b in zip(sur.trainable_variables, best_state):
-                        p.copy_(b)
-                if verbose:
-                    print("Restoring from a checkpoint")
-            if decays >= max_decay_steps:
-                if verbose:
-                    print(f"We have reset {decays} times so quitting")
-                break
+                print("Restoring from a checkpoint")
+        if action == "quit":
+            if verbose:
+                print(f"We have reset {ctl.decays} times so quitting")
+            break
     if set_expectations:
         model.set_calibration_expectations()
     return losses

@@ -297,3 +297,32 @@ def test_chunked_oracle_driver_equals_one_piece(likelihood, logt):
         assert abs(v - float(parts[k])) <= 1e-12 * abs(float(parts[k]))
     for k in O.VAR_ORDER:
         np.testing.assert_allclose(pg[k], split["prior"][k].numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_c_port_equals_numpy_port():
+    """oracle/sparse_exact_omp.c (the multithreaded port bench.py times as
+    cpu_baseline) == oracle/sparse_exact.py to fp64 rounding, incl. empty rows and
+    columns and an un-scaled run."""
+    import scipy.sparse as sp
+    from oracle import sparse_exact as SE
+    from oracle import sparse_exact_c as SC
+    rng = np.random.default_rng(8)
+    B, D, K = 301, 77, 7
+    x = ((rng.random((B, D)) < 0.1) * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    x[3] = 0
+    x[:, 5] = 0
+    X = sp.csr_matrix(x)
+    eta = rng.uniform(0.5, 3.0, size=D)
+    u = np.abs(rng.normal(0.3, 0.1, size=(D, K)))
+    v = np.abs(rng.normal(0.3, 0.1, size=(K, D)))
+    w = np.abs(rng.normal(0.2, 0.05, size=(1, D)))
+    s = np.abs(rng.normal(0.4, 0.1, size=(2, D)))
+    for scale_rows in (True, False):
+        a = SE.data_term(X, eta, 4.5, scale_rows, u, v, w, s)
+        b = SC.data_term(X, eta, 4.5, scale_rows, u, v, w, s)
+        assert abs(a["x"] - b["x"]) <= 1e-12 * abs(a["x"]) and abs(a["z"] - b["z"]) <= 1e-12 * abs(a["z"])
+        assert a["n_nonfinite"] == b["n_nonfinite"] == 0
+        for k in ("u", "v", "w", "s"):
+            np.testing.assert_allclose(b["grads"][k], a["grads"][k], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(b["z_rows"], a["z_rows"], rtol=1e-12, atol=1e-14)
+    assert SC.max_threads() >= 1

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc.sh <outdir> <bench args...> ; separate PMC passes (no trace domains mixed in)
+# then:  python tools/pmc_traffic.py <outdir> <workload> profiles/pmc_traffic.json
 export TMPDIR=/tmp
 out=$1; shift
 mkdir -p $out
