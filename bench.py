@@ -221,7 +221,9 @@ def main():
         rows = args.rows
     S = args.samples
     # strong scaling: contiguous shards of whole generator chunks
-    chunk = synth.CHUNK_ROWS
+    chunk = {"c5": synth.MIXED_CHUNK_ROWS}.get(args.workload, synth.CHUNK_ROWS)
+    if args.workload.startswith("c4"):
+        chunk = 25_000
     nchunks = -(-rows // chunk)
     c0 = nchunks * rank // world
     c1 = nchunks * (rank + 1) // world
@@ -232,13 +234,12 @@ def main():
     logt = args.workload.startswith("c4")
     mixed_mask = None
     if args.workload == "c5":
-        if world != 1:
-            raise SystemExit("the c5 workload is single-GPU in this bench")
-        sc, mixed_mask = synth.mixed_c5(rows, D, dev, 20241218 + 5, panel_rows=args.panel_rows)
+        # BASELINE.json config 5 names 4 GPUs: row shards like C3
+        sc, mixed_mask = synth.mixed_c5(my_rows, D, dev, 20241218 + 5, panel_rows=args.panel_rows,
+                                        first_chunk=c0, chunk_rows=chunk)
     elif logt:
-        per = 25_000
-        sc = synth.scrna_like(my_rows, D, dev, 20241218 + 4, first_chunk=c0 * (chunk // per),
-                              panel_rows=args.panel_rows, chunk_rows=per,
+        sc = synth.scrna_like(my_rows, D, dev, 20241218 + 4, first_chunk=c0,
+                              panel_rows=args.panel_rows, chunk_rows=chunk,
                               target_density=density)
     else:
         # --split: gradient accumulators and work items in two column halves, so the
@@ -291,8 +292,13 @@ def main():
 
     hook = None
     if distributed:
-        from spmf_amd.dist import ShardReducer
-        hook = ShardReducer()
+        from spmf_amd.dist import LibraryComm, ShardReducer
+        # SPMF_BENCH_COMM=lib: the library's own RCCL communicator (spmf_allreduce) moves the
+        # accumulators; default: torch.distributed's (the transport rehearsed on CPU with gloo)
+        comm = None
+        if os.environ.get("SPMF_BENCH_COMM") == "lib" and backend == "nccl":
+            comm = LibraryComm(model)
+        hook = ShardReducer(comm=comm)
         hook.set_batch_totals(rows_g, lgam_g)
 
     lib, h = _lib.load(), model._handle()

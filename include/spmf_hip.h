@@ -68,6 +68,10 @@ extern "C" {
                                      * Bernoulli(logits) on the columns flagged by spmf_ctx_set_column_types, Poisson
                                      * on the others; linear decoder only */
 #define SPMF_FLAG_LOG_TRANSFORM 2u  /* poisson.py:41-42,52-53: sparse stored-cell terms + dense f32-MFMA exp sums */
+#define SPMF_FLAG_ABS_HORSESHOE 16u /* horshoe_plus=False (poisson.py:378-398): AbsHorseshoe priors on u (scale
+                                     * u_tau_scale*decay^k) and s (scale s_tau_scale); only the variables v, w, u, s
+                                     * (indices 0, 1, 2, 7) exist: the other params / grads pointers are ignored
+                                     * (may be NULL) and their energy parts are 0 */
 
 typedef struct spmf_ctx spmf_ctx;
 
@@ -198,6 +202,22 @@ int spmf_data_pass_split(spmf_ctx* ctx, const spmf_counts* counts, int S,
                          const float* const params[SPMF_NVARS], const float* eta, int part,
                          void* stream);
 
+/* ---- the step's one collective, inside the library (RCCL over xGMI) ---------
+ * Row shards of the count matrix live on different GPUs, one process per GPU
+ * (the reference has no counterpart: only the `strategy` pass-through,
+ * poisson.py:60,72).  Between spmf_data_pass and spmf_finish every rank sums the
+ * packed accumulators:  spmf_allreduce(ctx, spmf_acc_ptr(ctx), spmf_acc_len(ctx,S),
+ * stream) -- ncclAllReduce(float, sum) on the caller's stream, so the collective is
+ * stream-ordered with the kernels around it and needs no host synchronisation.
+ * librccl is bound at run time (dlopen); without it these return SPMF_E_UNSUPPORTED
+ * and single-GPU use is unaffected.  Set-up: rank 0 calls spmf_comm_unique_id, the
+ * 128 bytes travel to the other ranks by any channel the host has (the Python
+ * mirror uses a torch.distributed broadcast), every rank calls spmf_comm_init. */
+int spmf_comm_unique_id(void* out128);
+int spmf_comm_init(spmf_ctx* ctx, const void* id128, int rank, int world);
+int spmf_allreduce(spmf_ctx* ctx, float* buf, int64_t n, void* stream);
+int spmf_comm_destroy(spmf_ctx* ctx);
+
 /* Phase 2: chain the accumulators to d/d(u,v,w,s), add the horseshoe-plus
  * prior (poisson.py:228-377) parts and gradients for all 12 variables, and
  * finish the 14 energy parts.  n_rows_global / lgamma_sum_global are the
@@ -208,7 +228,8 @@ int spmf_data_pass_split(spmf_ctx* ctx, const spmf_counts* counts, int S,
  *   literal 1.); a minibatch driver passes B/N.
  *   n_nonfinite[2*S] (fp64, may be NULL): [s] = stored cells of draw s whose
  *   log-pmf was not finite; the sparse fast path assumes 0 (poisson.py:606-616
- *   is then the identity).  [S+s] = cells of draw s (all B*D of them) whose
+ *   is then the identity).  [S+s] = saturation events of draw s: the number of
+ *   workgroups of the dense exp kernel (128 rows x all columns each) in which a
  *   log_transform exponent exceeded 70 and was saturated there: fp32 cannot
  *   hold exp(y) beyond y ~ 88 where the fp64 reference still can, so the decoder
  *   is evaluated as exp(min(y,70)) - 1; 0 means the decoder was exact. */
@@ -305,6 +326,17 @@ typedef struct spmf_sur_var {
   int64_t noise_ld;
 } spmf_sur_var;
 
+/* Base noise for every variable, drawn on the device into the caller's noise
+ * (and, kind 2, dgda) buffers: eps ~ N(0,1), or g ~ Gamma(softplus(t0), 1) with
+ * its implicit-reparameterisation derivative d g / d concentration.  Counter-based
+ * (Philox4x32-10): the draw is a pure function of (seed, counter [+ state[13]],
+ * variable index, draw, element), so replicas on different ranks that pass the
+ * same seed draw the same noise, and a step replayed from a hipGraph gets fresh
+ * noise through the device-resident step counter state[13] (spmf_vi_gate advances
+ * it; pass state = NULL to use `counter` alone). */
+int spmf_sample_noise(spmf_ctx* ctx, const spmf_sur_var* vars, int nvars, int S, uint64_t seed,
+                      uint64_t counter, const double* state, void* stream);
+
 /* theta for every variable and logq[S] (fp64) = sum over variables and
  * elements of log q(theta). */
 int spmf_surrogate_fwd(spmf_ctx* ctx, const spmf_sur_var* vars, int nvars, int S,
@@ -338,6 +370,7 @@ int spmf_adam_step(spmf_ctx* ctx, const spmf_adam_var* tensors, int ntensors, do
  *   [5] beta1^t  [6] beta2^t  [7] t                               (init 1, 1, 0)
  *   [8] loss of the last step  [9] 1 if it was applied, 0 if skipped
  *   [10] sum of applied losses  [11] applied steps  [12] skipped steps
+ *   [13] steps gated so far, applied or not (the RNG step counter of spmf_sample_noise)
  * spmf_vi_gate computes loss = -mean_s[x + z + c*(prior - log q)]/rows from the
  * [S,14] parts of spmf_finish and log q of spmf_surrogate_fwd (SURVEY 8a row
  * 14), marks the step skipped when the loss is not finite or a stored cell's

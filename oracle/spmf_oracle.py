@@ -45,6 +45,9 @@ LGAMMA_HALF = math.lgamma(0.5)
 #: (poisson.py:403-539 -> var_list at :572).  Also the checkpoint order.
 VAR_ORDER = ("v", "w", "u", "u_eta", "u_tau", "s_eta", "s_tau", "s",
              "u_eta_a", "u_tau_a", "s_eta_a", "s_tau_a")
+#: horshoe_plus=False (poisson.py:378-398, surrogate :540-565): only these four
+#: variables exist, in the order the surrogate_dict lists them (v, w, then s, u)
+VAR_ORDER_ABS = ("v", "w", "s", "u")
 
 
 def var_shapes(D: int, K: int) -> Dict[str, tuple]:
@@ -80,6 +83,14 @@ class OracleConfig:
     # poisson.py; encode is the Poisson one (row scaling per scale_rows).
     likelihood: str = "poisson"
     extra: dict = field(default_factory=dict)
+    # poisson.py:62,244 (``horshoe_plus`` sic): True = hierarchical horseshoe-plus prior
+    # on u and s (12 variables); False = AbsHorseshoe priors on u and s directly
+    # (:378-398; 4 variables v, w, s, u)
+    horseshoe_plus: bool = True
+
+    @property
+    def var_order(self):
+        return VAR_ORDER if self.horseshoe_plus else VAR_ORDER_ABS
 
 
 def _t(x):
@@ -112,6 +123,34 @@ def sqrt_inverse_gamma_log_prob(y, concentration, scale):
 def normal_log_prob(y, scale):
     """tfd.Normal(0, scale).log_prob(y)."""
     return -0.5 * math.log(2.0 * math.pi) - torch.log(scale) - 0.5 * (y / scale) ** 2
+
+
+def horseshoe_log_prob(x, scale):
+    """tfd.Horseshoe(scale).log_prob(x): tensorflow_probability's closed-form
+    APPROXIMATION of the (intractable) HalfCauchy-Normal marginal log-density
+    (tensorflow_probability/python/distributions/horseshoe.py, ``_log_prob``;
+    the log-space form of the bounds of Carvalho, Polson & Scott 2010).  Restated
+    from that published source [UNVERIFIED-3P: TFP is not installed here]; pinned
+    in tests/test_oracle.py against numerical quadrature of the exact density,
+    from which it differs by at most 6e-4 nats (asymptotically exact at both
+    ends) -- the accuracy a wrong constant would destroy."""
+    xx = (x / scale) ** 2 / 2.0
+    g = 0.5614594835668851            # exp(-EulerGamma)
+    b = 1.0420764938351215            # sqrt(2 (1-g) / (g (2-g)))
+    h_inf = 1.0801359952503342        # (1-g)(g^2-6g+12) / (3 g (2-g)^2 b)
+    q = 20.0 / 47.0 * xx ** 1.0919284281983377
+    h = 1.0 / (1.0 + xx ** 1.5) + h_inf * q / (1.0 + q)
+    c = -0.5 * math.log(2.0 * math.pi ** 3) - torch.log(g * scale)
+    z = math.log1p(-g) - math.log(g)
+    return (-torch.nn.functional.softplus(z - xx / (1.0 - g))
+            + torch.log(torch.log1p(g / xx - (1.0 - g) / (h + b * xx) ** 2)) + c)
+
+
+def abs_horseshoe_log_prob(y, scale):
+    """bayesianquilts AbsHorseshoe (poisson.py:16,382,391): the law of |X|,
+    X ~ Horseshoe(scale): the symmetric density folded onto y >= 0
+    [UNVERIFIED-3P: bayesianquilts is not installed and not pinned]."""
+    return horseshoe_log_prob(y, scale) + math.log(2.0)
 
 
 def bernoulli_log_prob(x, logits):
@@ -236,6 +275,13 @@ def prior_log_prob_parts(cfg: OracleConfig, p: Dict[str, torch.Tensor]):
     else:
         out["v"] = sm(halfnormal_log_prob(p["v"], torch.tensor(0.1, dtype=F64)))
         out["w"] = sm(halfnormal_log_prob(p["w"], one))
+    if not cfg.horseshoe_plus:                                   # poisson.py:378-398
+        out["u"] = sm(abs_horseshoe_log_prob(
+            p["u"], torch.tensor(cfg.u_tau_scale, dtype=F64) * decay * torch.ones_like(p["u"])))
+        # scale [1,D] broadcasts over the two rows of s [2,D] (:391-397)
+        out["s"] = sm(abs_horseshoe_log_prob(
+            p["s"], torch.tensor(cfg.s_tau_scale, dtype=F64) * torch.ones_like(p["s"])))
+        return out
     out["u"] = sm(halfnormal_log_prob(
         p["u"], p["u_eta"] * p["u_tau"] * decay))                # :247-251
     out["s"] = sm(halfnormal_log_prob(p["s"], p["s_eta"] * p["s_tau"]))
@@ -332,7 +378,8 @@ def surrogate_initial_state(cfg: OracleConfig):
     st = {}
     st["v"] = dict(kind="normal", loc=-6.0 * ones("v"), scale=5e-4 * ones("v"))
     st["w"] = dict(kind="normal", loc=-6.0 * ones("w"), scale=5e-4 * ones("w"))
-    st["u"] = dict(kind="normal", loc=-6.0 * ones("u"), scale=5e-4 * ones("u"))
+    st["u"] = dict(kind="normal", loc=(-6.0 if cfg.horseshoe_plus else -9.0) * ones("u"),
+                   scale=5e-4 * ones("u"))                       # :427-437 / :556
     st["u_eta"] = dict(kind="invgamma", concentration=3.0 * ones("u_eta"),
                        scale=ones("u_eta"))
     st["u_tau"] = dict(kind="invgamma", concentration=3.0 * ones("u_tau"),
@@ -352,6 +399,8 @@ def surrogate_initial_state(cfg: OracleConfig):
                          scale=ones("s_eta_a"))
     st["s_tau_a"] = dict(kind="invgamma", concentration=2.0 * ones("s_tau_a"),
                          scale=ones("s_tau_a") / cfg.s_tau_scale ** 2)
+    if not cfg.horseshoe_plus:
+        st = {n: st[n] for n in VAR_ORDER_ABS}                   # :540-565
     return st
 
 
@@ -394,8 +443,10 @@ def random_params(cfg: OracleConfig, S: int, seed: int, spread: float = 0.3,
             "s_eta": 0.9, "s_tau": 0.7, "s": 0.4, "u_eta_a": 1.2,
             "u_tau_a": 1.5, "s_eta_a": 1.1, "s_tau_a": 0.9}
     out = {}
-    for n in VAR_ORDER:
+    for n in VAR_ORDER:                     # (all twelve are drawn so that seeds agree;
         out[n] = base[n] * np.exp(spread * rng.standard_normal((S,) + sh[n]))
         if fp32_exact:
             out[n] = out[n].astype(np.float32).astype(np.float64)
+    if not cfg.horseshoe_plus:              #  the AbsHorseshoe model keeps its four)
+        out = {n: out[n] for n in VAR_ORDER_ABS}
     return out

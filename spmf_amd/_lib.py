@@ -24,6 +24,9 @@ FLAG_SCALE_ROWS = 1
 FLAG_LOG_TRANSFORM = 2
 FLAG_BERNOULLI = 4
 FLAG_MIXED = 8
+FLAG_ABS_HORSESHOE = 16
+#: horshoe_plus=False: the four variables of poisson.py:378-398 in surrogate order (:540-565)
+VAR_ORDER_ABS = ("v", "w", "s", "u")
 
 
 class SpmfError(RuntimeError):
@@ -94,6 +97,10 @@ SIGNATURES = {
     "spmf_dense_ll": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct)] + [C.c_void_p] * 8),
     "spmf_nonfinite_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p]),
+    "spmf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "spmf_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "spmf_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "spmf_comm_destroy": (C.c_int, [C.c_void_p]),
     "spmf_nonfinite_argmin": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
                                         C.c_void_p, C.c_void_p]),
     "spmf_nonfinite_lgamma": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_void_p,
@@ -102,6 +109,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spmf_surrogate_fwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p]),
+    "spmf_sample_noise": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int, C.c_uint64,
+                                    C.c_uint64, C.c_void_p, C.c_void_p]),
     "spmf_surrogate_bwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_void_p]),
     "spmf_ctx_set_column_split": (C.c_int, [C.c_void_p, C.c_int]),

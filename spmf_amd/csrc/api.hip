@@ -2,6 +2,7 @@
 // Host-side orchestration only: argument checks, workspace carving, stream
 // ordered launches.  No device allocation, no host<->device copies, no
 // synchronisation on the hot path (timing taps excepted, off by default).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -45,8 +46,52 @@ struct spmf_ctx {
   int batched = 0;                // the bound workspace holds per-draw tables (S draws per launch)
   int prior_pending = 0;          // S of the launched prior half, 0 = none
   const double* prior_parts = nullptr;
+  void* comm = nullptr;           // ncclComm_t of the row-shard collective (spmf_comm_init)
+  int comm_rank = 0, comm_world = 1;
   std::string err;
 };
+
+// ---- RCCL, bound at run time ------------------------------------------------
+// The library does not link librccl: single-GPU users never need it.  spmf_comm_*
+// dlopen it on first use; the few entry points used are declared here with the
+// ABI of <rccl/rccl.h> (ncclUniqueId = 128 opaque bytes, passed by value).
+namespace {
+struct RcclId { char internal[128]; };
+typedef int (*fn_get_id)(RcclId*);
+typedef int (*fn_init_rank)(void**, int, RcclId, int);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+struct Rccl {
+  void* h = nullptr;
+  fn_get_id get_id = nullptr;
+  fn_init_rank init_rank = nullptr;
+  fn_allreduce allreduce = nullptr;
+  fn_destroy destroy = nullptr;
+  fn_errstr errstr = nullptr;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.h) break;
+    }
+    if (r.h) {
+      r.get_id = (fn_get_id)dlsym(r.h, "ncclGetUniqueId");
+      r.init_rank = (fn_init_rank)dlsym(r.h, "ncclCommInitRank");
+      r.allreduce = (fn_allreduce)dlsym(r.h, "ncclAllReduce");
+      r.destroy = (fn_destroy)dlsym(r.h, "ncclCommDestroy");
+      r.errstr = (fn_errstr)dlsym(r.h, "ncclGetErrorString");
+      if (!r.get_id || !r.init_rank || !r.allreduce || !r.destroy) r.h = nullptr;
+    }
+  }
+  return r.h ? &r : nullptr;
+}
+constexpr int kNcclFloat = 7, kNcclSum = 0;   // ncclFloat32, ncclSum (rccl.h enums)
+}  // namespace
 
 static int fail(spmf_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -145,6 +190,10 @@ void spmf_ctx_destroy(spmf_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->comm) {
+    Rccl* r = rccl();
+    if (r) (void)r->destroy(c->comm);
+  }
   delete c;
 }
 
@@ -444,8 +493,10 @@ static int likelihood_code(const spmf_ctx* c) {
 int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const params[SPMF_NVARS],
     const float* eta, double* parts, float* const grads[SPMF_NVARS], void* stream) {
   if (!c || !params || !grads || !eta || !parts || S < 1) return fail(c, SPMF_E_ARG, "prior_async: bad arguments");
+  const bool hsf = (c->flags & SPMF_FLAG_ABS_HORSESHOE) != 0;
   for (int i = 0; i < SPMF_NVARS; ++i)
-    if (!params[i] || !grads[i]) return fail(c, SPMF_E_ARG, "prior_async: all 12 params/grads must be non-null");
+    if ((!params[i] || !grads[i]) && !(hsf && i != 0 && i != 1 && i != 2 && i != 7))
+      return fail(c, SPMF_E_ARG, "prior_async: params/grads must be non-null (all 12; v,w,u,s with ABS_HORSESHOE)");
   hipStream_t st = (hipStream_t)stream;
   if (!c->side) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -454,13 +505,13 @@ int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const
   }
   // outputs are zeroed in stream order, then the side stream forks off `stream`
   launch_zero(parts, (size_t)S * SPMF_NPARTS * sizeof(double), st);
-  launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
+  if (!hsf) launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
   HIPCHK(c, hipEventRecord(c->ev_fork, st));
   HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
   {
     // one launch for all S draws (gridDim.y)
     FinishArgs fa{c->D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, nullptr, nullptr,
-        params, eta, grads, parts, nullptr, likelihood_code(c), c->ctype, c->Dh, S, 0, {}};
+        params, eta, grads, parts, nullptr, likelihood_code(c), c->ctype, c->Dh, S, 0, {}, hsf ? 1 : 0};
     for (int i = 0; i < SPMF_NVARS; ++i) fa.vstride[i] = (int64_t)var_size(c, i);
     launch_finish(c->KP, fa, 1, c->side);
   }
@@ -476,8 +527,10 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
     double* n_nonfinite, void* stream) {
   if (!c || !params || !grads || !eta || !parts || S < 1) return fail(c, SPMF_E_ARG, "finish: bad arguments");
   if (!c->acc || c->ws_S < S) return fail(c, SPMF_E_ARG, "finish: no data pass precedes it for this S");
+  const bool hsf = (c->flags & SPMF_FLAG_ABS_HORSESHOE) != 0;
   for (int i = 0; i < SPMF_NVARS; ++i)
-    if (!params[i] || !grads[i]) return fail(c, SPMF_E_ARG, "finish: all 12 params/grads must be non-null");
+    if ((!params[i] || !grads[i]) && !(hsf && i != 0 && i != 1 && i != 2 && i != 7))
+      return fail(c, SPMF_E_ARG, "finish: params/grads must be non-null (all 12; v,w,u,s with ABS_HORSESHOE)");
   hipStream_t st = (hipStream_t)stream;
   const int KP = c->KP, D = c->D;
   const size_t al_ = acc_len(D, KP);
@@ -490,14 +543,14 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   } else {
     launch_zero(parts, (size_t)S * SPMF_NPARTS * sizeof(double), st);
-    launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
+    if (!hsf) launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
   }
   {
     // one launch for all S draws (gridDim.y)
     const bool tm = c->timing;
     FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight,
         c->acc, c->dprep, params, eta, grads, parts, n_nonfinite, likelihood_code(c), c->ctype, c->Dh, S,
-        (int64_t)al_, {}};
+        (int64_t)al_, {}, hsf ? 1 : 0};
     for (int i = 0; i < SPMF_NVARS; ++i) fa.vstride[i] = (int64_t)var_size(c, i);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
     launch_finish(KP, fa, joined ? 2 : 0, st);
@@ -582,6 +635,60 @@ int spmf_nonfinite_reduce(spmf_ctx* c, int64_t n, const float* ll, int pass, dou
   return SPMF_OK;
 }
 
+// ---- row-shard collective inside the library (spmf_allreduce) ---------
+int spmf_comm_unique_id(void* out128) {
+  if (!out128) return SPMF_E_ARG;
+  Rccl* r = rccl();
+  if (!r) return SPMF_E_UNSUPPORTED;
+  RcclId id;
+  const int rc = r->get_id(&id);
+  if (rc != 0) return SPMF_E_HIP;
+  memcpy(out128, &id, sizeof id);
+  return SPMF_OK;
+}
+
+int spmf_comm_init(spmf_ctx* c, const void* id128, int rank, int world) {
+  if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(c, SPMF_E_ARG, "comm_init: bad arguments");
+  Rccl* r = rccl();
+  if (!r) return fail(c, SPMF_E_UNSUPPORTED, "comm_init: librccl.so.1 could not be loaded");
+  if (c->comm) {
+    (void)r->destroy(c->comm);
+    c->comm = nullptr;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  RcclId id;
+  memcpy(&id, id128, sizeof id);
+  void* comm = nullptr;
+  const int rc = r->init_rank(&comm, world, id, rank);
+  if (rc != 0) return fail(c, SPMF_E_HIP, std::string("ncclCommInitRank: ") + (r->errstr ? r->errstr(rc) : "?"));
+  c->comm = comm;
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return SPMF_OK;
+}
+
+int spmf_allreduce(spmf_ctx* c, float* buf, int64_t n, void* stream) {
+  if (!c || !buf || n < 0) return fail(c, SPMF_E_ARG, "allreduce: bad arguments");
+  if (!c->comm) return fail(c, SPMF_E_ARG, "allreduce: spmf_comm_init was not called");
+  if (n == 0) return SPMF_OK;
+  Rccl* r = rccl();
+  const int rc = r->allreduce(buf, buf, (size_t)n, kNcclFloat, kNcclSum, c->comm, (hipStream_t)stream);
+  if (rc != 0) return fail(c, SPMF_E_HIP, std::string("ncclAllReduce: ") + (r->errstr ? r->errstr(rc) : "?"));
+  return SPMF_OK;
+}
+
+int spmf_comm_destroy(spmf_ctx* c) {
+  if (!c) return SPMF_E_ARG;
+  if (c->comm) {
+    Rccl* r = rccl();
+    if (r) (void)r->destroy(c->comm);
+    c->comm = nullptr;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+  }
+  return SPMF_OK;
+}
+
 int spmf_nonfinite_argmin(spmf_ctx* c, int64_t n, const float* ll, double index_base, double* io, void* stream) {
   if (!c || !ll || !io || n < 0 || !(index_base >= 0.0)) return fail(c, SPMF_E_ARG, "nonfinite_argmin: bad arguments");
   if (n == 0) return SPMF_OK;
@@ -638,6 +745,26 @@ int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
   hipStream_t st = (hipStream_t)stream;
   launch_zero(logq, (size_t)S * sizeof(double), st);
   launch_surrogate_fwd(T, nvars, max_n, S, logq, st);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_sample_noise(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, uint64_t seed, uint64_t counter,
+    const double* state, void* stream) {
+  if (!c || !vars || nvars < 1 || nvars > 12 || S < 1 || S > 65535) return fail(c, SPMF_E_ARG,
+      "sample_noise: bad arguments");
+  SurTable T;
+  int max_n = 0;
+  for (int i = 0; i < nvars; ++i) {
+    const spmf_sur_var& v = vars[i];
+    if (!v.t0 || !v.noise || v.n < 1 || v.kind < 0 || v.kind > 2 || (v.kind == 2 && !v.dgda)) return fail(c,
+        SPMF_E_ARG, "sample_noise: bad variable (t0 / noise / dgda buffers)");
+    if (v.noise_ld != 0 && v.noise_ld < v.n) return fail(c, SPMF_E_ARG, "surrogate: noise_ld < n");
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident,
+        v.noise_ld ? v.noise_ld : (int64_t)v.n};
+    if (v.n > max_n) max_n = v.n;
+  }
+  launch_sample_noise(T, nvars, max_n, S, seed, counter, state, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;
 }

@@ -21,8 +21,8 @@ constexpr int kDaccHead = 6;
 // reference overflows at 709); saturating keeps every sum and gradient of a
 // step finite (70: D * e^70 * |V'| stays far below FLT_MAX for any supported D),
 // so a batch with a few runaway cells still trains -- its gradient pushes their
-// exponents down -- instead of being skipped.  The cells with y > kYSat are
-// counted (dacc[4]); while that count is 0 the decoder is exact.
+// exponents down -- instead of being skipped.  Saturation events are counted
+// (dacc[4], workgroup granularity); while that count is 0 the decoder is exact.
 constexpr float kYSat = 70.0f;
 // the block sums land in one of kDaccRep replicas (blockIdx % kDaccRep) so the
 // fp64 atomics of thousands of blocks do not serialise on 4+KP addresses;

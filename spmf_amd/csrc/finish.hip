@@ -72,6 +72,32 @@ __device__ __forceinline__ void ig_half(float a, float beta, float half_log_beta
   ga = -1.5f * ia + beta * ia * ia;
 }
 
+// tfd.Horseshoe(scale).log_prob (TFP's closed-form approximation of the HalfCauchy-Normal
+// marginal, tensorflow_probability/python/distributions/horseshoe.py; restated and pinned
+// against quadrature in oracle/spmf_oracle.py horseshoe_log_prob) folded onto x >= 0
+// (bayesianquilts AbsHorseshoe, poisson.py:382,391), and its derivative in x.
+__device__ __forceinline__ void abs_horseshoe(double x, double sigma, double& lp, double& dlp) {
+  constexpr double g = 0.5614594835668851, b = 1.0420764938351215, h_inf = 1.0801359952503342;
+  constexpr double p = 1.0919284281983377;
+  const double xs = x / sigma;
+  const double t = 0.5 * xs * xs;
+  const double st = sqrt(t), t15 = t * st;
+  const double q = (20.0 / 47.0) * pow(t, p);
+  const double h = 1.0 / (1.0 + t15) + h_inf * q / (1.0 + q);
+  const double a = (log1p(-g) - log(g)) - t / (1.0 - g);
+  const double sp = a > 0.0 ? a + log1p(exp(-a)) : log1p(exp(a));
+  const double hb = h + b * t;
+  const double A = g / t - (1.0 - g) / (hb * hb);
+  const double L = log1p(A);
+  lp = -sp + log(L) - 0.5 * log(2.0 * 3.14159265358979323846 * 3.14159265358979323846 * 3.14159265358979323846)
+       - log(g * sigma) + kLog2;
+  const double sg = 1.0 / (1.0 + exp(-a));
+  const double dq = p * q / t;
+  const double dh = -1.5 * st / ((1.0 + t15) * (1.0 + t15)) + h_inf * dq / ((1.0 + q) * (1.0 + q));
+  const double dA = -g / (t * t) + 2.0 * (1.0 - g) * (dh + b) / (hb * hb * hb);
+  dlp = (sg / (1.0 - g) + dA / ((1.0 + A) * L)) * x / (sigma * sigma);
+}
+
 // PHASE 0: everything (one launch).  PHASE 1: the prior half only -- all twelve
 // log-densities and pw * d prior/d theta written to G; needs nothing from the
 // data pass, so the host runs it on a side stream beside the sparse passes.
@@ -87,14 +113,16 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
                                                      double* __restrict__ parts,
                                                      double* __restrict__ nnf_out, int logt,
                                                      const uint8_t* __restrict__ ctype, int Dh,
-                                                     int64_t acc_stride, VStride VS) {
+                                                     int64_t acc_stride, VStride VS, int hs) {
+  // hs: horshoe_plus=False (poisson.py:378-398): AbsHorseshoe priors on u and s, no
+  // scale hierarchy -- only P/G[V_, W_, U_, S_] are touched
   constexpr bool PRIOR = PHASE != 2, DATA = PHASE != 1;
   if (gridDim.y > 1) {   // S draws per launch: everything per draw moves by its stride
     const size_t sd = blockIdx.y;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-      P.p[i] += sd * (size_t)VS.v[i];
-      G.p[i] += sd * (size_t)VS.v[i];
+      if (P.p[i]) P.p[i] += sd * (size_t)VS.v[i];
+      if (G.p[i]) G.p[i] += sd * (size_t)VS.v[i];
     }
     if (acc) acc += sd * (size_t)acc_stride;
     if (dprep) dprep += sd * (size_t)(KP + 1);
@@ -127,7 +155,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     // log_transform: the dense kernel already subtracted sum_b E_bd z_b from gV'
     // (mixed, code 3: still needed for the Poisson columns)
     zsum_s[t] = (!DATA || logt == 1 || logt == 2) ? 0.f : (float)unpack(tail, kDaccHead + t);
-    utau_s[t] = t < K ? P.p[UTAU_][t] : 1.f;
+    utau_s[t] = hs ? u_tau_scale : (t < K ? P.p[UTAU_][t] : 1.f);   // hs: scale = u_tau_scale * decay^k
     dec_s[t] = (float)pow((double)decay, (double)t);   // powf is ~1e-6 off at t~60: a systematic part error
     gutau_s[t] = 0.f;
     if (PRIOR) {
@@ -170,8 +198,8 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     const bool on = e < KP * FTD && d < D && k < K;
     const size_t i = on ? (size_t)d * K + k : 0;
     in_u[it] = on ? P.p[U_][i] : 0.f;
-    in_ue[it] = (PRIOR && on) ? P.p[UETA_][i] : 1.f;
-    in_ua[it] = (PRIOR && on) ? P.p[UETAA_][i] : 1.f;
+    in_ue[it] = (PRIOR && on && !hs) ? P.p[UETA_][i] : 1.f;
+    in_ua[it] = (PRIOR && on && !hs) ? P.p[UETAA_][i] : 1.f;
     in_ga[it] = (DATA && on) ? gAp[(size_t)d * KP + k] : 0.f;
   }
 #pragma unroll
@@ -190,7 +218,12 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
         ga_u = u * dA;
         du = w1s[dl] * dA;
       }
-      if (PRIOR) {
+      if (PRIOR && hs) {
+        double lp, dlp;
+        abs_horseshoe((double)u, scd_s[k], lp, dlp);
+        part[U_] += lp;
+        G.p[U_][i] = du + pw * (float)dlp;
+      } else if (PRIOR) {
         const float ue = in_ue[it], ua = in_ua[it];
         const float sc = utau_s[k] * dec_s[k];
         // the three log-densities share their fp64 logs (software fp64 log is what
@@ -276,9 +309,10 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     const float e = etas_[t];
     const float s0 = P.p[S_][d], s1 = P.p[S_][D + d], w = P.p[W_][d];
     // all operands before the first store (see the [D,K] loop)
-    const float se0 = PRIOR ? P.p[SETA_][d] : 1.f, se1 = PRIOR ? P.p[SETA_][D + d] : 1.f;
-    const float stau = PRIOR ? P.p[STAU_][d] : 1.f, sta = PRIOR ? P.p[STAUA_][d] : 1.f;
-    const float sa0 = PRIOR ? P.p[SETAA_][d] : 1.f, sa1 = PRIOR ? P.p[SETAA_][D + d] : 1.f;
+    const bool hier = PRIOR && !hs;
+    const float se0 = hier ? P.p[SETA_][d] : 1.f, se1 = hier ? P.p[SETA_][D + d] : 1.f;
+    const float stau = hier ? P.p[STAU_][d] : 1.f, sta = hier ? P.p[STAUA_][d] : 1.f;
+    const float sa0 = hier ? P.p[SETAA_][d] : 1.f, sa1 = hier ? P.p[SETAA_][D + d] : 1.f;
     const float gph_d = DATA ? gph[d] : 0.f;
     float dw = 0.f, ds0 = 0.f, ds1 = 0.f;
     if (DATA) {
@@ -298,6 +332,14 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       if (bern_s[t]) lp -= kLog2;     // Bernoulli column: w ~ Normal(0,1) (bernoulli.py:201-216)
       part[W_] += (double)lp;
       G.p[W_][d] = dw + pw * gy;
+      if (hs) {
+        double l0, g0, l1, g1;
+        abs_horseshoe((double)s0, (double)s_tau_scale, l0, g0);
+        abs_horseshoe((double)s1, (double)s_tau_scale, l1, g1);
+        part[S_] += l0 + l1;
+        G.p[S_][d] = ds0 + pw * (float)g0;
+        G.p[S_][D + d] = ds1 + pw * (float)g1;
+      } else {
       double lp0, lp1;
       float gy0, gs0, gy1, gs1;
       halfnormal(s0, se0 * stau, lp0, gy0, gs0);
@@ -325,6 +367,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       ig_half(sta, beta, 0.5f * logf(beta), c_lp, c_ga);
       part[STAUA_] += (double)c_lp;
       G.p[STAUA_][d] = pw * (a_ga + c_ga);
+      }
     } else {
       G.p[W_][d] += dw;
       G.p[S_][d] += ds0;
@@ -334,7 +377,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   __syncthreads();
   if (PRIOR) {
     // ---- [1,K] vectors: u_tau, u_tau_a (block 0 adds their own prior) ------
-    if (t < K) {
+    if (t < K && !hs) {
       float g = gutau_s[t];
       if (blockIdx.x == 0) {
         const float ut = P.p[UTAU_][t], uta = P.p[UTAUA_][t];
@@ -422,7 +465,7 @@ static void launch_finish_t(const FinishArgs& a, int phase, hipStream_t st) {
                      (double)a.B_global, a.lgamma_sum, (float)a.u_tau_scale,                     \
                      (float)a.s_tau_scale, a.decay, (float)a.prior_weight, a.acc, a.dprep, P,    \
                      a.eta, G, a.parts, a.n_nonfinite, a.logt, a.ctype, a.Dh > 0 ? a.Dh : a.D,   \
-                     a.acc_stride, VS)
+                     a.acc_stride, VS, a.abs_horseshoe)
   if (phase == 1) SPMF_FIN(1);
   else if (phase == 2) SPMF_FIN(2);
   else SPMF_FIN(0);

@@ -139,6 +139,7 @@ struct FinishArgs {
   int S;
   int64_t acc_stride;
   int64_t vstride[12];
+  int abs_horseshoe;     // horshoe_plus=False: only params/grads 0, 1, 2, 7 are used
 };
 void launch_finish(int KP, const FinishArgs& a, int phase, hipStream_t st);
 
@@ -167,6 +168,8 @@ struct AdamTable {
   AdamVar v[24];
 };
 void launch_surrogate_fwd(const SurTable& T, int nvars, int max_n, int S, double* logq, hipStream_t st);
+void launch_sample_noise(const SurTable& T, int nvars, int max_n, int S, uint64_t seed, uint64_t counter,
+                         const double* state, hipStream_t st);
 void launch_surrogate_bwd(const SurTable& T, int nvars, int max_n, int S, float inv_sb, float c, hipStream_t st);
 void launch_vi_gate(const double* parts, const double* logq, const double* nnf, int S, double c, double rows, double* state, hipStream_t st);
 void launch_adam_dev(const AdamTable& T, int ntensors, int max_n, const double* state, hipStream_t st);

@@ -261,6 +261,116 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable T, float lr, float 
 // ---- device-resident optimiser state (graph-capturable VI step) -------------
 // state[]: see include/spmf_hip.h (SPMF_VI_*).  One thread: loss of this step
 // from the 14 parts and log q, the apply/skip decision, Adam's running powers.
+// ---------------------------------------------------------------------------
+// Base noise of the surrogate, drawn on the device (replaces torch's randn /
+// _standard_gamma / _standard_gamma_grad on the step path).
+//   counter-based RNG: Philox4x32-10 (Salmon et al., SC'11), key = the 64-bit seed,
+//   counter = (element, draw | variable << 16 | attempt << 24, step counter lo, hi);
+//   the step counter comes from the device-resident VI state (state[13], advanced by
+//   the gate kernel) when the step is replayed from a hipGraph, else from the host.
+//   kind 0/1: eps ~ N(0,1) by Box-Muller.
+//   kind 2:   g ~ Gamma(a, 1), a = softplus(t0), by Marsaglia & Tsang (2000) (a < 1:
+//             Gamma(a+1) * U^(1/a)), and the implicit-reparameterisation derivative
+//             (Figurnov et al. 2018)   dg/da = -(dP/da)(a, g) / p(g; a)
+//             with P the regularised lower incomplete gamma function, from its series
+//             P(a,x) = sum_n T_n,  T_n = x^(a+n) e^-x / Gamma(a+n+1),
+//             dT_n/da = T_n (log x - psi(a+n+1)),  in fp64.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+__device__ __forceinline__ float normal_bm(uint32_t a, uint32_t b) {
+  return sqrtf(-2.f * logf(u01(a))) * cospif(2.f * u01(b));
+}
+__device__ __forceinline__ double digammad_(double x) {
+  double r = 0.0;
+  while (x < 8.0) {
+    r -= 1.0 / x;
+    x += 1.0;
+  }
+  const double i = 1.0 / x, i2 = i * i;
+  return r + log(x) - 0.5 * i - i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0))));
+}
+// d g / d a of g ~ Gamma(a, 1) at the drawn value (implicit reparameterisation)
+__device__ __forceinline__ float gamma_dgda(double a, double x) {
+  // -dP/da / p = -sum_n R_n (log x - psi(a+n+1)),  R_n = T_n / p(x; a) = x^(n+1) / (a (a+1) ... (a+n)):
+  // the density cancels analytically, so no exp / lgamma is needed.  fp64 throughout
+  // (in the right tail the terms reach ~e^x before they cancel); the reciprocal is a
+  // v_rcp_f32 seed + two Newton steps instead of an fp64 division; ~x + 40 terms.
+  const double lx = log(x);
+  double R = x / a;                                     // R_0
+  double psi = digammad_(a + 1.0);
+  double acc = 0.0;
+  for (int n = 0; n < 4000; ++n) {
+    const double term = R * (lx - psi);
+    acc += term;
+    if ((double)n > x && fabs(term) < 1e-12 * fabs(acc) + 1e-300) break;
+    const double d = a + (double)(n + 1);
+    double rc = (double)__builtin_amdgcn_rcpf((float)d);
+    rc = rc * (2.0 - d * rc);
+    rc = rc * (2.0 - d * rc);
+    psi += rc;
+    R *= x * rc;
+  }
+  return (float)(-acc);
+}
+
+__global__ __launch_bounds__(256) void sample_noise_kernel(SurTable T, int S, uint32_t seed_lo,
+                                                           uint32_t seed_hi, uint64_t counter,
+                                                           const double* __restrict__ state) {
+  const int var = blockIdx.y, s = blockIdx.z;
+  const SurVar v = T.v[var];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= v.n) return;
+  if (state) counter += (uint64_t)state[13];           // steps taken so far (device-resident)
+  const uint2 key = make_uint2(seed_lo, seed_hi);
+  const uint32_t c1 = (uint32_t)s | ((uint32_t)var << 16);
+  const uint32_t clo = (uint32_t)counter, chi = (uint32_t)(counter >> 32);
+  float* nz = const_cast<float*>(v.noise) + (size_t)s * v.ld + i;
+  if (v.kind != 2) {
+    const uint4 r = philox4x32_10(make_uint4((uint32_t)i, c1, clo, chi), key);
+    *nz = normal_bm(r.x, r.y);
+    return;
+  }
+  const float a = softplusf(v.t0[i]);
+  const float ab = a < 1.f ? a + 1.f : a;              // boost: Gamma(a) = Gamma(a+1) U^(1/a)
+  const float d = ab - (1.f / 3.f), cc = rsqrtf(9.f * d);
+  float g = d;                                          // (fallback after 32 rejections: the mode)
+  float ub = 1.f;
+  for (uint32_t att = 0; att < 32; ++att) {
+    const uint4 r = philox4x32_10(make_uint4((uint32_t)i, c1 | (att << 24), clo, chi), key);
+    if (att == 0) ub = u01(r.w);
+    const float x = normal_bm(r.x, r.y);
+    const float t = 1.f + cc * x;
+    if (t <= 0.f) continue;
+    const float vv = t * t * t;
+    const float u = u01(r.z);
+    if (logf(u) < 0.5f * x * x + d - d * vv + d * logf(vv)) {
+      g = d * vv;
+      break;
+    }
+  }
+  if (a < 1.f) g *= powf(ub, 1.f / a);
+  g = fmaxf(g, 1e-30f);
+  *nz = g;
+  const_cast<float*>(v.dgda)[(size_t)s * v.ld + i] = gamma_dgda((double)a, (double)g);
+}
+
+void launch_sample_noise(const SurTable& T, int nvars, int max_n, int S, uint64_t seed, uint64_t counter,
+                         const double* state, hipStream_t st) {
+  dim3 grid((max_n + 255) / 256, nvars, S);
+  hipLaunchKernelGGL(sample_noise_kernel, grid, dim3(256), 0, st, T, S, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), counter, state);
+}
+
 __global__ void vi_gate_kernel(const double* __restrict__ parts, const double* __restrict__ logq,
                                const double* __restrict__ nnf, int S, double c, double rows,
                                double* __restrict__ state) {
@@ -274,6 +384,7 @@ __global__ void vi_gate_kernel(const double* __restrict__ parts, const double* _
   }
   const double loss = -(acc / S) / rows;
   const bool ok = (loss - loss == 0.0) && bad == 0.0;      // finite and no non-finite cell
+  state[13] += 1.0;                                        // RNG step counter (spmf_sample_noise)
   state[8] = loss;
   state[9] = ok ? 1.0 : 0.0;
   if (ok) {

@@ -26,13 +26,59 @@ def shard_bounds(total_rows: int, world: int, rank: int, granule: int = 1):
     return min(total_rows, u0 * granule), min(total_rows, u1 * granule)
 
 
-class ShardReducer:
-    """Holds the global batch constants and performs the per-step all-reduce."""
+class LibraryComm:
+    """The library's own RCCL communicator (include/spmf_hip.h: spmf_comm_init /
+    spmf_allreduce): ncclAllReduce issued by libspmf_hip.so on the caller's stream,
+    so the step's collective is stream-ordered with the kernels around it and torch
+    is not on the data path.  torch.distributed (any backend) only carries the 128-byte
+    unique id from rank 0 to the others; with one rank nothing travels at all."""
 
-    def __init__(self, group=None):
+    def __init__(self, model, rank=None, world=None, group=None):
+        import ctypes as C
+        from . import _lib
+        self.model = model
+        lib, h = _lib.load(), model._handle()
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            rc = lib.spmf_comm_unique_id(buf)
+            if rc != 0:
+                raise _lib.SpmfError(f"spmf_comm_unique_id failed (rc={rc}): librccl not loadable")
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world > 1:
+            if dist.get_backend(group) == "nccl":
+                dev = ident.to(model.device)
+                dist.broadcast(dev, 0, group=group)
+                ident = dev.cpu()
+            else:
+                dist.broadcast(ident, 0, group=group)
+        raw = (C.c_char * 128).from_buffer_copy(bytes(ident.numpy().tobytes()))
+        _lib.check(h, lib.spmf_comm_init(h, raw, int(rank), int(world)), "spmf_comm_init")
+        self.rank, self.world = int(rank), int(world)
+
+    def all_reduce_(self, t):
+        from . import _lib
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("LibraryComm reduces contiguous fp32 device tensors (the packed accumulators)")
+        lib, h = _lib.load(), self.model._handle()
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        _lib.check(h, lib.spmf_allreduce(h, t.data_ptr(), t.numel(), stream), "spmf_allreduce")
+
+
+class ShardReducer:
+    """Holds the global batch constants and performs the per-step all-reduce.
+    ``comm``: a LibraryComm moves the packed fp32 accumulators with the library's
+    own RCCL communicator; without one (default) torch.distributed does."""
+
+    def __init__(self, group=None, comm=None):
         self.group = group
-        self.active = dist.is_initialized()      # also with one rank (exercises the transport)
-        self.world = dist.get_world_size(group) if self.active else 1
+        self.comm = comm
+        self.active = dist.is_initialized() or comm is not None   # also with one rank (exercises the transport)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else (comm.world if comm else 1)
         self.rows_global = None
         self.lgamma_global = None
 
@@ -52,6 +98,11 @@ class ShardReducer:
         self.rows_global, self.lgamma_global = int(rows_global), float(lgamma_global)
 
     def _sum(self, t):
+        if self.comm is not None and t.is_cuda and t.dtype == torch.float32:
+            self.comm.all_reduce_(t)
+            return
+        if not dist.is_initialized():
+            return                               # one rank, library comm only: nothing else to sum
         if dist.get_backend(self.group) != "nccl" and t.is_cuda:
             h = t.cpu()                      # rehearsal transport (gloo): host-staged
             dist.all_reduce(h, group=self.group)
@@ -66,6 +117,9 @@ class ShardReducer:
         stream, ordered after what is already queued on the current stream, so the
         kernels launched next (the upper half's column pass) overlap it."""
         if not self.active:
+            return None
+        if self.comm is not None:
+            self._sum(piece)                      # stream-ordered on the caller's stream
             return None
         if dist.get_backend(self.group) == "nccl":
             return dist.all_reduce(piece, group=self.group, async_op=True)
@@ -86,6 +140,37 @@ class ShardReducer:
                 self._sum(tot)
             return int(round(float(tot[0]))), float(tot[1])
         return self.rows_global, self.lgamma_global
+
+    # ---- replicated state ------------------------------------------------------
+    def sync_replicas(self, tensors, src=0):
+        """Broadcast rank `src`'s copy of the replicated tensors (surrogate
+        trainables, Adam moments).  Every rank applies the same update to identical
+        all-reduced gradients, but the finish kernel's cross-block float atomics
+        (u_tau gradient, energy parts) are order dependent in the last bit, so the
+        replicas can drift apart over thousands of steps; the driver calls this
+        every few hundred steps (one small broadcast)."""
+        if not self.active:
+            return
+        for t in tensors:
+            if dist.get_backend(self.group) != "nccl" and t.is_cuda:
+                h = t.detach().cpu()
+                dist.broadcast(h, src, group=self.group)
+                t.detach().copy_(h)
+            else:
+                dist.broadcast(t.detach(), src, group=self.group)
+
+    def replicas_max_abs_diff(self, tensors):
+        """max over ranks and tensors of |t - rank 0's t| (a diagnostic: 0.0 means
+        the replicas are bit-identical)."""
+        worst = 0.0
+        for t in tensors:
+            ref = t.detach().clone()
+            self.sync_replicas([ref])
+            d = (t.detach() - ref).abs().max().reshape(1).double().cpu() if t.numel() else torch.zeros(1, dtype=torch.float64)
+            if self.active:
+                dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.group)
+            worst = max(worst, float(d))
+        return worst
 
     def __call__(self, acc, rows, lgamma_sum):
         """all_reduce hook of PoissonFactorization.energy_and_grads."""

@@ -61,14 +61,13 @@ class PoissonFactorization:
             raise NotImplementedError(
                 "custom encoder_function/decoder_function are not supported by "
                 "the HIP path (only x/eta and log(x/eta+1) are built in)")
-        if not horshoe_plus:
-            raise NotImplementedError(
-                "horshoe_plus=False (AbsHorseshoe prior, poisson.py:378-398) "
-                "is not implemented in the HIP path")
         self.strategy = strategy
         self.scale_rows = scale_rows
         self.scale_columns = scale_columns
         self.horseshoe_plus = horshoe_plus
+        # the model's latent variables in the reference's surrogate order: all twelve
+        # (poisson.py:403-539), or v, w, s, u for horshoe_plus=False (:378-398, :540-565)
+        self.var_order = VAR_ORDER if horshoe_plus else _lib.VAR_ORDER_ABS
         self.eta_i = 1.
         self.xi_u_global = 1.
         if column_norms is not None:
@@ -109,7 +108,8 @@ class PoissonFactorization:
                 "the HIP hot path needs a GPU device (no CPU fallback)")
         lib = _lib.load()
         flags = (_lib.FLAG_SCALE_ROWS if self.scale_rows else 0) | (
-            _lib.FLAG_LOG_TRANSFORM if self.log_transform else 0) | self._likelihood_flag
+            _lib.FLAG_LOG_TRANSFORM if self.log_transform else 0) | self._likelihood_flag | (
+            0 if self.horseshoe_plus else _lib.FLAG_ABS_HORSESHOE)
         h = C.c_void_p()
         rc = lib.spmf_ctx_create(self.device.index or 0, int(self.latent_dim),
                                  int(self.feature_dim), flags, C.byref(h))
@@ -261,12 +261,12 @@ class PoissonFactorization:
             cache[key] = sc.batch_struct(*(pr or (0, None)))
         return sc, cache[key]
 
-    def _pack_params(self, params, names=VAR_ORDER):
+    def _pack_params(self, params, names=None):
         """dict name -> tensor  =>  (S, {name: contiguous fp32 [S,*shape]})."""
         D, K = self.feature_dim, self.latent_dim
         shapes = var_shapes(D, K)
         out, S = {}, None
-        for n in names:
+        for n in (names if names is not None else self.var_order):
             if n not in params:
                 raise KeyError(f"missing parameter '{n}'")
             t = params[n]
@@ -316,9 +316,11 @@ class PoissonFactorization:
         self._ensure_workspace(cs.n_rows, S)
         eta = self._eta_device()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        pin = _lib.PtrArray(*[P[n].data_ptr() for n in VAR_ORDER])
-        grads = {n: torch.empty_like(P[n]) for n in VAR_ORDER}
-        gout = _lib.PtrArray(*[grads[n].data_ptr() for n in VAR_ORDER])
+        # the C-ABI takes twelve slots in VAR_ORDER; variables the model does not have
+        # (horshoe_plus=False) stay NULL
+        pin = _lib.PtrArray(*[P[n].data_ptr() if n in P else None for n in VAR_ORDER])
+        grads = {n: torch.empty_like(P[n]) for n in self.var_order}
+        gout = _lib.PtrArray(*[grads[n].data_ptr() if n in grads else None for n in VAR_ORDER])
         parts = torch.empty(S, _lib.NPARTS, dtype=torch.float64, device=self.device)
         # [0:S] non-finite stored cells, [S:2S] saturated cells (log_transform)
         nnf2 = torch.empty(2 * S, dtype=torch.float64, device=self.device)
@@ -375,7 +377,8 @@ class PoissonFactorization:
             _lib.check(h, lib.spmf_finish(h, S, int(rows_g), float(lg_g), float(prior_weight), pin,
                                           eta.data_ptr(), parts.data_ptr(), gout, nnf.data_ptr(),
                                           stream), "spmf_finish")
-        pd = {n: parts[:, i] for i, n in enumerate(PART_ORDER)}
+        pd = {n: parts[:, i] for i, n in enumerate(PART_ORDER)
+              if n in ("z", "x") or n in self.var_order}
         self._last_parts = parts                      # [S,14] block (spmf_vi_gate input)
         self.last_saturated = nnf2[S:]                # cells with exp() saturated (common.h kYSat)
         return pd, grads, nnf
@@ -603,10 +606,10 @@ class PoissonFactorization:
         (initial values :403-539).  The prior itself lives in the finish
         kernel."""
         from .vi import Surrogate
-        self.bijectors = {n: "softplus" for n in VAR_ORDER}
+        self.bijectors = {n: "softplus" for n in self.var_order}
         self.surrogate_distribution = Surrogate(self)
         self.surrogate_vars = self.surrogate_distribution.variables
-        self.var_list = list(VAR_ORDER)
+        self.var_list = list(self.var_order)
         self.set_calibration_expectations()
 
     def set_calibration_expectations(self, samples=32):

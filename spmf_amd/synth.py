@@ -135,26 +135,40 @@ def scrna_like(rows, D, device, seed, first_chunk=0, panel_rows=8192, chunk_rows
     return SparseCounts(row_ptr, torch.cat(cols), torch.cat(vals), rows, D, panel_rows)
 
 
-def mixed_c5(rows, D, device, seed, panel_rows=8192):
+MIXED_CHUNK_ROWS = 25_000
+
+
+def mixed_c5(rows, D, device, seed, panel_rows=8192, first_chunk=0, chunk_rows=MIXED_CHUNK_ROWS):
     """C5: even columns Poisson as C2 (Bernoulli(0.01) mask x
-    (1 + Poisson(2))), odd columns Bernoulli(0.05) 0/1.  Returns
+    (1 + Poisson(2))), odd columns Bernoulli(0.05) 0/1.  Generated in row chunks
+    seeded by chunk id (the global matrix does not depend on how many ranks share
+    it); ``first_chunk`` is the global index of this shard's first chunk.  Returns
     (SparseCounts, bernoulli_column_mask)."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
     dens = 0.5 * 0.01 + 0.5 * 0.05
-    lam = torch.full((rows,), D * dens * 1.05, device=device)
-    n = torch.poisson(lam, generator=g).clamp_(max=D).to(torch.int64)
-    r = torch.repeat_interleave(torch.arange(rows, device=device), n)
-    # draw a column: odd (Bernoulli) with prob 5/6, even (Poisson) with prob 1/6
-    odd = torch.rand(r.numel(), device=device, generator=g) < (0.05 / 0.06)
-    half = torch.randint(0, D // 2, (int(r.numel()),), device=device, generator=g)
-    c = 2 * half + odd.to(torch.int64)
-    key = torch.unique(r * D + c)
-    r, c = key // D, key % D
-    x = torch.where(c % 2 == 1, torch.ones(key.numel(), device=device),
-                    1.0 + torch.poisson(torch.full((key.numel(),), 2.0, device=device), generator=g))
-    cnt = torch.bincount(r, minlength=rows)
+    cnts, cols, vals = [], [], []
+    done, cid = 0, first_chunk
+    while done < rows:
+        n_rows = min(chunk_rows, rows - done)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1000 + 11 + cid)
+        lam = torch.full((n_rows,), D * dens * 1.05, device=device)
+        n = torch.poisson(lam, generator=g).clamp_(max=D).to(torch.int64)
+        r = torch.repeat_interleave(torch.arange(n_rows, device=device), n)
+        # draw a column: odd (Bernoulli) with prob 5/6, even (Poisson) with prob 1/6
+        odd = torch.rand(r.numel(), device=device, generator=g) < (0.05 / 0.06)
+        half = torch.randint(0, D // 2, (int(r.numel()),), device=device, generator=g)
+        c = 2 * half + odd.to(torch.int64)
+        key = torch.unique(r * D + c)
+        r, c = key // D, key % D
+        x = torch.where(c % 2 == 1, torch.ones(key.numel(), device=device),
+                        1.0 + torch.poisson(torch.full((key.numel(),), 2.0, device=device), generator=g))
+        cnts.append(torch.bincount(r, minlength=n_rows))
+        cols.append(c.to(torch.int32))
+        vals.append(x.to(torch.float32))
+        done += n_rows
+        cid += 1
+    cnt = torch.cat(cnts)
     row_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
     row_ptr[1:] = torch.cumsum(cnt, 0)
     mask = (torch.arange(D) % 2 == 1).numpy()
-    return SparseCounts(row_ptr, c.to(torch.int32), x.to(torch.float32), rows, D, panel_rows), mask
+    return SparseCounts(row_ptr, torch.cat(cols), torch.cat(vals), rows, D, panel_rows), mask

@@ -13,11 +13,11 @@ The surrogate is the reference's (poisson.py:403-539): Softplus(Normal) for
 u, v, w, s and Softplus(InverseGamma) for the scale hierarchy; positive
 distribution parameters are softplus(raw) trainables.
 
-The VI step runs on the device end to end: base noise comes from torch's
-generators (``randn`` / ``_standard_gamma`` and its implicit-reparameterisation
-derivative -- RNG plumbing), everything else -- the transform to theta, log q,
-the energy and its gradient, the chain back to the trainables and the Adam
-update -- are HIP kernels behind the C-ABI (surrogate.hip + the hot path).
+The VI step runs on the device end to end in HIP kernels behind the C-ABI:
+the base noise (Philox normal / gamma sampler with the implicit-
+reparameterisation derivative), the transform to theta, log q, the energy and
+its gradient, the chain back to the trainables and the Adam update
+(surrogate.hip + the hot path).  torch supplies storage and the 64-bit seed.
 (The plain torch-autograd restatement of the same step that the tests compare
 against lives in tests/_vi_reference.py, not in the product.)
 """
@@ -41,7 +41,7 @@ def softplus_inverse(y):
     return y + np.log(-np.expm1(-y))
 
 
-def _initial_state(D, K, u_tau_scale, s_tau_scale):
+def _initial_state(D, K, u_tau_scale, s_tau_scale, horseshoe_plus=True):
     """(kind, constrained initial parameters) per variable, poisson.py:403-539."""
     from .poisson import var_shapes
     sh = var_shapes(D, K)
@@ -49,7 +49,7 @@ def _initial_state(D, K, u_tau_scale, s_tau_scale):
     return {
         "v": ("normal", -6.0 * one("v"), 5e-4 * one("v")),
         "w": ("normal", -6.0 * one("w"), 5e-4 * one("w")),
-        "u": ("normal", -6.0 * one("u"), 5e-4 * one("u")),
+        "u": ("normal", (-6.0 if horseshoe_plus else -9.0) * one("u"), 5e-4 * one("u")),   # :427-437 / :556
         "u_eta": ("invgamma", 3.0 * one("u_eta"), one("u_eta")),
         "u_tau": ("invgamma", 3.0 * one("u_tau"), one("u_tau")),
         "s_eta": ("invgamma", one("s_eta"), one("s_eta")),
@@ -76,12 +76,14 @@ class Surrogate:
         self.kinds: Dict[str, str] = {}
         self.trainable_variables: List[torch.Tensor] = []
         self._index = {}
-        init = _initial_state(D, K, model.u_tau_scale, model.s_tau_scale)
+        self.var_order = tuple(getattr(model, "var_order", VAR_ORDER))
+        init = _initial_state(D, K, model.u_tau_scale, model.s_tau_scale,
+                              getattr(model, "horseshoe_plus", True))
         identity = set(getattr(model, "_identity_vars", ()))
         # per-element Identity flags (mixed likelihood): name -> uint8 tensor
         self.ident_mask = dict(getattr(model, "_identity_mask", {}) or {})
         staged = []
-        for n in VAR_ORDER:
+        for n in self.var_order:
             kind, a, b = init[n]
             if n in identity:          # tfb.Identity(Normal): bernoulli.py:187-193,362-381
                 kind = "normal_identity"
@@ -125,36 +127,45 @@ class Surrogate:
     _KIND = {"normal": 0, "normal_identity": 1, "invgamma": 2}
 
     @torch.no_grad()
-    def draw_noise(self, S):
-        """Base noise per variable: eps ~ N(0,1) [S,*shape], or for the
-        InverseGamma kinds g ~ Gamma(softplus(t0), 1) and d g/d concentration.
-        One randn and one gamma draw over ALL variables (torch's gamma sampler
-        costs ~30 us per call whatever the size; per variable that was 0.45 ms of
-        a 4.2 ms C3 step): a variable's noise is a column slice of the [S, total]
-        buffer (row stride = total, passed to the kernels as noise_ld)."""
+    def draw_noise(self, S, seed=None, state=None):
+        """Base noise per variable, drawn by the HIP sampler (spmf_sample_noise:
+        Philox4x32-10; eps ~ N(0,1), or for the InverseGamma kinds g ~
+        Gamma(softplus(t0), 1) and d g/d concentration by implicit
+        reparameterisation).  One launch for ALL variables: a variable's noise is a
+        column slice of an [S, total] buffer (row stride = total, passed as noise_ld).
+        ``seed``: 64-bit key; None draws one from torch's CPU generator, so
+        ``torch.manual_seed`` still makes a run reproducible and ranks that share a
+        seed (dist.sync_seed) draw identical noise.  ``state``: the optimiser's
+        device state; its step counter (advanced by spmf_vi_gate) is added to the
+        Philox counter, which is what gives a hipGraph replay fresh noise."""
+        model = self._model()
+        lib, h = _lib.load(), model._handle()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
         out = {}
-        nor = [n for n in VAR_ORDER if self.kinds[n] != "invgamma"]
+        nor = [n for n in self.var_order if self.kinds[n] != "invgamma"]
         if nor:
             sizes = [self.params_of(n)[0].numel() for n in nor]
-            eps = torch.randn(S, sum(sizes), device=self.device, dtype=torch.float32)
+            eps = torch.empty(S, sum(sizes), device=self.device, dtype=torch.float32)
             for n, piece in zip(nor, eps.split(sizes, dim=1)):
                 out[n] = (piece.view((S,) + tuple(self.params_of(n)[0].shape)), None)
         if self._gam_names:
-            a = _sp(self._gam_flat)                       # raw concentrations share one buffer
-            if S > 1:
-                a = a.expand(S, -1).contiguous()
-            a = a.view(S, -1)
-            g = torch._standard_gamma(a).clamp_min_(1e-30)
-            dg = torch._standard_gamma_grad(a, g)
             sizes = [self.params_of(n)[0].numel() for n in self._gam_names]
+            g = torch.empty(S, sum(sizes), device=self.device, dtype=torch.float32)
+            dg = torch.empty(S, sum(sizes), device=self.device, dtype=torch.float32)
             for n, gp, dp in zip(self._gam_names, g.split(sizes, dim=1), dg.split(sizes, dim=1)):
                 shape = (S,) + tuple(self.params_of(n)[0].shape)
                 out[n] = (gp.view(shape), dp.view(shape))
+        arr = self._table(S, out)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(h, lib.spmf_sample_noise(h, arr, len(self.var_order), S, seed, 0,
+                                            state.data_ptr() if state is not None else None,
+                                            stream), "spmf_sample_noise")
         return out
 
     def _table(self, S, noise, theta=None, gtheta=None, grads=None):
-        arr = (_lib.SurVar * len(VAR_ORDER))()
-        for i, n in enumerate(VAR_ORDER):
+        arr = (_lib.SurVar * len(self.var_order))()
+        for i, n in enumerate(self.var_order):
             t0, t1 = self.params_of(n)
             nz, dg = noise[n]
             v = arr[i]
@@ -176,11 +187,11 @@ class Surrogate:
         """theta (dict name -> [S,*shape]) and logq [S] (float64) by the HIP kernel."""
         lib, h = _lib.load(), model._handle()
         theta = {n: torch.empty(noise[n][0].shape, dtype=torch.float32, device=self.device)
-                 for n in VAR_ORDER}
+                 for n in self.var_order}
         logq = torch.empty(S, dtype=torch.float64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         arr = self._table(S, noise, theta=theta)
-        _lib.check(h, lib.spmf_surrogate_fwd(h, arr, len(VAR_ORDER), S, logq.data_ptr(), stream),
+        _lib.check(h, lib.spmf_surrogate_fwd(h, arr, len(self.var_order), S, logq.data_ptr(), stream),
                    "spmf_surrogate_fwd")
         return theta, logq
 
@@ -189,10 +200,10 @@ class Surrogate:
         """d loss / d trainables (list in trainable order) given dE/dtheta."""
         lib, h = _lib.load(), model._handle()
         grads = [torch.empty_like(p) for p in self.trainable_variables]
-        gt = {n: gtheta[n].contiguous() for n in VAR_ORDER}
+        gt = {n: gtheta[n].contiguous() for n in self.var_order}
         stream = torch.cuda.current_stream(self.device).cuda_stream
         arr = self._table(S, noise, gtheta=gt, grads=grads)
-        _lib.check(h, lib.spmf_surrogate_bwd(h, arr, len(VAR_ORDER), S, float(inv_sb), float(c),
+        _lib.check(h, lib.spmf_surrogate_bwd(h, arr, len(self.var_order), S, float(inv_sb), float(c),
                                              stream), "spmf_surrogate_bwd")
         return grads
 
@@ -315,7 +326,7 @@ def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None, nonfinit
     parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=all_reduce, prior_weight=c,
                                            nonfinite=nonfinite)
     rows = B
-    prior = sum(parts[n] for n in VAR_ORDER)
+    prior = sum(parts[n] for n in model.var_order)
     energy = parts["x"] + parts["z"] + c * prior           # [S] float64
     loss = -(energy - c * logq).mean() / rows
     grads = sur.backward_hip(model, S, noise, g, 1.0 / (S * rows), c)
@@ -323,7 +334,7 @@ def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None, nonfinit
 
 
 @torch.no_grad()
-def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None):
+def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=None):
     """One whole VI step with no host read-back: noise, surrogate, energy +
     gradient, loss/skip decision (spmf_vi_gate), chain rule, gated Adam
     (spmf_adam_step_dev).  The launch sequence depends only on the batch
@@ -331,7 +342,9 @@ def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None):
     lib, h = _lib.load(), model._handle()
     sur = model.surrogate_distribution
     S = int(sample_size)
-    noise = sur.draw_noise(S)
+    # seed given (StepRunner): a fixed key + the device step counter, so the launch
+    # sequence is replayable; else a fresh key from torch's generator per call
+    noise = sur.draw_noise(S, seed=seed, state=opt.state if seed is not None else None)
     theta, logq = sur.forward_hip(model, S, noise)
     sc, cs = model._batch(batch)
     B = cs.n_rows
@@ -366,6 +379,8 @@ class StepRunner:
         self.replays = 0
         self.keep_tensors = False  # tests: keep the captured step's tensors
         self.kept = {}
+        # Philox key of this runner's noise; the per-step variation is the device counter
+        self.seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
 
     def _key(self, batch):
         sc, cs = self.model._batch(batch)
@@ -373,7 +388,7 @@ class StepRunner:
 
     def step(self, batch):
         if not self.use_graph:
-            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S)
+            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, seed=self.seed)
             return
         key, cs = self._key(batch)
         hit = self.graphs.get(key)
@@ -386,7 +401,7 @@ class StepRunner:
             del self.graphs[key]
         if self.seen.get(key) is not cs or ws == 0:
             # first sight: eager (also the warm-up that sizes the workspace)
-            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S)
+            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, seed=self.seed)
             if len(self.seen) > 4 * self.max_graphs:
                 self.seen.clear()
             self.seen[key] = cs
@@ -406,7 +421,8 @@ class StepRunner:
         gc.disable()
         try:
             with torch.cuda.graph(graph, pool=self.pool):
-                vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, keep=keep)
+                vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, keep=keep,
+                            seed=self.seed)
         finally:
             if gc_was_on:
                 gc.enable()
@@ -473,6 +489,7 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
     losses, best_state = [], None
     ctl = PlateauController(learning_rate, rel_tol, abs_tol, max_decay_steps, lr_decay_factor)
     device_loop = all_reduce is None
+    sync_every = int(kwargs.get("sync_every", 200))
     if device_loop:
         opt.init_state(clip_value)
         runner = StepRunner(model, opt, dataset_size, sample_size,
@@ -510,6 +527,10 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
                 opt.step(grads, clip_value)
                 tot += lv
                 nb += 1
+                # row shards: keep the replicated trainables and Adam moments bit-identical
+                # (ShardReducer.sync_replicas explains why they can drift)
+                if sync_every and hasattr(all_reduce, "sync_replicas") and opt.t % sync_every == 0:
+                    all_reduce.sync_replicas(list(sur.trainable_variables) + opt.m + opt.v)
         if nb == 0:
             # every batch of the epoch was skipped (non-finite loss): returning
             # quietly would look like a converged fit

@@ -32,7 +32,7 @@ def rsample(sur, S, generator=None):
     """-> (theta: name -> [S,*shape] with autograd graph, logq [S]) for a
     spmf_amd.vi.Surrogate (poisson.py:403-569 as the build defines it)."""
     theta, logq = {}, 0.0
-    for n in VAR_ORDER:
+    for n in sur.var_order:
         t0, t1 = sur.params_of(n)
         shape = (S,) + tuple(t0.shape)
         if sur.kinds[n] in ("normal", "normal_identity"):
@@ -71,10 +71,10 @@ def elbo_step_reference(model, batch, dataset_rows, sample_size, all_reduce=None
     B = cs.n_rows
     c = float(B) / float(dataset_rows)
     parts, g, nnf = model.energy_and_grads(batch, det, all_reduce=all_reduce, prior_weight=c)
-    prior = sum(parts[n] for n in VAR_ORDER)
+    prior = sum(parts[n] for n in sur.var_order)
     energy = parts["x"] + parts["z"] + c * prior           # [S] float64
     loss = -(energy - c * logq.detach().double()).mean() / B
-    lin = sum((g[n] * theta[n]).sum() for n in VAR_ORDER)
+    lin = sum((g[n] * theta[n]).sum() for n in sur.var_order)
     sur_loss = -(lin - c * logq.sum()) / (sample_size * B)
     grads = torch.autograd.grad(sur_loss, sur.trainable_variables)
     return loss, list(grads), nnf

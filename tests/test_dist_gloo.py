@@ -1,7 +1,10 @@
-"""N>1 path on CPU: world_size-2 gloo.  Each rank owns a row shard, produces
-the packed accumulators (here by the numpy restatement, since the HIP data
-pass needs a GPU), the product's ShardReducer all-reduces them, and the
-finished energy/gradients must equal the unsharded fp64 oracle."""
+"""N>1 path on CPU: world_size 2 and 4, gloo.  Each rank owns a row shard,
+produces the packed accumulators of S = 2 draws (here by the numpy restatement,
+since the HIP data pass needs a GPU), the product's ShardReducer all-reduces
+them in ONE call, and the finished energy/gradients of every draw must equal the
+unsharded fp64 oracle.  Also rehearsed: the column-split start/wait protocol,
+the global batch weighting of the sharded VI step (B_global/N, not the shard's
+rows), and the replica sync / drift diagnostic."""
 import math
 import os
 import socket
@@ -32,7 +35,7 @@ def _problem():
     cfg = O.OracleConfig(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(B * D))
     cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
     cfg.xi_u_global = 3.7
-    params = O.random_params(cfg, 1, 78)
+    params = O.random_params(cfg, 2, 78)          # S = 2 draws
     return cfg, x, params
 
 
@@ -43,11 +46,14 @@ def _worker(rank, world, port, q):
     from spmf_amd.dist import ShardReducer, shard_bounds
     cfg, x, params = _problem()
     r0, r1 = shard_bounds(x.shape[0], world, rank, granule=16)
-    one = {k: v[0] for k, v in params.items()}
+    S = params["u"].shape[0]
+    draws = [{k: v[i] for k, v in params.items()} for i in range(S)]
     eta = cfg.eta_i.numpy().reshape(-1)
     xs = sp.csr_matrix(x[r0:r1])
-    acc = torch.from_numpy(SE.shard_accumulators(xs, eta, cfg.xi_u_global, True,
-                                                 one["u"], one["v"], one["w"], one["s"]))
+    # the real accumulator buffer: [S][acc_len], all draws reduced by one collective
+    acc = torch.from_numpy(np.concatenate([
+        SE.shard_accumulators(xs, eta, cfg.xi_u_global, True, d["u"], d["v"], d["w"], d["s"])
+        for d in draws]))
     from scipy.special import gammaln
     lg = float(gammaln(xs.data + 1.0).sum())
     from spmf_amd.dist import sync_seed
@@ -67,11 +73,27 @@ def _worker(rank, world, port, q):
     assert red.totals(r1 - r0, lg) == (rows_g, lg_g)
     rg2, lg2 = red(acc, r1 - r0, lg)
     assert (rg2, lg2) == (rows_g, lg_g)
-    assert torch.equal(acc, acc2)
-    out = SE.finish_from_acc(acc.numpy(), rows_g, lg_g, eta, one["u"], one["v"], one["w"], one["s"])
+    # (two ranges vs one call: the ring splits the buffer differently, so with more
+    #  than two ranks the fp32 sums differ in the last bit)
+    assert torch.allclose(acc, acc2, rtol=1e-6, atol=1e-30) and (world > 2 or torch.equal(acc, acc2))
+    al = acc.numel() // S
+    outs = [SE.finish_from_acc(acc.numpy()[i * al:(i + 1) * al], rows_g, lg_g, eta, d["u"], d["v"],
+                               d["w"], d["s"]) for i, d in enumerate(draws)]
+    # the sharded VI step weights the batch by its GLOBAL row count
+    from spmf_amd.vi import batch_rows_global
+
+    class _CS:
+        n_rows, lgamma_sum = r1 - r0, lg
+    assert batch_rows_global(_CS, red) == rows_g == x.shape[0]
+    assert batch_rows_global(_CS, None) == r1 - r0
+    # replicas: equal after a sync, and the diagnostic sees a planted difference
+    rep = [torch.full((5,), float(rank)), torch.arange(3.0) + rank]
+    assert red.replicas_max_abs_diff(rep) == float(world - 1)
+    red.sync_replicas(rep)
+    assert red.replicas_max_abs_diff(rep) == 0.0 and float(rep[0][0]) == 0.0
     if rank == 0:
-        q.put((r0, r1, rows_g, colsum.numpy(), out["x"], out["z"],
-               {k: v for k, v in out["grads"].items()}))
+        q.put((r0, r1, rows_g, colsum.numpy(), [o["x"] for o in outs], [o["z"] for o in outs],
+               [{k: v for k, v in o["grads"].items()} for o in outs]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,12 +108,13 @@ def test_shard_bounds_cover_rows_once():
             assert a[1] == b[0]
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_gloo_allreduce_matches_unsharded_oracle():
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_allreduce_matches_unsharded_oracle(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=100)
@@ -100,12 +123,13 @@ def test_two_rank_gloo_allreduce_matches_unsharded_oracle():
         assert p.exitcode == 0
     r0, r1, rows_g, colsum, px, pz, grads = res
     cfg, x, params = _problem()
-    assert rows_g == x.shape[0] and (r0, r1) == (0, 48)
+    assert rows_g == x.shape[0] and (r0, r1) == ((0, 48) if world == 2 else (0, 16))
     np.testing.assert_allclose(colsum, x.sum(0), rtol=1e-12)
     parts, _, groups = O.energy_and_grads(cfg, x, params)
     # accumulators travel as fp32 (that is the wire format): 1e-5 tolerance
-    np.testing.assert_allclose(px, parts["x"][0].item(), rtol=1e-5)
-    np.testing.assert_allclose(pz, parts["z"][0].item(), rtol=1e-5)
-    for k, g in grads.items():
-        ref = groups["data"][k][0].numpy()
-        assert np.abs(g - ref).max() <= 1e-5 * np.abs(ref).max(), k
+    for i in range(len(px)):
+        np.testing.assert_allclose(px[i], parts["x"][i].item(), rtol=1e-5)
+        np.testing.assert_allclose(pz[i], parts["z"][i].item(), rtol=1e-5)
+        for k, g in grads[i].items():
+            ref = groups["data"][k][i].numpy()
+            assert np.abs(g - ref).max() <= 1e-5 * np.abs(ref).max(), (i, k)

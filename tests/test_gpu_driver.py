@@ -109,7 +109,7 @@ def test_hip_vi_step_matches_torch_autograd_reference(bernoulli):
     ref_loss = -(lin - c * lq_ref.sum()) / (S * B)
     ref_grads = torch.autograd.grad(ref_loss, sur.trainable_variables)
     for i, (a, r) in enumerate(zip(grads, ref_grads)):
-        assert (a - r).abs().max() <= 1e-5 * max(float(r.abs().max()), 1e-12), i
+        assert (a - r).abs().max() <= 2e-4 * max(float(r.abs().max()), 1e-12), i   # fp32 torch reference (its own rounding); the fp64 comparison at 1e-5 is test_hip_surrogate_matches_oracle_transform_and_fp64_autograd
     # Adam: one fused step == the tensor-op Adam
     p0 = [p.detach().clone() for p in sur.trainable_variables]
     ref_params = [p.detach().clone().requires_grad_(False) for p in p0]
@@ -374,3 +374,63 @@ def test_checkpoint_roundtrip(tmp_path):
     bad = dict(state, surrogate_vars=state["surrogate_vars"][:-1])
     with pytest.raises(ValueError):
         m2.reconstitute(bad)
+
+
+def test_hip_sampler_statistics_and_implicit_gradient():
+    """spmf_sample_noise: eps ~ N(0,1) and g ~ Gamma(a,1) pass moment and KS checks,
+    the implicit-reparameterisation derivative dg/da equals (i) the finite-difference
+    derivative of the inverse CDF at fixed probability (scipy, fp64) and (ii) torch's
+    _standard_gamma_grad; draws are reproducible under torch.manual_seed, differ from
+    call to call, and advance with the device step counter."""
+    import scipy.special as sps
+    import scipy.stats as sst
+    from spmf_amd import PoissonFactorization
+    m = PoissonFactorization(latent_dim=8, feature_dim=600, u_tau_scale=0.01, device="cuda",
+                             panel_rows=64)
+    sur = m.surrogate_distribution
+    with torch.no_grad():     # spread the concentrations: a = softplus(t0) in ~[0.3, 6]
+        t0, _ = sur.params_of("u_eta")
+        t0.copy_(torch.linspace(-1.0, 6.0, t0.numel(), device=t0.device).view_as(t0))
+    S = 16
+    torch.manual_seed(123)
+    n1 = sur.draw_noise(S)
+    torch.manual_seed(123)
+    n2 = sur.draw_noise(S)
+    n3 = sur.draw_noise(S)
+    for k in n1:
+        assert torch.equal(n1[k][0], n2[k][0]) and not torch.equal(n1[k][0], n3[k][0]), k
+    eps = n1["u"][0].flatten().double().cpu().numpy()
+    assert abs(eps.mean()) < 0.02 and abs(eps.std() - 1.0) < 0.02
+    assert sst.kstest(eps[:20000], "norm").pvalue > 1e-3
+    g = n1["u_eta"][0].double().cpu().numpy().reshape(S, -1)
+    dg = n1["u_eta"][1].double().cpu().numpy().reshape(S, -1)
+    a = torch.nn.functional.softplus(sur.params_of("u_eta")[0].detach()).double().cpu().numpy().reshape(-1)
+    # moments per concentration bucket
+    for lo, hi in ((0.3, 1.0), (1.0, 3.0), (3.0, 6.1)):
+        sel = (a >= lo) & (a < hi)
+        z = (g[:, sel] - a[sel]) / np.sqrt(a[sel])           # standardised: mean 0, var 1
+        assert abs(z.mean()) < 0.03 and abs(z.var() - 1.0) < 0.06, (lo, hi, z.mean(), z.var())
+    j = np.argmin(np.abs(a - 2.0))
+    assert sst.kstest(np.concatenate([n["u_eta"][0].double().cpu().numpy().reshape(S, -1)[:, j - 40:j + 40].ravel()
+                                      / 1.0 for n in (n1, n3)]), "gamma", args=(a[j],)).pvalue > 1e-4
+    # implicit gradient: d/da of the quantile at fixed probability
+    idx = np.linspace(0, a.size - 1, 60).astype(int)
+    for i in idx:
+        ai, gi = a[i], g[0, i]
+        pr = sps.gammainc(ai, gi)
+        if not (1e-6 < pr < 1 - 1e-9):
+            continue
+        h = 1e-5 * ai
+        fd = (sps.gammaincinv(ai + h, pr) - sps.gammaincinv(ai - h, pr)) / (2 * h)
+        assert abs(dg[0, i] - fd) <= 2e-4 * max(abs(fd), 1e-3), (ai, gi, dg[0, i], fd)
+    ref = torch._standard_gamma_grad(torch.as_tensor(np.broadcast_to(a, g.shape).copy()),
+                                     torch.as_tensor(g)).numpy()
+    ok = np.abs(dg - ref) <= 2e-3 * np.maximum(np.abs(ref), 1e-2)
+    assert ok.mean() > 0.999
+    # device step counter: same key, different counter -> different noise; same counter -> same
+    st = torch.zeros(16, dtype=torch.float64, device="cuda")
+    a0 = sur.draw_noise(2, seed=77, state=st)["v"][0].clone()
+    a1 = sur.draw_noise(2, seed=77, state=st)["v"][0].clone()
+    st[13] = 5.0
+    a2 = sur.draw_noise(2, seed=77, state=st)["v"][0].clone()
+    assert torch.equal(a0, a1) and not torch.equal(a0, a2)

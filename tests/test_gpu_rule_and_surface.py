@@ -324,3 +324,66 @@ def test_hip_surrogate_matches_oracle_transform_and_fp64_autograd(bernoulli):
     for i, (a, r) in enumerate(zip(grads, ref_grads)):
         a = a.double().cpu()
         assert float((a - r).abs().max()) <= 1e-5 * max(float(r.abs().max()), 1e-12), (i, VAR_ORDER[i // 2])
+
+
+@pytest.mark.parametrize("B,D,K,S,logt", [(40, 21, 3, 2, False), (120, 64, 32, 1, False), (60, 30, 8, 1, True)])
+def test_abs_horseshoe_branch_energy_and_grads(B, D, K, S, logt):
+    """horshoe_plus=False (poisson.py:378-398): four variables v, w, s, u with
+    AbsHorseshoe priors on u and s (TFP's Horseshoe log-density approximation,
+    folded) -- parts and gradients against the fp64 oracle."""
+    from spmf_amd import PoissonFactorization
+    rng = np.random.default_rng(60 + B)
+    x = ((rng.random((B, D)) < 0.25) * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, horseshoe_plus=False, log_transform=logt,
+                         u_tau_scale=1.0 / math.sqrt(B * D), s_tau_scale=0.7)
+    cfg.eta_i = T(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = 4.0
+    params = O.random_params(cfg, S, 5, fp32_exact=True)
+    if logt:
+        params["v"] *= 0.2
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale, s_tau_scale=0.7,
+                             horshoe_plus=False, log_transform=logt, column_norms=cfg.eta_i,
+                             device="cuda", panel_rows=32)
+    m.xi_u_global = cfg.xi_u_global
+    assert list(m.var_list) == ["v", "w", "s", "u"] and len(m.surrogate_vars) == 8
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    assert float(nnf.sum()) == 0 and set(parts) == {"v", "w", "s", "u", "z", "x"}
+    for k, r in pref.items():
+        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
+    for k, r in gref.items():
+        g = grads[k].cpu().double().numpy().reshape(r.shape)
+        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+    # the class surface and the driver work on the four-variable model
+    tot = m.unormalized_log_prob(data={"counts": x}, **params)
+    np.testing.assert_allclose(tot.cpu().numpy(), O.unormalized_log_prob(cfg, x, params).numpy(), rtol=1e-5)
+    th = m.surrogate_distribution.sample(3)
+    assert set(th) == {"v", "w", "s", "u"}
+    assert float(th["u"].mean()) < 0.1 * float(th["v"].mean())      # u starts at softplus(-9)
+    if not logt:
+        torch.manual_seed(2)
+        losses = m.fit(lambda: [{"counts": x}], dataset_size=B, sample_size=2, num_steps=6,
+                       learning_rate=0.02, rel_tol=1e-12, verbose=False)
+        assert len(losses) >= 3 and all(math.isfinite(v) for v in losses)
+
+
+def test_library_rccl_allreduce_single_rank():
+    """spmf_comm_unique_id / spmf_comm_init / spmf_allreduce (RCCL bound inside the
+    library): a one-rank communicator on this GPU; the step through it equals the
+    plain step (a sum over one rank is the identity) and the collective is
+    stream-ordered with the kernels around it."""
+    from spmf_amd.dist import LibraryComm, ShardReducer
+    cfg, x, params = make_problem(120, 40, 8, 2, 33, 0.2)
+    m = build_model(cfg, 32)
+    p0, g0, _ = m.energy_and_grads({"counts": x}, params)
+    comm = LibraryComm(m, rank=0, world=1)
+    red = ShardReducer(comm=comm)
+    p1, g1, _ = m.energy_and_grads({"counts": x}, params, all_reduce=red)
+    for k in p0:
+        np.testing.assert_allclose(p1[k].cpu().numpy(), p0[k].cpu().numpy(), rtol=1e-7)
+    for k in g0:
+        assert float((g1[k] - g0[k]).abs().max()) <= 1e-6 * float(g0[k].abs().max())
+    t = torch.arange(1000, dtype=torch.float32, device="cuda")
+    comm.all_reduce_(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32))

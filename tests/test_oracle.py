@@ -326,3 +326,57 @@ def test_c_port_equals_numpy_port():
             np.testing.assert_allclose(b["grads"][k], a["grads"][k], rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(b["z_rows"], a["z_rows"], rtol=1e-12, atol=1e-14)
     assert SC.max_threads() >= 1
+
+
+def test_horseshoe_log_prob_restates_tfp_approximation_close_to_the_exact_density():
+    """tfd.Horseshoe.log_prob is a closed-form approximation; the restatement in the
+    oracle must sit within its known accuracy (< 1e-3 nats) of the exact
+    HalfCauchy-Normal marginal (numerical quadrature) over eight decades of x/scale
+    and be asymptotically exact at both ends -- any mis-remembered constant fails."""
+    from scipy import integrate
+    for scale in (1.0, 0.01, 3.0):
+        for r in (1e-4, 1e-3, 1e-2, 0.1, 0.5, 1.0, 2.0, 5.0, 20.0, 100.0, 1e3):
+            x = r * scale
+            f = lambda lam: (np.exp(-0.5 * (x / (lam * scale)) ** 2) / (np.sqrt(2 * np.pi) * lam * scale)
+                             * 2 / (np.pi * (1 + lam * lam)))
+            exact = np.log(integrate.quad(f, 0, np.inf, limit=500)[0])
+            got = float(O.horseshoe_log_prob(torch.tensor(x, dtype=torch.float64),
+                                             torch.tensor(scale, dtype=torch.float64)))
+            tol = 1e-3 if 0.05 < r < 10 else 2e-5
+            assert abs(got - exact) < tol, (scale, r, got, exact)
+    # folded density integrates to one
+    tot = integrate.quad(lambda y: float(torch.exp(O.abs_horseshoe_log_prob(
+        torch.tensor(y, dtype=torch.float64), torch.tensor(0.7, dtype=torch.float64)))), 0, np.inf,
+        limit=500)[0]
+    assert abs(tot - 1.0) < 2e-3
+
+
+def test_abs_horseshoe_branch_parts_and_gradients():
+    """horshoe_plus=False (poisson.py:378-398): four variables, AbsHorseshoe priors on
+    u (scale u_tau_scale * decay^k) and s (scale s_tau_scale); autograd == finite
+    differences."""
+    rng = np.random.default_rng(11)
+    B, D, K = 9, 7, 3
+    x = rng.poisson(1.0, size=(B, D)).astype(np.float64)
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, horseshoe_plus=False, u_tau_scale=0.05)
+    p = O.random_params(cfg, 1, 2)
+    assert tuple(p) == O.VAR_ORDER_ABS == tuple(cfg.var_order)
+    parts = O.unormalized_log_prob_parts(cfg, x, p)
+    assert set(parts) == {"v", "w", "u", "s", "z", "x"}
+    decay = 0.99 ** np.arange(K)
+    want_u = sum(float(O.abs_horseshoe_log_prob(torch.tensor(p["u"][0, d, k]),
+                                                torch.tensor(0.05 * decay[k])))
+                 for d in range(D) for k in range(K))
+    assert abs(float(parts["u"]) - want_u) < 1e-10 * abs(want_u)
+    _, grads, _ = O.energy_and_grads(cfg, x, p)
+    tot = lambda q: float(sum(v.sum() for v in O.unormalized_log_prob_parts(cfg, x, q).values()))
+    for name, idx in (("u", (0, 2, 1)), ("s", (0, 1, 3)), ("v", (0, 1, 4)), ("w", (0, 0, 2))):
+        h = 1e-6 * p[name][idx]
+        hi = {k: v.copy() for k, v in p.items()}
+        lo = {k: v.copy() for k, v in p.items()}
+        hi[name][idx] += h
+        lo[name][idx] -= h
+        fd = (tot(hi) - tot(lo)) / (2 * h)
+        assert abs(float(grads[name][idx]) - fd) <= 1e-6 * max(1.0, abs(fd)), (name, fd)
+    st = O.surrogate_initial_state(cfg)
+    assert tuple(st) == O.VAR_ORDER_ABS and float(st["u"]["loc"][0, 0]) == -9.0
