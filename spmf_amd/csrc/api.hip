@@ -398,7 +398,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
       // cores, then the stored-cell terms (sweep 2) with the dense row term.
       RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, logt == 1 ? ct->gval : ct->val, rscale, c->Ap, c->Vp, c->phi,
-          dprep, c->z, c->gzs, dacc, 1, logt, nullptr, c->ctype};
+          dprep, c->z, c->gzs, dacc, 1, logt, nullptr, c->ctype, 1, D, dacc_stride};
       launch_row_pass(KP, r1, st);
       if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
       const int act = logt >= 2 ? 1 : 0;
@@ -422,7 +422,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       launch_expdot(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
       RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
-          dacc, 2, logt, c->gzd, c->ctype};
+          dacc, 2, logt, c->gzd, c->ctype, 1, D, dacc_stride};
       launch_row_pass(KP, r2, st);
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
@@ -590,7 +590,7 @@ int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float*
   launch_prep(c->KP, pa, st);
   RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val,
       (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs,
-      c->dacc, 1, logt, nullptr, nullptr};
+      c->dacc, 1, logt, nullptr, nullptr, 1, c->D, 0};
   launch_row_pass(c->KP, ra, st);
   HIPCHK(c, hipMemcpy2DAsync(z_out, (size_t)c->K * sizeof(float), c->z, (size_t)c->KP * sizeof(float),
       (size_t)c->K * sizeof(float), (size_t)ct->n_rows, hipMemcpyDeviceToDevice, st));
@@ -617,7 +617,7 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
   launch_prep(c->KP, pa, st);
   RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val,
       (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs,
-      c->dacc, 1, logt, nullptr, nullptr};
+      c->dacc, 1, logt, nullptr, nullptr, 1, c->D, 0};
   launch_row_pass(c->KP, ra, st);
   DenseLLArgs da{ct->n_rows, c->D, lik, c->z, c->Vp, c->phi, c->ctype, ct->row_ptr, ct->col_idx, ct->val, rate_out,
       ll_out};

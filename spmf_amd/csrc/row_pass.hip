@@ -26,6 +26,8 @@
 // long rows) + 8*KP B per row written; the factor-row gathers (2 x 4*KP B per
 // entry) are served by L2/Infinity Cache because A' and V' (D*KP*4 B each)
 // stay resident.  Algorithmic bytes: DESIGN.md section 4.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -40,8 +42,18 @@ namespace spmf {
 
 namespace {
 
+// The intercept phi_d is needed once per stored entry ("one entry per lane": 64 different
+// cache lines per wave load).  tools/gather_rows_probe.hip: that third gather stream costs
+// the row pass 0.35 ms of 1.9 on C3 (mode 6 vs mode 2); staged in LDS once per workgroup
+// (4*D bytes, 80 KB at D = 20 000, two 512-thread workgroups per CU) it costs 0.1.
+__device__ __forceinline__ float* lds_dyn() {
+  extern __shared__ __attribute__((aligned(16))) float spmf_row_lds[];
+  return spmf_row_lds;
+}
+
 // LIK: 0 Poisson / linear decoder, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
-template <int KP, int LIK>
+// LDSPHI: phi is read from the workgroup's LDS copy instead of global memory
+template <int KP, int LIK, bool LDSPHI = false>
 struct RowCtx {
   static constexpr int LPN = KP / 4;
   static constexpr int NPI = 64 / LPN;
@@ -103,7 +115,7 @@ struct RowCtx {
     if (slot < nchunk && xs > 0.f) {
       if (LIK == 2 || (LIK == 3 && ctype[cs])) {
         // Bernoulli(logits = <z,V'> + phi) (bernoulli.py:147-155): stored-cell part x*logit
-        const float lg = rmine + phi[cs];
+        const float lg = rmine + (LDSPHI ? lds_dyn()[cs] : phi[cs]);
         if (lg > -INFINITY && lg < INFINITY) {
           ll = fmaf(xs, lg, ll);
           cc = xs;                                   // d(x*logit)/d<z,V'>
@@ -113,7 +125,7 @@ struct RowCtx {
       } else {
         // linear decoder: r = <z,V'> + phi; log_transform: r = exp(<z,V'>) - 1 + phi
         const float ey = LIK == 1 ? expf(fminf(rmine, kYSat)) : 1.f;
-        const float r = (LIK == 1 ? ey - 1.f : rmine) + phi[cs];
+        const float r = (LIK == 1 ? ey - 1.f : rmine) + (LDSPHI ? lds_dyn()[cs] : phi[cs]);
         if (r > 0.f && r < INFINITY) {
           ll = fmaf(xs, logf(r), ll);
           cc = xs * ey * __builtin_amdgcn_rcpf(r);   // d(x log r)/d<z,V'>
@@ -144,8 +156,11 @@ struct RowCtx {
 
 }  // namespace
 
-template <int KP, int LIK>
-__global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
+// BT: threads per workgroup.  256: phi from global memory.  512 / 1024: phi staged in LDS
+// (4*D bytes of dynamic LDS: two workgroups per CU up to D = 20 480, one up to 40 960),
+// four waves per SIMD either way.
+template <int KP, int LIK, int BT = 256>
+__global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pass_kernel(
     int64_t B, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ row_scale,
     const float* __restrict__ Ap, const float* __restrict__ Vp, const float* __restrict__ phi,
@@ -164,7 +179,13 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
   }
   const bool encode_only = mode == 1;
   constexpr int LPN = KP / 4;
-  RowCtx<KP, LIK> cx;
+  constexpr bool LDSPHI = BT != 256;
+  if (LDSPHI) {
+    float* pl = lds_dyn();
+    for (int i = threadIdx.x; i < Dcols; i += BT) pl[i] = phi[i];
+    __syncthreads();
+  }
+  RowCtx<KP, LIK, LDSPHI> cx;
   cx.Ap = Ap;
   cx.Vp = Vp;
   cx.phi = phi;
@@ -292,7 +313,11 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
 
   // ---- block reduction, one set of fp64 atomics per block ---------------
   __shared__ double red[16];
-  __shared__ double zred[4][KP];
+  __shared__ double zred_static[BT == 256 ? 4 : 1][KP];
+  // with phi in LDS the per-wave z sums reuse that region (phi is no longer needed once
+  // every wave has left the row loop): keeps two 80 KB workgroups inside 160 KB
+  if (LDSPHI) __syncthreads();
+  double (*zred)[KP] = LDSPHI ? reinterpret_cast<double (*)[KP]>(lds_dyn()) : zred_static;
   const int wid = threadIdx.x >> 6;
   if (grp == 0) {
     zred[wid][sub * 4 + 0] = (double)zsum.x;
@@ -318,10 +343,53 @@ __global__ __launch_bounds__(256, ROW_WAVES_PER_SIMD) void row_pass_kernel(
   }
 }
 
+template <int KP, int LIK, int BT>
+static void launch_row_lds(const RowArgs& a, hipStream_t st) {
+  const size_t lds = std::max((size_t)a.D * 4, (size_t)(BT / 64) * KP * sizeof(double));
+  static size_t lds_allowed = 64 * 1024;      // opt in to more dynamic LDS as far as needed
+  if (lds > lds_allowed) {
+    if (hipFuncSetAttribute((const void*)row_pass_kernel<KP, LIK, BT>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();                  // not granted: clear, the launch below reports
+    } else {
+      lds_allowed = lds;
+    }
+  }
+  const int64_t want = (a.B + (BT / 64) - 1) / (BT / 64);
+  // workgroups beyond the resident ones re-stage phi (4*D bytes each, L2 hits): a few
+  // waves of workgroups keep the tail short without a visible staging cost
+  const int64_t cap = 2048 * 256 / BT;
+  const int nb = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+  hipLaunchKernelGGL((row_pass_kernel<KP, LIK, BT>), dim3(nb, a.S > 1 ? a.S : 1), dim3(BT), lds, st,
+                     a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z,
+                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride);
+}
+
+#ifndef ROW_LDS_PHI
+#define ROW_LDS_PHI 1
+#endif
+
 template <int KP>
 static void launch_row_t(const RowArgs& a, hipStream_t st) {
   int64_t want = (a.B + 3) / 4;  // 4 waves (rows in flight) per 256-thread block
   int nb = (int)(want < 1 ? 1 : (want > ROW_MAX_BLOCKS ? ROW_MAX_BLOCKS : want));
+  // phi from LDS: the sweep-2 forms of the Poisson likelihoods at the K of the named
+  // configs, when 4*D bytes fit (and the batch is big enough to fill the wider blocks)
+  if constexpr (KP >= 16) {
+    if (ROW_LDS_PHI && a.mode != 1 && (a.logt == 0 || a.logt == 1) && a.B >= 4096) {
+      const size_t need = (size_t)a.D * 4;
+      if (need <= 80 * 1024) {
+        if (a.logt == 0) launch_row_lds<KP, 0, 512>(a, st);
+        else launch_row_lds<KP, 1, 512>(a, st);
+        return;
+      }
+      if (need <= 160 * 1024 - 1024) {
+        if (a.logt == 0) launch_row_lds<KP, 0, 1024>(a, st);
+        else launch_row_lds<KP, 1, 1024>(a, st);
+        return;
+      }
+    }
+  }
 #define SPMF_ROW_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, \
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, \
