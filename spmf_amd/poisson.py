@@ -55,12 +55,16 @@ class PoissonFactorization:
             initialize_distributions=True,
             dtype=torch.float64, device=None, panel_rows=DEFAULT_PANEL_ROWS,
             **kwargs):
+        # poisson.py:94-97 lets callers swap g / f.  The kernels know the two built-in
+        # pairs only; with a callable the energy takes the dense torch-on-device route of
+        # spmf_amd/custom_codec.py -- announced, never silent.
+        self._custom_codec = None
         if encoder_function is not None or decoder_function is not None:
-            # poisson.py:94-97 lets callers swap g/f; the kernels only know
-            # the two built-in pairs.
-            raise NotImplementedError(
-                "custom encoder_function/decoder_function are not supported by "
-                "the HIP path (only x/eta and log(x/eta+1) are built in)")
+            self._custom_codec = (encoder_function or self._builtin_encoder,
+                                  decoder_function or self._builtin_decoder)
+            print("custom encoder_function/decoder_function: the energy is evaluated densely with "
+                  "torch ops on the device (spmf_amd/custom_codec.py); the HIP kernels cover the "
+                  "built-in x/eta and log(x/eta+1) pairs only")
         self.strategy = strategy
         self.scale_rows = scale_rows
         self.scale_columns = scale_columns
@@ -98,6 +102,35 @@ class PoissonFactorization:
             self.create_distributions()
         print(
             f"Feature dim: {self.feature_dim} -> Latent dim {self.latent_dim}")
+
+    def _builtin_encoder(self, x):
+        """g (poisson.py:34-43) as a tensor function, for a model that swaps only f."""
+        eta = self._eta_device().to(x.dtype)
+        return torch.log(x / eta + 1.) if self.log_transform else x / eta
+
+    def _builtin_decoder(self, y):
+        """f (poisson.py:45-54) as a tensor function, for a model that swaps only g."""
+        eta = self._eta_device().to(y.dtype)
+        return torch.exp(y * eta) - 1. if self.log_transform else y * eta
+
+    def _custom_energy(self, data, params, all_reduce, prior_weight):
+        from . import custom_codec
+        if all_reduce is not None:
+            raise NotImplementedError("custom encoder/decoder callables: single shard only")
+        sc, cs = self._batch(data)
+        x = sc.to_dense()
+        pr = data.get("panels") if isinstance(data, dict) else None
+        if pr is not None:
+            r0 = pr[0] * sc.panel_rows
+            x = x[r0:r0 + cs.n_rows]
+        parts, grads, nbad = custom_codec.energy_and_grads(self, x, params, prior_weight)
+        S = nbad.shape[0]
+        block = torch.stack([parts[n] for n in PART_ORDER], 1).contiguous()
+        self._last_parts = block
+        self.last_saturated = torch.zeros(S, dtype=torch.float64, device=self.device)
+        shapes = var_shapes(self.feature_dim, self.latent_dim)
+        grads = {n: g.reshape((S,) + shapes[n]).contiguous() for n, g in grads.items()}
+        return {n: block[:, i] for i, n in enumerate(PART_ORDER)}, grads, nbad
 
     # ------------------------------------------------------------------
     # native context
@@ -310,6 +343,8 @@ class PoissonFactorization:
         """
         if nonfinite not in ("count", "rule"):
             raise ValueError("nonfinite must be 'count' or 'rule'")
+        if self._custom_codec is not None:
+            return self._custom_energy(data, params, all_reduce, prior_weight)
         lib, h = _lib.load(), self._handle()
         sc, cs = self._batch(data)
         S, P = self._pack_params(params)
@@ -405,6 +440,9 @@ class PoissonFactorization:
         """Returns the log likelihood without summing along axes
         (poisson.py:156-184): {'log_likelihood': [S,B,D], 'rate': [S,B,D]}
         (no sample axis when the parameters have none)."""
+        if self._custom_codec is not None:
+            raise NotImplementedError(
+                "log_likelihood_components with custom encoder/decoder callables is not built")
         lib, h = _lib.load(), self._handle()
         sc, cs = self._batch(data)
         S, P = self._pack_params({"s": s, "u": u, "v": v, "w": w}, names=("s", "u", "v", "w"))
@@ -554,6 +592,14 @@ class PoissonFactorization:
         """Returns theta given x (poisson.py:623-650), [B,K] (or [S,B,K])."""
         u = self._expect("u", u).to(self.device, torch.float32)
         s = self._expect("s", s).to(self.device, torch.float32)
+        if self._custom_codec is not None:
+            sc, cs = self._batch(x if isinstance(x, dict) else {self.count_key: x})
+            xd = sc.to_dense().double()
+            wts = (s / s.sum(-2, keepdim=True)).double()
+            z = torch.matmul(self._custom_codec[0](xd), wts[..., 0, :].unsqueeze(-1) * u.double())
+            if self.scale_rows:
+                z = z * (xd.sum(-1, keepdim=True) / float(self.xi_u_global))
+            return z.to(torch.float32)
         lib, h = _lib.load(), self._handle()
         sc, cs = self._batch(x if isinstance(x, dict) else {self.count_key: x})
         single = u.dim() == 2

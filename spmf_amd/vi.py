@@ -488,7 +488,8 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
     epochs = num_epochs if num_epochs is not None else num_steps
     losses, best_state = [], None
     ctl = PlateauController(learning_rate, rel_tol, abs_tol, max_decay_steps, lr_decay_factor)
-    device_loop = all_reduce is None
+    # (custom encoder/decoder callables run torch autograd inside the step: eager loop)
+    device_loop = all_reduce is None and getattr(model, "_custom_codec", None) is None
     sync_every = int(kwargs.get("sync_every", 200))
     if device_loop:
         opt.init_state(clip_value)

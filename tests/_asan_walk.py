@@ -1,0 +1,72 @@
+"""Run under LD_PRELOAD=<asan runtime>: loads the AddressSanitizer build of the
+C-ABI layer and walks its host-side paths that need no GPU (argument checks,
+workspace arithmetic, struct handling, error strings, RCCL id).  Exit code 0 and
+no AddressSanitizer report on stderr == pass (tests/test_host.py checks both)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from spmf_amd import _lib  # noqa: E402
+
+lib = C.CDLL(os.path.join(ROOT, "spmf_amd", "libspmf_hip_asan.so"))
+for name, (res, args) in _lib.SIGNATURES.items():
+    fn = getattr(lib, name)
+    fn.restype, fn.argtypes = res, args
+
+assert lib.spmf_version() == 2 and lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct)
+h = C.c_void_p()
+assert lib.spmf_ctx_create(0, 100, 10, 0, C.byref(h)) == -1
+assert lib.spmf_ctx_create(0, 0, 10, 0, C.byref(h)) == -1
+assert lib.spmf_ctx_create(0, 8, 10, _lib.FLAG_LOG_TRANSFORM | _lib.FLAG_BERNOULLI, C.byref(h)) == -4
+for flags in (0, 1, 2 | 1, 4, 8, 16 | 1):
+    for K in (1, 3, 16, 33, 64):
+        assert lib.spmf_ctx_create(0, K, 1000, flags, C.byref(h)) == 0
+        kp = lib.spmf_padded_k(h)
+        assert kp >= K and kp in (4, 8, 16, 32, 64)
+        for S in (1, 2, 20):
+            n1 = lib.spmf_workspace_bytes(h, 0, S)
+            n2 = lib.spmf_workspace_bytes(h, 4096, S)
+            assert n2 > n1 > 0 and lib.spmf_acc_len(h, S) == S * (2 * 1000 * kp + 1000 + 2 * (6 + kp))
+        assert lib.spmf_ctx_set_prior(h, 0.0, 1.0, 0.99) == -1 and b"> 0" in lib.spmf_last_error(h)
+        assert lib.spmf_ctx_set_prior(h, 0.01, 1.0, 0.99) == 0
+        assert lib.spmf_ctx_set_workspace(h, None, 10) == -1
+        assert lib.spmf_ctx_set_workspace(h, 12345, 1 << 20) == -1          # misaligned
+        assert lib.spmf_ctx_set_column_split(h, 33) == -1
+        rc = lib.spmf_ctx_set_column_split(h, 512)
+        assert rc == (0 if flags in (0, 1, 16 | 1) else -4), (flags, rc)
+        off, ln = (C.c_int64 * 2)(), (C.c_int64 * 2)()
+        assert lib.spmf_acc_split(h, off, ln) == 0 and off[1] == ln[0]
+        assert lib.spmf_ctx_set_column_split(h, 0) == 0
+        # calls that must fail on their argument checks before touching the device
+        cs = _lib.CountsStruct()
+        cs.n_cols = 999
+        P = _lib.PtrArray()
+        assert lib.spmf_data_pass(h, C.byref(cs), 1, P, None, None) == -1
+        assert lib.spmf_data_pass(h, None, 1, P, 4096, None) != 0
+        assert lib.spmf_finish(h, 1, 10, 0.0, 1.0, P, 4096, 4096, P, None, None) == -1
+        assert lib.spmf_encode(h, C.byref(cs), None, None, None, None, None) == -1
+        assert lib.spmf_dense_ll(h, C.byref(cs), *([None] * 8)) == -1
+        assert lib.spmf_nonfinite_reduce(h, -1, 4096, 0, 4096, None) == -1
+        assert lib.spmf_nonfinite_argmin(h, 8, None, 0.0, 4096, None) == -1
+        assert lib.spmf_nonfinite_patch(h, C.byref(cs), 1, P, None, None, None, None) == -1
+        sv = (_lib.SurVar * 12)()
+        assert lib.spmf_surrogate_fwd(h, sv, 12, 1, 4096, None) == -1
+        assert lib.spmf_surrogate_bwd(h, sv, 13, 1, 1.0, 1.0, None) == -1
+        assert lib.spmf_sample_noise(h, sv, 12, 1, 1, 0, None, None) == -1
+        av = (_lib.AdamVar * 24)()
+        assert lib.spmf_adam_step(h, av, 24, 1e-3, 0.9, 0.999, 1e-7, 1, 0.0, None) == -1
+        assert lib.spmf_adam_step_dev(h, av, 25, 4096, None) == -1
+        assert lib.spmf_vi_gate(h, None, None, None, 1, 1.0, 1.0, None, None) == -1
+        assert lib.spmf_allreduce(h, 4096, 8, None) == -1 and b"comm_init" in lib.spmf_last_error(h)
+        assert lib.spmf_comm_init(h, None, 0, 1) == -1
+        assert lib.spmf_comm_destroy(h) == 0
+        ms = (C.c_float * 6)()
+        assert lib.spmf_last_timing(h, ms) == -1
+        lib.spmf_ctx_destroy(h)
+buf = (C.c_char * 128)()
+assert lib.spmf_comm_unique_id(buf) in (0, -4) and lib.spmf_comm_unique_id(None) == -1
+lib.spmf_ctx_destroy(None)
+assert lib.spmf_last_error(None) == b"null ctx"
+print("asan walk ok")

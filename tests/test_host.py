@@ -193,3 +193,22 @@ def test_work_items_sorted_by_column_half():
     cs = sc.batch_struct(1, 3)
     assert cs.col_split == 32 and cs.item_mid == sc.item_mid.data_ptr() + 4
     assert cs.max_items_half[0] == int(sc.items_per_half[0, 1:3].max())
+
+
+@pytest.mark.timeout(600)
+def test_c_abi_host_layer_under_address_sanitizer():
+    """an ASAN host build of the C-ABI layer (make -C spmf_amd/csrc asan:
+    api.hip compiled with -fsanitize=address for the host, linked with the regular kernel
+    objects) walks every argument-check / workspace / descriptor path that needs no GPU."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "spmf_amd", "csrc")
+    r = subprocess.run(["make", "-s", "-C", csrc, "-j8", "all", "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rt = r.stdout.strip().splitlines()[-1]
+    assert rt.endswith(".so") and os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+    w = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_asan_walk.py")],
+                       capture_output=True, text=True, env=env, timeout=500)
+    assert w.returncode == 0 and "asan walk ok" in w.stdout, (w.stdout[-1500:], w.stderr[-3000:])
+    assert "AddressSanitizer" not in w.stderr, w.stderr[-3000:]
