@@ -142,6 +142,11 @@ int spmf_ctx_set_prior(spmf_ctx* ctx, double u_tau_scale, double s_tau_scale,
 /* SPMF_FLAG_MIXED only: column_is_bernoulli[D] (uint8, device, caller-owned,
  * must outlive the ctx calls). */
 int spmf_ctx_set_column_types(spmf_ctx* ctx, const uint8_t* column_is_bernoulli);
+/* Optional with SPMF_FLAG_MIXED: the ascending indices of the Bernoulli columns (int32,
+ * device, caller-owned, must outlive the ctx calls).  With it the dense softplus /
+ * sigmoid sums run over those n columns only (compacted rows of V'); without it over
+ * all D columns with the Poisson ones masked by a -1e30 logit bias. */
+int spmf_ctx_set_bernoulli_columns(spmf_ctx* ctx, const int32_t* cols, int n);
 
 /* Bytes of caller-owned device workspace needed for batches of up to
  * max_rows rows and S draws. */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "spmf_last_error": (C.c_char_p, [C.c_void_p]),
     "spmf_ctx_set_prior": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "spmf_ctx_set_column_types": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spmf_ctx_set_bernoulli_columns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "spmf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int]),
     "spmf_ctx_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "spmf_counts_stats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 7

@@ -31,6 +31,9 @@ struct spmf_ctx {
   double* dprep = nullptr;
   float *Ap = nullptr, *Vp = nullptr, *phi = nullptr, *z = nullptr, *gzs = nullptr, *gzd = nullptr, *dbias = nullptr;
   const uint8_t* ctype = nullptr;   // mixed likelihood: 1 = Bernoulli column (device, caller-owned)
+  const int32_t* bcols = nullptr;   // mixed likelihood: ascending indices of the Bernoulli columns (optional)
+  int n_bcols = 0;
+  float *Vb = nullptr, *bb = nullptr;   // compacted V' rows / logit biases of those columns
   // timing taps
   int timing = 0;
   static constexpr int kSets = 64;  // ring of event sets: no sync inside a timed loop
@@ -122,7 +125,7 @@ static size_t var_size(const spmf_ctx* c, int i) {
 }
 
 struct Carve {
-  size_t acc, dacc, dprep, Ap, Vp, phi, dbias, z, gzs, gzd, total;
+  size_t acc, dacc, dprep, Ap, Vp, phi, dbias, Vb, bb, z, gzs, gzd, total;
 };
 // Small batches run all S draws in ONE launch per kernel (gridDim.y = S): the per-draw tables and
 // row outputs then exist S times.  Only for the linear Poisson decoder, only while the S table
@@ -147,6 +150,8 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.Vp = o;    o += al(nd * D * KP * sizeof(float));
   k.phi = o;   o += al(nd * D * sizeof(float));
   k.dbias = o; o += al(D * sizeof(float));
+  k.Vb = o;    if (c->flags & SPMF_FLAG_MIXED) o += al(D * KP * sizeof(float));
+  k.bb = o;    if (c->flags & SPMF_FLAG_MIXED) o += al(D * sizeof(float));
   k.z = o;     o += al(nd * (size_t)rows * KP * sizeof(float));
   k.gzs = o;   o += al(nd * (size_t)rows * KP * sizeof(float));
   k.gzd = o;   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) o += al((size_t)rows * KP * sizeof(float));
@@ -217,6 +222,14 @@ int spmf_ctx_set_column_types(spmf_ctx* c, const uint8_t* column_is_bernoulli) {
   return SPMF_OK;
 }
 
+int spmf_ctx_set_bernoulli_columns(spmf_ctx* c, const int32_t* cols, int n) {
+  if (!c || !(c->flags & SPMF_FLAG_MIXED) || n < 0 || n > c->D || (n > 0 && !cols)) return fail(c, SPMF_E_ARG,
+      "set_bernoulli_columns: needs a SPMF_FLAG_MIXED ctx and n indices in [0, D)");
+  c->bcols = n > 0 ? cols : nullptr;
+  c->n_bcols = n;
+  return SPMF_OK;
+}
+
 size_t spmf_workspace_bytes(const spmf_ctx* c, int64_t max_rows, int S) {
   if (!c || max_rows < 0 || S < 1) return 0;
   return carve(c, max_rows, S).total;
@@ -249,6 +262,8 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   c->Vp = (float*)(c->ws + k.Vp);
   c->phi = (float*)(c->ws + k.phi);
   c->dbias = (float*)(c->ws + k.dbias);
+  c->Vb = (float*)(c->ws + k.Vb);
+  c->bb = (float*)(c->ws + k.bb);
   c->z = (float*)(c->ws + k.z);
   c->gzs = (float*)(c->ws + k.gzs);
   c->gzd = (float*)(c->ws + k.gzd);
@@ -404,21 +419,34 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       const int act = logt >= 2 ? 1 : 0;
       const float* lbias = logt == 3 ? c->dbias : c->phi;   // mixed: -1e30 masks the Poisson columns
       float* gphi_acc = acc + L.gphi_off(0);
+      // mixed likelihood with the Bernoulli column list set: the dense sums run over those
+      // columns only (compacted V' rows), instead of over all D with the Poisson half masked
+      const bool compact = logt == 3 && c->bcols && c->n_bcols > 0;
+      const float* Wd = c->Vp;
+      int Dd = D;
+      const int32_t* orows = nullptr;
+      if (compact) {
+        launch_compact_rows(c->n_bcols, KP, c->bcols, c->Vp, c->phi, c->Vb, c->bb, st);
+        Wd = c->Vb;
+        Dd = c->n_bcols;
+        lbias = c->bb;
+        orows = c->bcols;
+      }
       // Z-stationary: Q rows are columns d -> bias_q = phi (Bernoulli logits)
-      ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzd, 1.f, dacc + 3, 1, 0, act, nullptr,
-          act ? lbias : nullptr, nullptr};
+      ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, 1, 0, act, nullptr,
+          act ? lbias : nullptr, nullptr, nullptr};
       launch_expdot(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E (or sum softplus)
       // W-stationary launch has only D/128 workgroups: split the row (Q) range
       // into chunks until ~4 workgroups per CU are in flight
-      const int nbx = (D + 127) / 128;
+      const int nbx = (Dd + 127) / 128;
       const int qtiles = (int)((ct->n_rows + 127) / 128);
       int chunks = (1024 + nbx - 1) / nbx;
       if (chunks > qtiles) chunks = qtiles;
       if (chunks < 1) chunks = 1;
       // W-stationary: P rows are columns d -> bias_p = phi; Bernoulli also needs the
       // column sums of sigmoid for d/dphi (subtracted from the gphi accumulators)
-      ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, chunks, 1, act, act ? lbias : nullptr,
-          nullptr, act ? gphi_acc : nullptr};
+      ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, chunks, 1, act, act ? lbias : nullptr,
+          nullptr, act ? gphi_acc : nullptr, orows};
       launch_expdot(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
       RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
                                                      double* __restrict__ esum, int atomic_out,
                                                      const float* __restrict__ bias_p,
                                                      const float* __restrict__ bias_q,
-                                                     float* __restrict__ out2) {
+                                                     float* __restrict__ out2,
+                                                     const int32_t* __restrict__ out_rows) {
   constexpr int PITCH = KD + 4;   // 16-B aligned rows; (KD+4) % 64 = 4 keeps b128 column reads conflict free
   constexpr int KH = KD / 2;      // lane half h covers k in [h*KH, (h+1)*KH): any k order is valid
                                   // as long as A and B agree, and this one makes A a contiguous read
@@ -303,12 +304,15 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
 #pragma unroll
   for (int b = 0; b < PB; ++b) {
     const int p = p0 + b * 32 + c;
+    // out_rows: P holds a compacted subset of rows (mixed likelihood: the Bernoulli columns);
+    // results go to the rows of the full-size output they came from
+    const int prow = (out_rows && p < NP) ? out_rows[p] : p;
     if (p < NP) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float* dst = out + (size_t)p * KD + m * 32 + 8 * g + 4 * h;
+          float* dst = out + (size_t)prow * KD + m * 32 + 8 * g + 4 * h;
           if (atomic_out) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) atomicAdd(dst + j, sign * acc[b][m][4 * g + j]);
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
     if (ACT == 1 && out2) {
       float cs = colsum[b];
       cs += __shfl_xor(cs, 32);                         // the two lane halves hold disjoint q rows
-      if (h == 0 && p < NP && cs != 0.f) atomicAdd(&out2[p], sign * cs);
+      if (h == 0 && p < NP && cs != 0.f) atomicAdd(&out2[prow], sign * cs);
     }
   }
   if (esum) {
@@ -337,6 +341,29 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
   }
 }
 
+// Mixed likelihood: the dense softplus/sigmoid sums run over the Bernoulli columns only.
+// Vb[j] = V'[cols[j]], bb[j] = phi[cols[j]] (one wave per 64 floats of a row).
+__global__ __launch_bounds__(256) void compact_rows_kernel(int n, int KD, const int32_t* __restrict__ cols,
+                                                           const float* __restrict__ Vp,
+                                                           const float* __restrict__ phi,
+                                                           float* __restrict__ Vb, float* __restrict__ bb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tot = (int64_t)n * KD;
+  if (i < tot) {
+    const int j = (int)(i / KD), k = (int)(i % KD);
+    const int d = cols[j];
+    Vb[i] = Vp[(size_t)d * KD + k];
+    if (k == 0) bb[j] = phi[d];
+  }
+}
+void launch_compact_rows(int n, int KD, const int32_t* cols, const float* Vp, const float* phi, float* Vb,
+                         float* bb, hipStream_t st) {
+  if (n <= 0) return;
+  const int64_t tot = (int64_t)n * KD;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, n, KD, cols, Vp,
+                     phi, Vb, bb);
+}
+
 void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st) {
   const int pb = KD == 32 ? 2 : 1;
   const int nbx = (a.NP + 128 * pb - 1) / (128 * pb);
@@ -344,7 +371,7 @@ void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st) {
   dim3 grid(nbx, chunks);
 #define SPMF_ED_LAUNCH(KD_, ACT_)                                                              \
   hipLaunchKernelGGL((expdot_kernel<KD_, ACT_>), grid, dim3(256), 0, st, a.NP, a.NQ, a.P, a.Q, \
-                     a.out, a.sign, a.esum, a.atomic_out, a.bias_p, a.bias_q, a.out2)
+                     a.out, a.sign, a.esum, a.atomic_out, a.bias_p, a.bias_q, a.out2, a.out_rows)
   if (KD == 32 && a.act == 0) SPMF_ED_LAUNCH(32, 0);
   else if (KD == 32) SPMF_ED_LAUNCH(32, 1);
   else if (KD == 64 && a.act == 0) SPMF_ED_LAUNCH(64, 0);

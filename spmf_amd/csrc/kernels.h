@@ -71,8 +71,11 @@ struct ExpdotArgs {
   int act;             // 0 exp (Poisson log_transform), 1 sigmoid/softplus (Bernoulli)
   const float *bias_p, *bias_q;  // act 1: logit bias per P row / per Q row (one of them)
   float* out2;         // act 1: out2[p] += sign * sum_q sigmoid (may be null)
+  const int32_t* out_rows;   // P is a compacted row subset: out / out2 rows to write (may be null)
 };
 void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st);
+void launch_compact_rows(int n, int KD, const int32_t* cols, const float* Vp, const float* phi, float* Vb,
+                         float* bb, hipStream_t st);
 
 struct DenseLLArgs {
   int64_t B;

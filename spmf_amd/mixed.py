@@ -37,6 +37,7 @@ class MixedFactorization(PoissonFactorization):
         if kwargs.get("log_transform"):
             raise NotImplementedError("MixedFactorization supports the linear decoder only")
         self.bernoulli_columns = mask
+        self.compact_bernoulli = bool(kwargs.pop("compact_bernoulli", True))
         self._ctype_dev = None
         super().__init__(latent_dim=latent_dim, feature_dim=feature_dim, **kwargs)
 
@@ -47,6 +48,13 @@ class MixedFactorization(PoissonFactorization):
             self._ctype_dev = torch.as_tensor(self.bernoulli_columns.astype(np.uint8)).to(self.device)
             _lib.check(h, _lib.load().spmf_ctx_set_column_types(h, self._ctype_dev.data_ptr()),
                        "spmf_ctx_set_column_types")
+            # the dense softplus sums only need the Bernoulli columns: hand the library their list
+            self._bcols_dev = torch.as_tensor(np.flatnonzero(self.bernoulli_columns).astype(np.int32)
+                                              ).to(self.device)
+            if self.compact_bernoulli and self._bcols_dev.numel() > 0:
+                _lib.check(h, _lib.load().spmf_ctx_set_bernoulli_columns(
+                    h, self._bcols_dev.data_ptr(), int(self._bcols_dev.numel())),
+                    "spmf_ctx_set_bernoulli_columns")
         return h
 
     def create_distributions(self):
