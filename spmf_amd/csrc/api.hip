@@ -29,6 +29,8 @@ struct spmf_ctx {
   float* acc = nullptr;
   double* dacc = nullptr;
   double* dprep = nullptr;
+  double* fpart = nullptr;   // finish kernel: per-block prior-part sums
+  float* futau = nullptr;    //                per-block u_tau gradient sums
   float *Ap = nullptr, *Vp = nullptr, *phi = nullptr, *z = nullptr, *gzs = nullptr, *gzd = nullptr, *dbias = nullptr;
   const uint8_t* ctype = nullptr;   // mixed likelihood: 1 = Bernoulli column (device, caller-owned)
   const int32_t* bcols = nullptr;   // mixed likelihood: ascending indices of the Bernoulli columns (optional)
@@ -125,7 +127,7 @@ static size_t var_size(const spmf_ctx* c, int i) {
 }
 
 struct Carve {
-  size_t acc, dacc, dprep, Ap, Vp, phi, dbias, Vb, bb, z, gzs, gzd, total;
+  size_t acc, dacc, dprep, ppart, putau, Ap, Vp, phi, dbias, Vb, bb, z, gzs, gzd, total;
 };
 // Small batches run all S draws in ONE launch per kernel (gridDim.y = S): the per-draw tables and
 // row outputs then exist S times.  Only for the linear Poisson decoder, only while the S table
@@ -146,6 +148,9 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.acc = o;   o += al((size_t)S * acc_len(c->D, c->KP) * sizeof(float));
   k.dacc = o;  o += al((size_t)S * kDaccRep * (kDaccHead + KP) * sizeof(double));
   k.dprep = o; o += al((size_t)S * (KP + 1) * sizeof(double));
+  const size_t fnb = (D + 31) / 32;                       // workgroups of the finish kernel
+  k.ppart = o; o += al((size_t)S * fnb * 12 * sizeof(double));
+  k.putau = o; o += al((size_t)S * fnb * KP * sizeof(float));
   k.Ap = o;    o += al(nd * D * KP * sizeof(float));
   k.Vp = o;    o += al(nd * D * KP * sizeof(float));
   k.phi = o;   o += al(nd * D * sizeof(float));
@@ -258,6 +263,8 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   c->acc = (float*)(c->ws + k.acc);
   c->dacc = (double*)(c->ws + k.dacc);
   c->dprep = (double*)(c->ws + k.dprep);
+  c->fpart = (double*)(c->ws + k.ppart);
+  c->futau = (float*)(c->ws + k.putau);
   c->Ap = (float*)(c->ws + k.Ap);
   c->Vp = (float*)(c->ws + k.Vp);
   c->phi = (float*)(c->ws + k.phi);
@@ -382,7 +389,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
   if (parts_mask != 3 && S != 1) return fail(c, SPMF_E_UNSUPPORTED, "data_pass_split: one draw per step only");
   const bool first = parts_mask & 1, second = parts_mask & 2;
   // zero acc | dacc | dprep (contiguous in the carve)
-  if (first) launch_zero(c->acc, (size_t)((char*)c->Ap - (char*)c->acc), st);
+  if (first) launch_zero(c->acc, (size_t)((char*)c->fpart - (char*)c->acc), st);
   if (c->timing && first) {
     c->ev_set = (c->ev_set + 1) % spmf_ctx::kSets;
     c->ev = c->evs[c->ev_set];
@@ -525,6 +532,7 @@ int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const
   for (int i = 0; i < SPMF_NVARS; ++i)
     if ((!params[i] || !grads[i]) && !(hsf && i != 0 && i != 1 && i != 2 && i != 7))
       return fail(c, SPMF_E_ARG, "prior_async: params/grads must be non-null (all 12; v,w,u,s with ABS_HORSESHOE)");
+  if (!c->fpart) return fail(c, SPMF_E_WORKSPACE, "prior_async: no data pass has bound the workspace yet");
   hipStream_t st = (hipStream_t)stream;
   if (!c->side) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -533,13 +541,14 @@ int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const
   }
   // outputs are zeroed in stream order, then the side stream forks off `stream`
   launch_zero(parts, (size_t)S * SPMF_NPARTS * sizeof(double), st);
-  if (!hsf) launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
+  (void)hsf;   // (u_tau gradient: written whole by finish_reduce_kernel, no zero fill)
   HIPCHK(c, hipEventRecord(c->ev_fork, st));
   HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
   {
     // one launch for all S draws (gridDim.y)
     FinishArgs fa{c->D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight, nullptr, nullptr,
-        params, eta, grads, parts, nullptr, likelihood_code(c), c->ctype, c->Dh, S, 0, {}, hsf ? 1 : 0};
+        params, eta, grads, parts, nullptr, likelihood_code(c), c->ctype, c->Dh, S, 0, {}, hsf ? 1 : 0,
+        c->fpart, c->futau};
     for (int i = 0; i < SPMF_NVARS; ++i) fa.vstride[i] = (int64_t)var_size(c, i);
     launch_finish(c->KP, fa, 1, c->side);
   }
@@ -571,14 +580,14 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   } else {
     launch_zero(parts, (size_t)S * SPMF_NPARTS * sizeof(double), st);
-    if (!hsf) launch_zero(grads[4], (size_t)S * c->K * sizeof(float), st);
+    (void)hsf;   // (u_tau gradient: written whole by finish_reduce_kernel, no zero fill)
   }
   {
     // one launch for all S draws (gridDim.y)
     const bool tm = c->timing;
     FinishArgs fa{D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay, prior_weight,
         c->acc, c->dprep, params, eta, grads, parts, n_nonfinite, likelihood_code(c), c->ctype, c->Dh, S,
-        (int64_t)al_, {}, hsf ? 1 : 0};
+        (int64_t)al_, {}, hsf ? 1 : 0, c->fpart, c->futau};
     for (int i = 0; i < SPMF_NVARS; ++i) fa.vstride[i] = (int64_t)var_size(c, i);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
     launch_finish(KP, fa, joined ? 2 : 0, st);

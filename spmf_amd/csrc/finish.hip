@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
                                                      double* __restrict__ parts,
                                                      double* __restrict__ nnf_out, int logt,
                                                      const uint8_t* __restrict__ ctype, int Dh,
-                                                     int64_t acc_stride, VStride VS, int hs) {
+                                                     int64_t acc_stride, VStride VS, int hs,
+                                                     double* __restrict__ ppart,
+                                                     float* __restrict__ putau) {
   // hs: horshoe_plus=False (poisson.py:378-398): AbsHorseshoe priors on u and s, no
   // scale hierarchy -- only P/G[V_, W_, U_, S_] are touched
   constexpr bool PRIOR = PHASE != 2, DATA = PHASE != 1;
@@ -129,6 +131,12 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     parts += sd * 14;
     if (nnf_out) nnf_out += sd;
   }
+  // Cross-block sums (the twelve prior parts, the u_tau gradient) go to per-block slots
+  // that finish_reduce_kernel adds up in block order: given the same accumulators the
+  // results are bit-identical from run to run and from rank to rank (the replicated
+  // parameters of a row-sharded job cannot drift apart through this kernel).
+  if (ppart) ppart += ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12;
+  if (putau) putau += ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * KP;
   __shared__ float tile[KP][FTD + 1];
   __shared__ float w1s[FTD], ietas[FTD], etas_[FTD], GAs[FTD];
   __shared__ float zsum_s[KP], utau_s[KP], dec_s[KP], gutau_s[KP];
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
         part[UTAUA_] += (double)lp2;
         G.p[UTAUA_][t] = pw * (ga + ga2);
       }
-      atomicAdd(&G.p[UTAU_][t], g);  // zeroed by the host before launch
+      putau[t] = g;
     }
     // ---- energy parts ------------------------------------------------------
     __shared__ double pred[12][4];
@@ -402,10 +410,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       if (lane == 0) pred[i][wid] = s;
     }
     __syncthreads();
-    if (t < 12) {
-      const double s = pred[t][0] + pred[t][1] + pred[t][2] + pred[t][3];
-      if (s != 0.0) atomicAdd(&parts[t], s);
-    }
+    if (t < 12) ppart[t] = pred[t][0] + pred[t][1] + pred[t][2] + pred[t][3];
   }
   if (DATA && blockIdx.x == 0 && t == 0) {
     const double llx = unpack(tail, 0), zsq = unpack(tail, 1);
@@ -419,13 +424,52 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * dprep[k];
       if (logt == 3) sum_r += unpack(tail, 3);   // mixed: + softplus over the Bernoulli columns
     }
-    atomicAdd(&parts[13], llx - (logt == 2 ? 0.0 : lgamma_sum) - sum_r);
-    atomicAdd(&parts[12], Bglob * (double)K * kHalfLog2OverPi - 0.5 * zsq);
+    parts[13] = llx - (logt == 2 ? 0.0 : lgamma_sum) - sum_r;      // single writer
+    parts[12] = Bglob * (double)K * kHalfLog2OverPi - 0.5 * zsq;
     if (nnf_out) {
       nnf_out[0] = unpack(tail, 2);
       nnf_out[gridDim.y] = unpack(tail, 4);     // [S + s]: saturated cells (log_transform)
     }
   }
+}
+
+// Second stage of the finish kernel's cross-block sums: one workgroup per draw.  The
+// association is fixed (16 / 4 strided chains per slot, folded in chain order), so the
+// result does not depend on timing; the chains only exist to have loads in flight.
+__global__ __launch_bounds__(256) void finish_reduce_kernel(int nb, int K, int KP, int hs,
+                                                           const double* __restrict__ ppart,
+                                                           const float* __restrict__ putau,
+                                                           double* __restrict__ parts, float* gutau,
+                                                           int64_t utau_stride) {
+  __shared__ double ps[16][12];
+  __shared__ float us[4][64];
+  const int sd = blockIdx.x, t = threadIdx.x;
+  ppart += (size_t)sd * nb * 12;
+  putau += (size_t)sd * nb * KP;
+  {
+    const int slot = t % 16, chain = t / 16;            // 16 chains x (12 slots + 4 idle)
+    double s = 0.0;
+    if (slot < 12)
+#pragma unroll 4
+      for (int b = chain; b < nb; b += 16) s += ppart[(size_t)b * 12 + slot];
+    if (slot < 12) ps[chain][slot] = s;
+  }
+  const bool ut = !hs && gutau != nullptr;
+  if (ut) {
+    const int k = t % 64, chain = t / 64;               // 4 chains x 64 features
+    float s = 0.f;
+    if (k < K)
+#pragma unroll 4
+      for (int b = chain; b < nb; b += 4) s += putau[(size_t)b * KP + k];
+    us[chain][k] = s;
+  }
+  __syncthreads();
+  if (t < 12) {
+    double s = 0.0;
+    for (int c = 0; c < 16; ++c) s += ps[c][t];
+    parts[(size_t)sd * 14 + t] = s;
+  }
+  if (ut && t < K) gutau[(size_t)sd * utau_stride + t] = (us[0][t] + us[1][t]) + (us[2][t] + us[3][t]);
 }
 
 __global__ void pack_kernel(int KP, const double* __restrict__ dacc, float* __restrict__ tail,
@@ -465,11 +509,14 @@ static void launch_finish_t(const FinishArgs& a, int phase, hipStream_t st) {
                      (double)a.B_global, a.lgamma_sum, (float)a.u_tau_scale,                     \
                      (float)a.s_tau_scale, a.decay, (float)a.prior_weight, a.acc, a.dprep, P,    \
                      a.eta, G, a.parts, a.n_nonfinite, a.logt, a.ctype, a.Dh > 0 ? a.Dh : a.D,   \
-                     a.acc_stride, VS, a.abs_horseshoe)
+                     a.acc_stride, VS, a.abs_horseshoe, a.ppart, a.putau)
   if (phase == 1) SPMF_FIN(1);
   else if (phase == 2) SPMF_FIN(2);
   else SPMF_FIN(0);
 #undef SPMF_FIN
+  if (phase != 2)   // the prior half produced per-block partials: add them up in block order
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(a.S > 1 ? a.S : 1), dim3(256), 0, st, nb, a.K, KP,
+                       a.abs_horseshoe, a.ppart, a.putau, a.parts, a.grads[4], a.vstride[4]);
 }
 
 // phase 0: whole finish; 1: prior half (no accumulators read); 2: data half (adds to G)

@@ -143,6 +143,8 @@ struct FinishArgs {
   int64_t acc_stride;
   int64_t vstride[12];
   int abs_horseshoe;     // horshoe_plus=False: only params/grads 0, 1, 2, 7 are used
+  double* ppart;         // [S][ceil(D/32)][12] per-block prior-part sums (workspace)
+  float* putau;          // [S][ceil(D/32)][KP] per-block u_tau gradient sums (workspace)
 };
 void launch_finish(int KP, const FinishArgs& a, int phase, hipStream_t st);
 

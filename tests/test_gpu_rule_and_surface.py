@@ -432,3 +432,44 @@ def test_custom_encoder_decoder_callables():
     losses = m3.fit(lambda: [{"counts": x}], dataset_size=50, sample_size=2, num_steps=5,
                     learning_rate=0.02, rel_tol=1e-12, verbose=False)
     assert len(losses) >= 3 and all(math.isfinite(v) for v in losses)
+
+
+def test_finish_is_deterministic_given_the_accumulators():
+    """SURVEY section 5 (deterministic-reduction self-check): the finish kernel's
+    cross-block sums are two-stage in block order, so two runs over the SAME
+    accumulators give bit-identical parts and gradients -- what keeps the replicated
+    parameters of a row-sharded job from drifting (every rank holds identical
+    accumulators after the all-reduce).  The data pass itself uses float atomics in the
+    column pass: two full evaluations agree to ~1e-7, not bitwise, which is also checked."""
+    import ctypes as C
+    from spmf_amd import _lib
+    cfg, x, params = make_problem(400, 300, 32, 2, 5, 0.05)
+    m = build_model(cfg, 64)
+    p1, g1, _ = m.energy_and_grads({"counts": x}, params)
+    lib, h = _lib.load(), m._handle()
+    sc, cs = m._batch({"counts": x})
+    S, P = m._pack_params(params)
+    eta = m._eta_device()
+    stream = torch.cuda.current_stream().cuda_stream
+    pin = _lib.PtrArray(*[P[n].data_ptr() for n in _lib.VAR_ORDER])
+    outs = []
+    for rep in range(3):
+        grads = {n: torch.full_like(P[n], float("nan")) for n in _lib.VAR_ORDER}
+        gout = _lib.PtrArray(*[grads[n].data_ptr() for n in _lib.VAR_ORDER])
+        parts = torch.full((S, 14), float("nan"), dtype=torch.float64, device="cuda")
+        nnf = torch.empty(2 * S, dtype=torch.float64, device="cuda")
+        _lib.check(h, lib.spmf_finish(h, S, cs.n_rows, float(cs.lgamma_sum), 1.0, pin, eta.data_ptr(),
+                                      parts.data_ptr(), gout, nnf.data_ptr(), stream), "spmf_finish")
+        torch.cuda.synchronize()
+        outs.append((parts.clone(), {k: v.clone() for k, v in grads.items()}))
+    for parts, grads in outs[1:]:
+        assert torch.equal(parts, outs[0][0])
+        for k in grads:
+            assert torch.equal(grads[k], outs[0][1][k]), k
+    # same values as the first full evaluation (same accumulators are still in the workspace)
+    for i, n in enumerate(_lib.PART_ORDER):
+        assert torch.equal(outs[0][0][:, i], p1[n]), n
+    # a second full evaluation: float atomics reorder the column pass's sums
+    p2, g2, _ = m.energy_and_grads({"counts": x}, params)
+    for k in g1:
+        assert float((g1[k] - g2[k]).abs().max()) <= 1e-6 * float(g1[k].abs().max()), k
