@@ -433,43 +433,30 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   }
 }
 
-// Second stage of the finish kernel's cross-block sums: one workgroup per draw.  The
-// association is fixed (16 / 4 strided chains per slot, folded in chain order), so the
-// result does not depend on timing; the chains only exist to have loads in flight.
-__global__ __launch_bounds__(256) void finish_reduce_kernel(int nb, int K, int KP, int hs,
-                                                           const double* __restrict__ ppart,
-                                                           const float* __restrict__ putau,
-                                                           double* __restrict__ parts, float* gutau,
-                                                           int64_t utau_stride) {
-  __shared__ double ps[16][12];
-  __shared__ float us[4][64];
-  const int sd = blockIdx.x, t = threadIdx.x;
-  ppart += (size_t)sd * nb * 12;
-  putau += (size_t)sd * nb * KP;
-  {
-    const int slot = t % 16, chain = t / 16;            // 16 chains x (12 slots + 4 idle)
+// Second stage of the finish kernel's cross-block sums: one wave per output (12 prior
+// parts + K u_tau gradients) and draw.  Lane l adds blocks l, l+64, ... in order, then a
+// butterfly folds the lanes: a fixed association, so the result does not depend on timing;
+// the lanes only exist to have the loads in flight.
+__global__ __launch_bounds__(64) void finish_reduce_kernel(int nb, int K, int KP, int hs,
+                                                          const double* __restrict__ ppart,
+                                                          const float* __restrict__ putau,
+                                                          double* __restrict__ parts, float* gutau,
+                                                          int64_t utau_stride) {
+  const int slot = blockIdx.x, sd = blockIdx.y, lane = threadIdx.x;
+  if (slot < 12) {
+    ppart += (size_t)sd * nb * 12;
     double s = 0.0;
-    if (slot < 12)
-#pragma unroll 4
-      for (int b = chain; b < nb; b += 16) s += ppart[(size_t)b * 12 + slot];
-    if (slot < 12) ps[chain][slot] = s;
-  }
-  const bool ut = !hs && gutau != nullptr;
-  if (ut) {
-    const int k = t % 64, chain = t / 64;               // 4 chains x 64 features
+    for (int b = lane; b < nb; b += 64) s += ppart[(size_t)b * 12 + slot];
+    s = wave_sum(s);
+    if (lane == 0) parts[(size_t)sd * 14 + slot] = s;
+  } else if (!hs && gutau) {
+    const int k = slot - 12;
+    putau += (size_t)sd * nb * KP;
     float s = 0.f;
-    if (k < K)
-#pragma unroll 4
-      for (int b = chain; b < nb; b += 4) s += putau[(size_t)b * KP + k];
-    us[chain][k] = s;
+    for (int b = lane; b < nb; b += 64) s += putau[(size_t)b * KP + k];
+    s = wave_sum(s);
+    if (lane == 0) gutau[(size_t)sd * utau_stride + k] = s;
   }
-  __syncthreads();
-  if (t < 12) {
-    double s = 0.0;
-    for (int c = 0; c < 16; ++c) s += ps[c][t];
-    parts[(size_t)sd * 14 + t] = s;
-  }
-  if (ut && t < K) gutau[(size_t)sd * utau_stride + t] = (us[0][t] + us[1][t]) + (us[2][t] + us[3][t]);
 }
 
 __global__ void pack_kernel(int KP, const double* __restrict__ dacc, float* __restrict__ tail,
@@ -515,7 +502,7 @@ static void launch_finish_t(const FinishArgs& a, int phase, hipStream_t st) {
   else SPMF_FIN(0);
 #undef SPMF_FIN
   if (phase != 2)   // the prior half produced per-block partials: add them up in block order
-    hipLaunchKernelGGL(finish_reduce_kernel, dim3(a.S > 1 ? a.S : 1), dim3(256), 0, st, nb, a.K, KP,
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(12 + a.K, a.S > 1 ? a.S : 1), dim3(64), 0, st, nb, a.K, KP,
                        a.abs_horseshoe, a.ppart, a.putau, a.parts, a.grads[4], a.vstride[4]);
 }
 
