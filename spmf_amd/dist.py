@@ -79,20 +79,28 @@ class ShardReducer:
         self.comm = comm
         self.active = dist.is_initialized() or comm is not None   # also with one rank (exercises the transport)
         self.world = dist.get_world_size(group) if dist.is_initialized() else (comm.world if comm else 1)
-        self.rows_global = None
+        self.rows_global = None        # per-step batch totals when every batch is the whole shard
         self.lgamma_global = None
+        self.dataset_rows = None       # set by reduce_stats
+        self.dataset_lgamma = None
 
-    def reduce_stats(self, colsum, colnnz, rows, lgamma_sum):
+    def reduce_stats(self, colsum, colnnz, rows, lgamma_sum, full_batch=False):
         """compute_scales' one-time reduction (poisson.py:118-135 across
-        shards): sums colsum/colnnz in place, returns global (rows, lgamma)."""
+        shards): sums colsum/colnnz in place, returns the dataset's global
+        (rows, lgamma) and keeps them as dataset_rows / dataset_lgamma.
+        ``full_batch``: every step's batch IS the rank's whole shard, so these are
+        also the per-step batch totals (set_batch_totals) and no step has to
+        reduce them again; leave it False when the shards are minibatched."""
         tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64,
                            device=colsum.device)
         if self.active:
             for t in (colsum, colnnz, tot):
                 self._sum(t)
-        self.rows_global = int(round(float(tot[0])))
-        self.lgamma_global = float(tot[1])
-        return self.rows_global, self.lgamma_global
+        self.dataset_rows = int(round(float(tot[0])))
+        self.dataset_lgamma = float(tot[1])
+        if full_batch:
+            self.set_batch_totals(self.dataset_rows, self.dataset_lgamma)
+        return self.dataset_rows, self.dataset_lgamma
 
     def set_batch_totals(self, rows_global, lgamma_global):
         self.rows_global, self.lgamma_global = int(rows_global), float(lgamma_global)

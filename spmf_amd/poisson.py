@@ -620,19 +620,27 @@ class PoissonFactorization:
     # ------------------------------------------------------------------
     # compute_scales (poisson.py:113-154)
     # ------------------------------------------------------------------
-    def compute_scales(self, data_factory, compute_normalization=True, n=None):
+    def compute_scales(self, data_factory, compute_normalization=True, n=None, all_reduce=None):
+        """``all_reduce``: with row shards (``data_factory`` yields THIS rank's rows)
+        a spmf_amd.dist.ShardReducer; its reduce_stats sums the column statistics
+        once over the ranks, so every rank ends with the same eta_i / xi_u_global
+        and the reducer knows the dataset's global row count."""
         if self.scale_columns and compute_normalization:
             print("Looping through the entire dataset once to get some stats")
             D = self.feature_dim
             colsum = torch.zeros(D, dtype=torch.float64, device=self.device)
             colnnz = torch.zeros(D, dtype=torch.float64, device=self.device)
-            N = 0
+            N, lg = 0, 0.0
             h = self._handle()
             for batch in iter(data_factory()):
                 x = batch[self.count_key] if isinstance(batch, dict) else batch
                 sc = SparseCounts.from_any(x, self.device, self.panel_rows)
                 sc.compute_stats(h, colsum, colnnz)
                 N += sc.n_rows
+                if all_reduce is not None:
+                    lg += float(sc.row_lgamma.sum())
+            if all_reduce is not None:
+                all_reduce.reduce_stats(colsum, colnnz, N, lg)
             colmeans_nonzero = colsum / colnnz          # NaN for empty columns
             # poisson.py:139-140 sums NaNs into xi for an empty column; the
             # build defines xi over the non-empty columns (SURVEY 8a row 3).

@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
     red = ShardReducer()
     colsum = torch.from_numpy(np.asarray(xs.sum(0)).reshape(-1).copy())
     colnnz = torch.from_numpy(np.asarray((xs > 0).sum(0)).reshape(-1).astype(np.float64))
-    rows_g, lg_g = red.reduce_stats(colsum, colnnz, r1 - r0, lg)
+    rows_g, lg_g = red.reduce_stats(colsum, colnnz, r1 - r0, lg, full_batch=True)
     # the column-split protocol (start / wait / totals) sums the same buffer in two ranges
     acc2 = acc.clone()
     half = acc2.numel() // 3
