@@ -300,7 +300,11 @@ int spmf_nonfinite_lgamma(spmf_ctx* ctx, const spmf_counts* counts, const float*
  * io = double[4]: [0] global minimum over all S*B*D cells (spmf_nonfinite_reduce
  * pass 0 over spmf_dense_ll output), [3] its cell (spmf_nonfinite_argmin);
  * nlg = double[S]: spmf_nonfinite_lgamma per draw.
- * Single shard only: with row shards the minimum needs its own (min) all-reduce. */
+ * Row shards: call it on the shard's OWN (not yet summed) accumulators with
+ * io[0] = the minimum over the shard minima, io[2] = sum_s nnf_s over ALL shards
+ * (0: taken from the accumulators, the single-shard case) and io[3] = +inf on
+ * every shard but the one that holds the minimum's cell; the value terms are
+ * per shard and add up in the all-reduce that follows. */
 int spmf_nonfinite_patch(spmf_ctx* ctx, const spmf_counts* counts, int S,
                          const float* const params[SPMF_NVARS], const float* eta,
                          const double* io, const double* nlg, void* stream);

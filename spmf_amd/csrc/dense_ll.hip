@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void nonfinite_patch_kernel(
     const float* tq = acc + (size_t)q * acc_stride + L.tail_off();
     N += (double)tq[2 * 2] + (double)tq[2 * 2 + 1];
   }
+  if (io[2] > 0.0) N = io[2];                            // row shards: the count over ALL shards
   const double m = io[0] - 10.0;
   if (t == 0) {
     const double nnf = (double)tail[4] + (double)tail[5];

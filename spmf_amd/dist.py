@@ -79,6 +79,7 @@ class ShardReducer:
         self.comm = comm
         self.active = dist.is_initialized() or comm is not None   # also with one rank (exercises the transport)
         self.world = dist.get_world_size(group) if dist.is_initialized() else (comm.world if comm else 1)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else (comm.rank if comm else 0)
         self.rows_global = None        # per-step batch totals when every batch is the whole shard
         self.lgamma_global = None
         self.dataset_rows = None       # set by reduce_stats
@@ -148,6 +149,20 @@ class ShardReducer:
                 self._sum(tot)
             return int(round(float(tot[0]))), float(tot[1])
         return self.rows_global, self.lgamma_global
+
+    def gather_scalar(self, value, device=None):
+        """[world] list of every rank's float32-exact scalar (the non-finite rule's
+        per-shard minimum, poisson.py:609): a one-hot vector through the SAME sum
+        all-reduce as the accumulators, so any transport that can sum can gather."""
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if (
+                self.comm is not None or (dist.is_initialized() and dist.get_backend(self.group) == "nccl")
+            ) else torch.device("cpu")
+        v = torch.zeros(self.world, dtype=torch.float32, device=device)
+        v[self.rank] = float(value)
+        if self.active:
+            self._sum(v)
+        return [float(x) for x in v.cpu()]
 
     # ---- replicated state ------------------------------------------------------
     def sync_replicas(self, tensors, src=0):

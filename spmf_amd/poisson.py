@@ -339,7 +339,9 @@ class PoissonFactorization:
         read-back): they are left out of 'x' and its gradient and counted in
         n_nonfinite.  "rule": the reference's replacement rule
         (poisson.py:606-616), value AND gradient -- one host read of the count
-        per call, the dense fallback only when it is non-zero (single shard).
+        per call, the dense fallback only when it is non-zero.  With row shards
+        the fallback costs a second data pass and all-reduce (the minimum is taken
+        over the shard minima, its gradient term comes from the shard that holds it).
         """
         if nonfinite not in ("count", "rule"):
             raise ValueError("nonfinite must be 'count' or 'rule'")
@@ -401,14 +403,33 @@ class PoissonFactorization:
                                       parts.data_ptr(), gout, nnf.data_ptr(), stream),
                    "spmf_finish")
         if nonfinite == "rule" and float(nnf.sum()) > 0.0:
-            if all_reduce is not None:
-                raise NotImplementedError(
-                    "the non-finite replacement rule needs a min all-reduce across row "
-                    "shards: single shard only (n_nonfinite reports the cells)")
             io, nlg = self._nonfinite_scan(sc, cs, data, S, P)
+            if all_reduce is not None:
+                # row shards: nnf is already the global count (it came through the
+                # all-reduce), so every rank is here.  The minimum is the minimum of the
+                # shard minima; the shard that holds it owns the gradient term.  The
+                # accumulators were summed in place, so this shard's own are rebuilt,
+                # patched (value terms are per shard and add up; the gradient term is
+                # the owner's, weighted by the GLOBAL count in io[2]) and summed again.
+                if split or not hasattr(all_reduce, "gather_scalar"):
+                    raise NotImplementedError(
+                        "the non-finite replacement rule across row shards needs a reducer "
+                        "with gather_scalar (spmf_amd.dist.ShardReducer) and the one-piece "
+                        "all-reduce (no column split)")
+                mins = all_reduce.gather_scalar(float(io[0]))
+                m_g = min(mins)
+                io[0] = m_g
+                io[2] = float(nnf.sum())
+                if all_reduce.rank != mins.index(m_g):
+                    io[3] = float("inf")
+                _lib.check(h, lib.spmf_data_pass(h, C.byref(cs), S, pin, eta.data_ptr(), stream),
+                           "spmf_data_pass")
             _lib.check(h, lib.spmf_nonfinite_patch(h, C.byref(cs), S, pin, eta.data_ptr(),
                                                    io.data_ptr(), nlg.data_ptr(), stream),
                        "spmf_nonfinite_patch")
+            if all_reduce is not None:
+                all_reduce(_wrap_f32(lib.spmf_acc_ptr(h), lib.spmf_acc_len(h, S), self.device, self._ws),
+                           cs.n_rows, cs.lgamma_sum)
             _lib.check(h, lib.spmf_finish(h, S, int(rows_g), float(lg_g), float(prior_weight), pin,
                                           eta.data_ptr(), parts.data_ptr(), gout, nnf.data_ptr(),
                                           stream), "spmf_finish")

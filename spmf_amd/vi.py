@@ -312,10 +312,11 @@ def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None, nonfinit
     ``dataset_rows`` is the size of the whole dataset (all shards).
     ``nonfinite``: "rule" applies the reference's replacement rule
     (poisson.py:606-616) with its gradient when stored cells have a non-finite
-    log-pmf (single shard; default there), "count" only counts them (the
-    caller then skips the batch; default with row shards)."""
+    log-pmf (the default, also across row shards when the reducer can gather the
+    shard minima: dist.ShardReducer), "count" only counts them (the caller then
+    skips the batch; the default with any other all_reduce hook)."""
     if nonfinite is None:
-        nonfinite = "rule" if all_reduce is None else "count"
+        nonfinite = "rule" if (all_reduce is None or hasattr(all_reduce, "gather_scalar")) else "count"
     sur = model.surrogate_distribution
     S = int(sample_size)
     noise = sur.draw_noise(S)
@@ -519,9 +520,11 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
             for batch in iter(batched_data_factory()):
                 loss, grads, nnf = elbo_step(model, batch, dataset_size, sample_size, all_reduce)
                 lv = float(loss)
-                # single shard: non-finite cells were handled by the rule; with row
-                # shards they are only counted and the batch is skipped
-                if not math.isfinite(lv) or (all_reduce is not None and float(nnf.sum()) > 0):
+                # non-finite cells were handled by the rule (single shard, or row shards
+                # behind a ShardReducer); behind any other hook they are only counted and
+                # the batch is skipped
+                ruled = all_reduce is None or hasattr(all_reduce, "gather_scalar")
+                if not math.isfinite(lv) or (not ruled and float(nnf.sum()) > 0):
                     if verbose:
                         print("Batch loss NaN, skipping")
                     continue

@@ -122,3 +122,61 @@ def test_two_rank_sharded_energy_step_and_fit_equal_single_process():
     # same noise stream (same seed), same data: the sharded fit follows the single-process fit
     np.testing.assert_allclose(res["losses"], losses, rtol=2e-4)
     assert res["drift"] == 0.0
+
+
+def _rule_worker(rank, world, port, q, flip):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from spmf_amd.dist import ShardReducer, shard_bounds
+    from test_gpu_parity import build_model
+    from test_gpu_rule_and_surface import _bad_cell_problem
+    cfg, x, params = _bad_cell_problem()
+    if flip:
+        x = x[::-1].copy()          # the rate-0 cell (and the minimum's cell) move to the other shard
+    r0, r1 = shard_bounds(x.shape[0], world, rank, granule=8)
+    m = build_model(cfg, 8)
+    red = ShardReducer()
+    parts, grads, nnf = m.energy_and_grads({"counts": x[r0:r1]}, params, all_reduce=red, nonfinite="rule")
+    if rank == 1:                   # the replicas must agree: report the one not checked elsewhere
+        q.put({"parts": {k: v.cpu().numpy() for k, v in parts.items()},
+               "grads": {k: v.cpu().numpy() for k, v in grads.items()}, "nnf": nnf.cpu().numpy()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("flip", [False, True])
+def test_two_rank_nonfinite_rule_equals_single_process(flip):
+    """poisson.py:606-616 across row shards: minimum over the shard minima, the
+    gradient term from the shard that holds the minimum's cell, value terms per
+    shard -- against the single-process rule (itself pinned to the oracle in
+    test_gpu_rule_and_surface.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rule_worker, args=(r, 2, port, q, flip)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=500)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import build_model
+    from test_gpu_rule_and_surface import _bad_cell_problem
+    cfg, x, params = _bad_cell_problem()
+    if flip:
+        x = x[::-1].copy()
+    m = build_model(cfg, 8)
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params, nonfinite="rule")
+    assert res["nnf"].tolist() == nnf.cpu().tolist() == [1.0, 0.0]
+    for k, v in parts.items():
+        np.testing.assert_allclose(res["parts"][k], v.cpu().numpy(), rtol=1e-6, err_msg=k)
+    for k, v in grads.items():
+        a, b = res["grads"][k], v.cpu().numpy()
+        assert np.isfinite(a).all(), k
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), (k, np.abs(a - b).max(), np.abs(b).max())
