@@ -34,3 +34,16 @@ def test_package_exports_both_class_names():
     assert hasattr(mederrata_spmf, "PoissonMatrixFactorization")
     assert issubclass(mederrata_spmf.PoissonMatrixFactorization,
                       mederrata_spmf.PoissonFactorization)
+
+
+def test_scrnaseq_cli_defaults_match_reference_script():
+    """bin/factorize_scrnaseq_counts.py hard-codes P=3 (:40), BATCH_SIZE=256 (:46) and
+    calibrate_advi(num_steps=500, learning_rate=0.01, abs_tol=1e-3, rel_tol=1e-3,
+    clip_value=10) (:101-105): the flags default to those."""
+    spec = importlib.util.spec_from_file_location(
+        "factorize_scrnaseq_counts", os.path.join(ROOT, "bin", "factorize_scrnaseq_counts.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.build_parser().parse_args(["--counts", "x_counts.npy"])
+    assert (a.dimension, a.batch_size, a.epoch) == (3, 256, 500)
+    assert (a.learning_rate, a.abs_tol, a.rel_tol, a.clip_value) == (0.01, 1e-3, 1e-3, 10.0)

@@ -174,6 +174,46 @@ def test_cli_log_transform_flag(tmp_path):
     assert rep.shape == (240, 3) and np.isfinite(rep).all()
 
 
+def test_scrnaseq_cli_end_to_end(tmp_path):
+    """bin/factorize_scrnaseq_counts.py (reference :29-130, the C4 model's caller): log_transform
+    with gene-mean column norms through the legacy constructor + calibrate_advi, dense and CSR
+    inputs, the seven .npy outputs and their score algebra."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(4)
+    N, D, P = 300, 40, 3
+    types = rng.integers(0, P, size=N)
+    prog = rng.gamma(0.3, 1.0, size=(P, D)) * (rng.random((P, D)) < 0.3) * 6.0 + 0.2
+    depth = rng.lognormal(0.0, 0.4, size=(N, 1))
+    X = rng.poisson(prog[types] * depth).astype(np.int64)
+    names = np.array([f"GENE{j}" for j in range(D)], dtype=object)
+    np.save(tmp_path / "toy_counts.npy", X)
+    np.save(tmp_path / "toy_genenames.npy", names, allow_pickle=True)
+    cmd = [sys.executable, os.path.join(ROOT, "bin", "factorize_scrnaseq_counts.py"),
+           "--genes", str(tmp_path / "toy_genenames.npy"), "-d", str(P), "-b", "64", "-e", "6",
+           "--seed", "3"]
+    r = subprocess.run(cmd + ["--counts", str(tmp_path / "toy_counts.npy")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"Total observations={N}, Batch size=64: dropping {N % 64} observations." in r.stdout
+    assert "factor 0: GENE" in r.stdout and "intercept: GENE" in r.stdout
+    out = {k: np.load(tmp_path / f"toy_{k}_{P}.npy") for k in
+           ("U", "V", "W", "Z", "cellscore", "genescore", "interceptscore")}
+    assert out["U"].shape == (D, P) and out["V"].shape == (P, D) and out["W"].shape == (1, D)
+    assert out["Z"].shape == (N, P)
+    assert all(np.isfinite(v).all() for v in out.values())
+    rsf = X.sum(1) / np.median(X.sum(1))
+    cn = np.maximum(X.mean(0), 1e-3)
+    np.testing.assert_allclose(out["cellscore"], out["Z"] * rsf[:, None], rtol=1e-6)
+    np.testing.assert_allclose(out["genescore"], out["V"] * cn[None, :], rtol=1e-6)
+    np.testing.assert_allclose(out["interceptscore"], out["W"] * cn[None, :], rtol=1e-6)
+    # the same run from a CSR .npz: same seed, same batches -> same factors
+    sp.save_npz(tmp_path / "toyb_counts.npz", sp.csr_matrix(X))
+    r = subprocess.run(cmd + ["--counts", str(tmp_path / "toyb_counts.npz")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    np.testing.assert_allclose(np.load(tmp_path / f"toyb_V_{P}.npy"), out["V"], rtol=2e-3, atol=1e-6)
+
+
 def test_qualitative_linear_structure_outcome():
     """notebooks/factorize_linear_structure.ipynb:53-66: every third column is
     driven by the latent factors, the rest is Poisson(1) noise.  After fitting,
