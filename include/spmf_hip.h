@@ -371,6 +371,16 @@ int spmf_adam_step(spmf_ctx* ctx, const spmf_adam_var* tensors, int ntensors, do
                    double beta1, double beta2, double eps, int step, double clip,
                    void* stream);
 
+/* spmf_surrogate_bwd and spmf_adam_step_dev in ONE pass over the trainables (the
+ * gradient of a trainable never goes to memory): tensors[2i], tensors[2i+1] are the
+ * Adam records (p, m, v, n; g unused) of vars[i].t0 / vars[i].t1, p pointing at the
+ * same memory; vars[i].g0 / g1 are not written.  Gated by state[9] like
+ * spmf_adam_step_dev.  The training loop's step path; the two separate calls remain
+ * for callers that want the gradient. */
+int spmf_surrogate_bwd_adam_dev(spmf_ctx* ctx, const spmf_sur_var* vars, int nvars, int S,
+                                double inv_sb, double c, const spmf_adam_var* tensors,
+                                const double* state, void* stream);
+
 /* Device-resident optimiser state, so that a whole VI step (noise, surrogate,
  * energy + gradient, chain rule, Adam) is a fixed launch sequence with no host
  * read-back and can be captured in a hipGraph and replayed.  state is a device

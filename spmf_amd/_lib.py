@@ -124,6 +124,9 @@ SIGNATURES = {
                                C.c_double, C.c_void_p, C.c_void_p]),
     "spmf_adam_step_dev": (C.c_int, [C.c_void_p, C.POINTER(AdamVar), C.c_int, C.c_void_p,
                                      C.c_void_p]),
+    "spmf_surrogate_bwd_adam_dev": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
+                                              C.c_double, C.c_double, C.POINTER(AdamVar),
+                                              C.c_void_p, C.c_void_p]),
     "spmf_adam_step": (C.c_int, [C.c_void_p, C.POINTER(AdamVar), C.c_int, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
                                  C.c_void_p]),

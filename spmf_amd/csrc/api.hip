@@ -51,6 +51,10 @@ struct spmf_ctx {
   int batched = 0;                // the bound workspace holds per-draw tables (S draws per launch)
   int prior_pending = 0;          // S of the launched prior half, 0 = none
   const double* prior_parts = nullptr;
+  // the library's only device allocation: a small scratch for per-block partial sums of the
+  // O(D*K) surrogate kernels (fixed-order reductions instead of same-address atomics)
+  double* scratch = nullptr;
+  static constexpr size_t kScratchDoubles = 1u << 18;   // 2 MiB
   void* comm = nullptr;           // ncclComm_t of the row-shard collective (spmf_comm_init)
   int comm_rank = 0, comm_world = 1;
   std::string err;
@@ -200,6 +204,7 @@ void spmf_ctx_destroy(spmf_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->scratch) (void)hipFree(c->scratch);
   if (c->comm) {
     Rccl* r = rccl();
     if (r) (void)r->destroy(c->comm);
@@ -539,9 +544,7 @@ int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
-  // outputs are zeroed in stream order, then the side stream forks off `stream`
-  launch_zero(parts, (size_t)S * SPMF_NPARTS * sizeof(double), st);
-  (void)hsf;   // (u_tau gradient: written whole by finish_reduce_kernel, no zero fill)
+  // the side stream forks off `stream` (outputs need no zero fill: single writers)
   HIPCHK(c, hipEventRecord(c->ev_fork, st));
   HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
   {
@@ -578,10 +581,9 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
   c->prior_parts = nullptr;
   if (joined) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
-  } else {
-    launch_zero(parts, (size_t)S * SPMF_NPARTS * sizeof(double), st);
-    (void)hsf;   // (u_tau gradient: written whole by finish_reduce_kernel, no zero fill)
   }
+  // (no zero fill: finish_reduce_kernel writes the twelve prior parts and the u_tau gradient
+  //  whole, the data half stores parts 12 and 13 -- single writers)
   {
     // one launch for all S draws (gridDim.y)
     const bool tm = c->timing;
@@ -780,8 +782,18 @@ int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
     if (v.n > max_n) max_n = v.n;
   }
   hipStream_t st = (hipStream_t)stream;
-  launch_zero(logq, (size_t)S * sizeof(double), st);
-  launch_surrogate_fwd(T, nvars, max_n, S, logq, st);
+  if (!c->scratch) {
+    // first use (never inside a stream capture: a step is run eagerly before it is captured);
+    // without it the kernel falls back to atomics
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap == hipStreamCaptureStatusNone &&
+        hipMalloc((void**)&c->scratch, spmf_ctx::kScratchDoubles * sizeof(double)) != hipSuccess) {
+      c->scratch = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  launch_surrogate_fwd(T, nvars, max_n, S, logq, c->scratch, spmf_ctx::kScratchDoubles, st);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;
 }
@@ -863,6 +875,34 @@ int spmf_adam_step_dev(spmf_ctx* c, const spmf_adam_var* tensors, int ntensors, 
     if (a.n > max_n) max_n = a.n;
   }
   launch_adam_dev(T, ntensors, max_n, state, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_surrogate_bwd_adam_dev(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, double inv_sb, double cw,
+    const spmf_adam_var* tensors, const double* state, void* stream) {
+  if (!c || !vars || !tensors || !state || nvars < 1 || nvars > 12 || S < 1) return fail(c, SPMF_E_ARG,
+      "surrogate_bwd_adam_dev: bad arguments");
+  SurTable T;
+  AdamTable A;
+  int max_n = 0;
+  for (int i = 0; i < nvars; ++i) {
+    const spmf_sur_var& v = vars[i];
+    if (!v.t0 || !v.t1 || !v.noise || !v.gtheta || v.n < 1 || v.kind < 0 || v.kind > 2 || (v.kind == 2 && !v.dgda))
+      return fail(c, SPMF_E_ARG, "surrogate_bwd_adam_dev: bad variable");
+    if (v.noise_ld != 0 && v.noise_ld < v.n) return fail(c, SPMF_E_ARG, "surrogate: noise_ld < n");
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, nullptr, nullptr, v.n, v.kind, v.ident,
+        v.noise_ld ? v.noise_ld : (int64_t)v.n};
+    if (v.n > max_n) max_n = v.n;
+    // tensors[2i], tensors[2i+1]: the Adam records of this variable's t0 / t1
+    for (int j = 0; j < 2; ++j) {
+      const spmf_adam_var& a = tensors[2 * i + j];
+      if (!a.p || !a.m || !a.v || a.n != v.n || a.p != (j ? v.t1 : v.t0)) return fail(c, SPMF_E_ARG,
+          "surrogate_bwd_adam_dev: tensors[2i+j] must be the Adam record (p, m, v, n) of vars[i].t{j}");
+      A.v[2 * i + j] = AdamVar{a.p, a.m, a.v, nullptr, a.n};
+    }
+  }
+  launch_surrogate_bwd_adam(T, A, nvars, max_n, S, (float)inv_sb, (float)cw, state, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;
 }

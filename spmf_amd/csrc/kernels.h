@@ -172,10 +172,13 @@ struct AdamVar {
 struct AdamTable {
   AdamVar v[24];
 };
-void launch_surrogate_fwd(const SurTable& T, int nvars, int max_n, int S, double* logq, hipStream_t st);
+void launch_surrogate_fwd(const SurTable& T, int nvars, int max_n, int S, double* logq, double* scratch,
+                          size_t scratch_doubles, hipStream_t st);
 void launch_sample_noise(const SurTable& T, int nvars, int max_n, int S, uint64_t seed, uint64_t counter,
                          const double* state, hipStream_t st);
 void launch_surrogate_bwd(const SurTable& T, int nvars, int max_n, int S, float inv_sb, float c, hipStream_t st);
+void launch_surrogate_bwd_adam(const SurTable& T, const AdamTable& A, int nvars, int max_n, int S, float inv_sb,
+                               float c, const double* state, hipStream_t st);
 void launch_vi_gate(const double* parts, const double* logq, const double* nnf, int S, double c, double rows, double* state, hipStream_t st);
 void launch_adam_dev(const AdamTable& T, int ntensors, int max_n, const double* state, hipStream_t st);
 void launch_adam(const AdamTable& T, int ntensors, int max_n, float lr, float b1, float b2, float eps, float c1, float c2, float clip, hipStream_t st);

@@ -56,12 +56,23 @@ __device__ __forceinline__ float digammaf_(float x) {
 #endif
 constexpr int kEPT = SPMF_EPT;
 
+// logq: with `lqpart` every block stores its sum per draw in its own slot
+// (lqpart[s][block]) and logq_reduce_kernel adds the slots in a fixed order -- no
+// same-address fp64 atomics (1300 of them at C3 sizes, ~13 ns each, serialised)
+// and a result that is bit-identical from run to run; without it (scratch too
+// small for S * blocks) the blocks add to logq[s] atomically.
 __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
-                                                            double* __restrict__ logq) {
+                                                            double* __restrict__ logq,
+                                                            double* __restrict__ lqpart) {
   __shared__ double red[16];
   const SurVar v = T.v[blockIdx.y];
   const int base = blockIdx.x * (256 * kEPT);
-  if (base >= v.n) return;   // block-uniform
+  const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (base >= v.n) {          // block-uniform
+    if (lqpart && threadIdx.x == 0)
+      for (int s = 0; s < S; ++s) lqpart[(size_t)s * nblk + blk] = 0.0;
+    return;
+  }
   // per-element quantities that do not depend on the draw (softplus, lgamma, logs are the
   // expensive part): once, not once per draw
   float c0[kEPT], c1[kEPT], c2[kEPT];
@@ -114,13 +125,67 @@ __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
       }
     }
     const double tot = block_sum(lq, red);
-    if (threadIdx.x == 0) atomicAdd(&logq[s], tot);
+    if (threadIdx.x == 0) {
+      if (lqpart) lqpart[(size_t)s * nblk + blk] = tot;
+      else atomicAdd(&logq[s], tot);
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void logq_reduce_kernel(int nblk, const double* __restrict__ lqpart,
+                                                          double* __restrict__ logq) {
+  __shared__ double red[16];
+  const double* p = lqpart + (size_t)blockIdx.x * nblk;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += p[b];
+  const double tot = block_sum(s, red);
+  if (threadIdx.x == 0) logq[blockIdx.x] = tot;
 }
 
 // (one element per thread measured faster here: 30 us vs 46 us at 8 -- the body is
 // transcendental-heavy, parallelism matters more than block count)
 constexpr int kEPTB = 1;
+
+// d loss / d(t0, t1) of element i, summed over the S draws
+__device__ __forceinline__ void sur_bwd_elem(const SurVar& v, int i, int S, float inv_sb, float c,
+                                             float& g0, float& g1) {
+  g0 = 0.f;
+  g1 = 0.f;
+  const float t0 = v.t0[i], t1 = v.t1[i];
+  if (v.kind == 2) {
+    const float a = softplusf(t0), b = softplusf(t1);
+    const float lb = logf(b), dga = digammaf_(a);
+    for (int s = 0; s < S; ++s) {
+      const size_t o = (size_t)s * v.n + i, on = (size_t)s * v.ld + i;
+      const float g = v.noise[on], dgda = v.dgda[on], ge = v.gtheta[o];
+      const float y = b / g, sig = sigmoidf_(y);
+      const float dlq_dy = -(a + 1.f) / y + b / (y * y) - (1.f - sig);
+      const float dL_dy = inv_sb * (-ge * sig + c * dlq_dy);
+      const float dy_da = -b / (g * g) * dgda, dy_db = 1.f / g;
+      g0 += dL_dy * dy_da + inv_sb * c * (lb - dga - logf(y));
+      g1 += dL_dy * dy_db + inv_sb * c * (a / b - 1.f / y);
+    }
+    g0 *= sigmoidf_(t0);
+    g1 *= sigmoidf_(t1);
+  } else {
+    const float sg = softplusf(t1);
+    const bool ident = v.kind != 0 || (v.ident && v.ident[i]);
+    for (int s = 0; s < S; ++s) {
+      const size_t o = (size_t)s * v.n + i, on = (size_t)s * v.ld + i;
+      const float eps = v.noise[on], ge = v.gtheta[o];
+      const float y = t0 + sg * eps;
+      float dth = 1.f, dlq_dy = 0.f;
+      if (!ident) {
+        dth = sigmoidf_(y);
+        dlq_dy = -(1.f - dth);
+      }
+      const float dL_dy = inv_sb * (-ge * dth + c * dlq_dy);
+      g0 += dL_dy;
+      g1 += dL_dy * eps - inv_sb * c / sg;
+    }
+    g1 *= sigmoidf_(t1);
+  }
+}
 
 __global__ __launch_bounds__(256) void surrogate_bwd_kernel(SurTable T, int S, float inv_sb,
                                                             float c) {
@@ -133,45 +198,8 @@ __global__ __launch_bounds__(256) void surrogate_bwd_kernel(SurTable T, int S, f
 #pragma unroll
   for (int e = 0; e < kEPTB; ++e) {
     const int i = base + e * 256 + threadIdx.x;
-    float g0 = 0.f, g1 = 0.f;
-    if (i < v.n) {
-      const float t0 = v.t0[i], t1 = v.t1[i];
-      if (v.kind == 2) {
-        const float a = softplusf(t0), b = softplusf(t1);
-        const float lb = logf(b), dga = digammaf_(a);
-        for (int s = 0; s < S; ++s) {
-          const size_t o = (size_t)s * v.n + i, on = (size_t)s * v.ld + i;
-          const float g = v.noise[on], dgda = v.dgda[on], ge = v.gtheta[o];
-          const float y = b / g, sig = sigmoidf_(y);
-          const float dlq_dy = -(a + 1.f) / y + b / (y * y) - (1.f - sig);
-          const float dL_dy = inv_sb * (-ge * sig + c * dlq_dy);
-          const float dy_da = -b / (g * g) * dgda, dy_db = 1.f / g;
-          g0 += dL_dy * dy_da + inv_sb * c * (lb - dga - logf(y));
-          g1 += dL_dy * dy_db + inv_sb * c * (a / b - 1.f / y);
-        }
-        g0 *= sigmoidf_(t0);
-        g1 *= sigmoidf_(t1);
-      } else {
-        const float sg = softplusf(t1);
-        const bool ident = v.kind != 0 || (v.ident && v.ident[i]);
-        for (int s = 0; s < S; ++s) {
-          const size_t o = (size_t)s * v.n + i, on = (size_t)s * v.ld + i;
-          const float eps = v.noise[on], ge = v.gtheta[o];
-          const float y = t0 + sg * eps;
-          float dth = 1.f, dlq_dy = 0.f;
-          if (!ident) {
-            dth = sigmoidf_(y);
-            dlq_dy = -(1.f - dth);
-          }
-          const float dL_dy = inv_sb * (-ge * dth + c * dlq_dy);
-          g0 += dL_dy;
-          g1 += dL_dy * eps - inv_sb * c / sg;
-        }
-        g1 *= sigmoidf_(t1);
-      }
-    }
-    o0[e] = g0;
-    o1[e] = g1;
+    o0[e] = o1[e] = 0.f;
+    if (i < v.n) sur_bwd_elem(v, i, S, inv_sb, c, o0[e], o1[e]);
   }
 #pragma unroll
   for (int e = 0; e < kEPTB; ++e) {
@@ -290,13 +318,23 @@ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5
 __device__ __forceinline__ float normal_bm(uint32_t a, uint32_t b) {
   return sqrtf(-2.f * logf(u01(a))) * cospif(2.f * u01(b));
 }
+// fp64 reciprocal: v_rcp_f32 seed + two Newton steps (|rel err| ~ 1e-15 for the ranges used)
+__device__ __forceinline__ double rcpd_(double d) {
+  double rc = (double)__builtin_amdgcn_rcpf((float)d);
+  rc = rc * (2.0 - d * rc);
+  return rc * (2.0 - d * rc);
+}
 __device__ __forceinline__ double digammad_(double x) {
-  double r = 0.0;
+  // recurrence psi(x) = psi(x+m) - sum_{j<m} 1/(x+j): the sum as ONE fraction num/den
+  // (den = prod (x+j) <= 8^8), so one reciprocal instead of up to eight fp64 divisions
+  double num = 0.0, den = 1.0;
   while (x < 8.0) {
-    r -= 1.0 / x;
+    num = num * x + den;
+    den *= x;
     x += 1.0;
   }
-  const double i = 1.0 / x, i2 = i * i;
+  const double r = -num * rcpd_(den);
+  const double i = rcpd_(x), i2 = i * i;
   return r + log(x) - 0.5 * i - i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0))));
 }
 // d g / d a of g ~ Gamma(a, 1) at the drawn value (implicit reparameterisation)
@@ -312,11 +350,8 @@ __device__ __forceinline__ float gamma_dgda(double a, double x) {
   for (int n = 0; n < 4000; ++n) {
     const double term = R * (lx - psi);
     acc += term;
-    if ((double)n > x && fabs(term) < 1e-12 * fabs(acc) + 1e-300) break;
-    const double d = a + (double)(n + 1);
-    double rc = (double)__builtin_amdgcn_rcpf((float)d);
-    rc = rc * (2.0 - d * rc);
-    rc = rc * (2.0 - d * rc);
+    if ((double)n > x && fabs(term) < 1e-10 * fabs(acc) + 1e-300) break;   // the result is stored as fp32
+    const double rc = rcpd_(a + (double)(n + 1));
     psi += rc;
     R *= x * rc;
   }
@@ -404,6 +439,35 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(AdamTable T, const double
              (float)(1.0 - state[5]), (float)(1.0 - state[6]), (float)state[4]);
 }
 
+// Chain rule and gated Adam in one pass: the gradient of a trainable pair never goes
+// to memory (the separate kernels move 21 floats per element, this one 16).  A.v[2*var],
+// A.v[2*var+1] are the Adam records of variable var's t0 / t1 (p aliases T's t0 / t1).
+__global__ __launch_bounds__(256) void surrogate_bwd_adam_kernel(SurTable T, AdamTable A, int S,
+                                                                 float inv_sb, float c,
+                                                                 const double* __restrict__ state) {
+  if (state[9] == 0.0) return;                              // step skipped
+  const SurVar v = T.v[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= v.n) return;
+  float g0, g1;
+  sur_bwd_elem(v, i, S, inv_sb, c, g0, g1);
+  const float lr = (float)state[0], b1 = (float)state[1], b2 = (float)state[2], eps = (float)state[3];
+  const float c1 = (float)(1.0 - state[5]), c2 = (float)(1.0 - state[6]), clip = (float)state[4];
+  const AdamVar& a0 = A.v[2 * blockIdx.y];
+  const AdamVar& a1 = A.v[2 * blockIdx.y + 1];
+  float m0 = a0.m[i], v0 = a0.v[i], m1 = a1.m[i], v1 = a1.v[i];
+  const float p0 = adam_elem(m0, v0, a0.p[i], g0, lr, b1, b2, eps, c1, c2, clip);
+  const float p1 = adam_elem(m1, v1, a1.p[i], g1, lr, b1, b2, eps, c1, c2, clip);
+  a0.m[i] = m0; a0.v[i] = v0; a0.p[i] = p0;
+  a1.m[i] = m1; a1.v[i] = v1; a1.p[i] = p1;
+}
+
+void launch_surrogate_bwd_adam(const SurTable& T, const AdamTable& A, int nvars, int max_n, int S,
+                               float inv_sb, float c, const double* state, hipStream_t st) {
+  dim3 grid((max_n + 255) / 256, nvars);
+  hipLaunchKernelGGL(surrogate_bwd_adam_kernel, grid, dim3(256), 0, st, T, A, S, inv_sb, c, state);
+}
+
 void launch_vi_gate(const double* parts, const double* logq, const double* nnf, int S, double c,
                     double rows, double* state, hipStream_t st) {
   hipLaunchKernelGGL(vi_gate_kernel, dim3(1), dim3(64), 0, st, parts, logq, nnf, S, c, rows, state);
@@ -414,9 +478,16 @@ void launch_adam_dev(const AdamTable& T, int ntensors, int max_n, const double* 
 }
 
 void launch_surrogate_fwd(const SurTable& T, int nvars, int max_n, int S, double* logq,
-                          hipStream_t st) {
+                          double* scratch, size_t scratch_doubles, hipStream_t st) {
   dim3 grid((max_n + 256 * kEPT - 1) / (256 * kEPT), nvars);
-  hipLaunchKernelGGL(surrogate_fwd_kernel, grid, dim3(256), 0, st, T, S, logq);
+  const size_t nblk = (size_t)grid.x * grid.y;
+  if (scratch && nblk * (size_t)S <= scratch_doubles) {
+    hipLaunchKernelGGL(surrogate_fwd_kernel, grid, dim3(256), 0, st, T, S, logq, scratch);
+    hipLaunchKernelGGL(logq_reduce_kernel, dim3(S), dim3(256), 0, st, (int)nblk, scratch, logq);
+    return;
+  }
+  launch_zero(logq, (size_t)S * sizeof(double), st);
+  hipLaunchKernelGGL(surrogate_fwd_kernel, grid, dim3(256), 0, st, T, S, logq, (double*)nullptr);
 }
 void launch_surrogate_bwd(const SurTable& T, int nvars, int max_n, int S, float inv_sb, float c,
                           hipStream_t st) {

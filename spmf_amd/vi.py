@@ -207,6 +207,25 @@ class Surrogate:
                                              stream), "spmf_surrogate_bwd")
         return grads
 
+    @torch.no_grad()
+    def backward_adam_hip(self, model, S, noise, gtheta, inv_sb, c, opt):
+        """backward_hip + AdamHIP.step_dev fused (spmf_surrogate_bwd_adam_dev): the
+        step path of the training loop, gated by the optimiser's device state."""
+        lib, h = _lib.load(), model._handle()
+        if opt.params is not self.trainable_variables and any(
+                a is not b for a, b in zip(opt.params, self.trainable_variables)):
+            raise ValueError("the optimiser must own the surrogate's trainables, in order")
+        gt = {n: gtheta[n].contiguous() for n in self.var_order}
+        arr = self._table(S, noise, gtheta=gt)
+        av = (_lib.AdamVar * len(opt.params))()
+        for i, (p, m, v) in enumerate(zip(opt.params, opt.m, opt.v)):
+            a = av[i]
+            a.p, a.m, a.v, a.g, a.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), None, p.numel()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(h, lib.spmf_surrogate_bwd_adam_dev(
+            h, arr, len(self.var_order), S, float(inv_sb), float(c), av, opt.state.data_ptr(),
+            stream), "spmf_surrogate_bwd_adam_dev")
+
     def _model(self):
         m = self._model_ref() if self._model_ref is not None else None
         if m is None:
@@ -355,6 +374,10 @@ def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=No
     _lib.check(h, lib.spmf_vi_gate(h, model._last_parts.data_ptr(), logq.data_ptr(),
                                    nnf.data_ptr(), S, c, float(B), opt.state.data_ptr(), stream),
                "spmf_vi_gate")
+    if keep is None:
+        # chain rule + gated Adam in one pass (the gradient never goes to memory)
+        sur.backward_adam_hip(model, S, noise, g, 1.0 / (S * B), c, opt)
+        return
     grads = sur.backward_hip(model, S, noise, g, 1.0 / (S * B), c)
     opt.step_dev(grads)
     if keep is not None:

@@ -303,6 +303,29 @@ def test_device_gated_step_equals_host_driven_step():
         assert (p.detach() - q.detach()).abs().max() <= 1e-6 * max(1.0, float(p.detach().abs().max()))
 
 
+def test_fused_chain_rule_adam_equals_the_two_separate_kernels():
+    """spmf_surrogate_bwd_adam_dev (the step path) against spmf_surrogate_bwd +
+    spmf_adam_step_dev (the keep= path): trainables AND both Adam moments after three
+    steps on the same Philox key."""
+    from spmf_amd.vi import AdamHIP, vi_step_dev
+    X = _data(300, 18)
+    N = X.shape[0]
+    batch = {"counts": X}
+    a, b = _fresh_model(X), _fresh_model(X)
+    oa = AdamHIP(a, a.surrogate_distribution.trainable_variables, 0.05)
+    ob = AdamHIP(b, b.surrogate_distribution.trainable_variables, 0.05)
+    oa.init_state(clip_value=3.0)
+    ob.init_state(clip_value=3.0)
+    for step in range(3):
+        vi_step_dev(a, oa, batch, N, 2, seed=1234)              # fused
+        vi_step_dev(b, ob, batch, N, 2, keep={}, seed=1234)     # separate kernels
+    assert oa.read_state()[7] == ob.read_state()[7] == 3
+    for name, xs, ys in (("p", oa.params, ob.params), ("m", oa.m, ob.m), ("v", oa.v, ob.v)):
+        for x, y in zip(xs, ys):
+            x, y = x.detach(), y.detach()
+            assert (x - y).abs().max() <= 2e-6 * max(float(y.abs().max()), 1e-30), name
+
+
 def test_device_gate_skips_non_finite_step():
     from spmf_amd.vi import AdamHIP, vi_step_dev
     X = _data(200, 12)
