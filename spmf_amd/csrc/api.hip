@@ -54,7 +54,7 @@ struct spmf_ctx {
   // the library's only device allocation: a small scratch for per-block partial sums of the
   // O(D*K) surrogate kernels (fixed-order reductions instead of same-address atomics)
   double* scratch = nullptr;
-  static constexpr size_t kScratchDoubles = 1u << 18;   // 2 MiB
+  static constexpr size_t kScratchDoubles = 1u << 20;   // 8 MiB
   void* comm = nullptr;           // ncclComm_t of the row-shard collective (spmf_comm_init)
   int comm_rank = 0, comm_world = 1;
   std::string err;

@@ -61,12 +61,17 @@ constexpr int kEPT = SPMF_EPT;
 // same-address fp64 atomics (1300 of them at C3 sizes, ~13 ns each, serialised)
 // and a result that is bit-identical from run to run; without it (scratch too
 // small for S * blocks) the blocks add to logq[s] atomically.
+#ifndef SPMF_EPTF
+#define SPMF_EPTF 4
+#endif
+constexpr int kEPTF = SPMF_EPTF;   // elements per thread of surrogate_fwd_kernel
+
 __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
                                                             double* __restrict__ logq,
                                                             double* __restrict__ lqpart) {
   __shared__ double red[16];
   const SurVar v = T.v[blockIdx.y];
-  const int base = blockIdx.x * (256 * kEPT);
+  const int base = blockIdx.x * (256 * kEPTF);
   const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (base >= v.n) {          // block-uniform
     if (lqpart && threadIdx.x == 0)
@@ -75,10 +80,10 @@ __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
   }
   // per-element quantities that do not depend on the draw (softplus, lgamma, logs are the
   // expensive part): once, not once per draw
-  float c0[kEPT], c1[kEPT], c2[kEPT];
-  bool soft[kEPT];
+  float c0[kEPTF], c1[kEPTF], c2[kEPTF];
+  bool soft[kEPTF];
 #pragma unroll
-  for (int e = 0; e < kEPT; ++e) {
+  for (int e = 0; e < kEPTF; ++e) {
     const int i = base + e * 256 + threadIdx.x;
     c0[e] = c1[e] = c2[e] = 0.f;
     soft[e] = false;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void surrogate_fwd_kernel(SurTable T, int S,
     const float* __restrict__ nzp = v.noise + (size_t)s * v.ld;
     float* __restrict__ thp = v.theta + (size_t)s * v.n;
 #pragma unroll
-    for (int e = 0; e < kEPT; ++e) {
+    for (int e = 0; e < kEPTF; ++e) {
       const int i = base + e * 256 + threadIdx.x;
       if (i < v.n) {
         const float nz = nzp[i];
@@ -479,7 +484,7 @@ void launch_adam_dev(const AdamTable& T, int ntensors, int max_n, const double* 
 
 void launch_surrogate_fwd(const SurTable& T, int nvars, int max_n, int S, double* logq,
                           double* scratch, size_t scratch_doubles, hipStream_t st) {
-  dim3 grid((max_n + 256 * kEPT - 1) / (256 * kEPT), nvars);
+  dim3 grid((max_n + 256 * kEPTF - 1) / (256 * kEPTF), nvars);
   const size_t nblk = (size_t)grid.x * grid.y;
   if (scratch && nblk * (size_t)S <= scratch_doubles) {
     hipLaunchKernelGGL(surrogate_fwd_kernel, grid, dim3(256), 0, st, T, S, logq, scratch);
