@@ -53,6 +53,12 @@ struct spmf_ctx {
   const double* prior_parts = nullptr;
   // the library's only device allocation: a small scratch for per-block partial sums of the
   // O(D*K) surrogate kernels (fixed-order reductions instead of same-address atomics)
+  // log_transform: E = exp(<z_b, W_d>) is computed once and kept for the second contraction
+  // (dense.hip, estdot_kernel), in row chunks of at most kEstCapBytes
+  float* est = nullptr;
+  int64_t est_rows = 0;           // rows per chunk of the bound workspace
+  int e_once = 1;                 // SPMF_DENSE_E_ONCE=0: recompute E in a second launch instead
+  static constexpr size_t kEstCapBytes = (size_t)8 << 30;
   double* scratch = nullptr;
   static constexpr size_t kScratchDoubles = 1u << 20;   // 8 MiB
   void* comm = nullptr;           // ncclComm_t of the row-shard collective (spmf_comm_init)
@@ -131,7 +137,7 @@ static size_t var_size(const spmf_ctx* c, int i) {
 }
 
 struct Carve {
-  size_t acc, dacc, dprep, ppart, putau, Ap, Vp, phi, dbias, Vb, bb, z, gzs, gzd, total;
+  size_t acc, dacc, dprep, ppart, putau, Ap, Vp, phi, dbias, Vb, bb, z, gzs, gzd, est, total;
 };
 // Small batches run all S draws in ONE launch per kernel (gridDim.y = S): the per-draw tables and
 // row outputs then exist S times.  Only for the linear Poisson decoder, only while the S table
@@ -142,6 +148,14 @@ static bool batched_draws(const spmf_ctx* c, int64_t rows, int S) {
   const size_t tables = (size_t)S * 2 * c->D * c->KP * sizeof(float);
   const size_t rowbuf = (size_t)S * 2 * (size_t)rows * c->KP * sizeof(float);
   return tables <= (3u << 20) && rowbuf <= (256u << 20);
+}
+
+// rows of one E chunk: whole 128-row workgroups of the exp kernel, at most kEstCapBytes
+static int64_t est_chunk_rows(const spmf_ctx* c, int64_t rows) {
+  const size_t per_row = (size_t)((c->D + 31) / 32) * 32 * sizeof(float);
+  int64_t cap = (int64_t)(spmf_ctx::kEstCapBytes / per_row) / 128 * 128;
+  if (cap < 128) cap = 128;
+  return rows < cap ? rows : cap;
 }
 
 static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
@@ -164,6 +178,9 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.z = o;     o += al(nd * (size_t)rows * KP * sizeof(float));
   k.gzs = o;   o += al(nd * (size_t)rows * KP * sizeof(float));
   k.gzd = o;   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) o += al((size_t)rows * KP * sizeof(float));
+  k.est = o;
+  if ((c->flags & SPMF_FLAG_LOG_TRANSFORM) && c->e_once)
+    o += al((size_t)((D + 31) / 32) * 32 * (size_t)est_chunk_rows(c, rows) * sizeof(float));
   k.total = o;
   return k;
 }
@@ -192,6 +209,7 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
     return SPMF_E_UNSUPPORTED;   // Bernoulli with the exp decoder is not built
   }
   c->flags = flags;
+  if (const char* e = getenv("SPMF_DENSE_E_ONCE")) c->e_once = e[0] != '0';
   *out = c;
   return SPMF_OK;
 }
@@ -279,6 +297,8 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   c->z = (float*)(c->ws + k.z);
   c->gzs = (float*)(c->ws + k.gzs);
   c->gzd = (float*)(c->ws + k.gzd);
+  c->est = ((c->flags & SPMF_FLAG_LOG_TRANSFORM) && c->e_once) ? (float*)(c->ws + k.est) : nullptr;
+  c->est_rows = est_chunk_rows(c, rows);
   c->ws_rows = rows;
   c->ws_S = S;
   c->batched = batched_draws(c, rows, S) ? 1 : 0;
@@ -444,6 +464,22 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         lbias = c->bb;
         orows = c->bcols;
       }
+      if (act == 0 && c->est) {
+        // E once: per row chunk, the Z-stationary exp kernel keeps E and the second
+        // contraction (gV'_d -= sum_b E_bd z_b) reads it back instead of recomputing it
+        // (chunks of equal size, whole 128-row workgroups: a short last chunk would run the
+        //  chip half empty)
+        const int64_t nch = (ct->n_rows + c->est_rows - 1) / c->est_rows;
+        int64_t step = ((ct->n_rows + nch - 1) / nch + 127) / 128 * 128;
+        if (step > c->est_rows) step = c->est_rows;
+        for (int64_t r0 = 0; r0 < ct->n_rows; r0 += step) {
+          const int nr = (int)((ct->n_rows - r0) < step ? (ct->n_rows - r0) : step);
+          ExpdotArgs ez{nr, Dd, c->z + (size_t)r0 * KP, Wd, c->gzd + (size_t)r0 * KP, 1.f, dacc + 3, 1, 0, 0,
+              nullptr, nullptr, nullptr, nullptr, c->est, (int64_t)nr};
+          launch_expdot(KP, ez, st);
+          launch_estdot(KP, Dd, nr, (int64_t)nr, c->est, c->z + (size_t)r0 * KP, gVp, -1.f, st);
+        }
+      } else {
       // Z-stationary: Q rows are columns d -> bias_q = phi (Bernoulli logits)
       ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, 1, 0, act, nullptr,
           act ? lbias : nullptr, nullptr, nullptr};
@@ -460,6 +496,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, chunks, 1, act, act ? lbias : nullptr,
           nullptr, act ? gphi_acc : nullptr, orows};
       launch_expdot(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+      }
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
       RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
           dacc, 2, logt, c->gzd, c->ctype, 1, D, dacc_stride};

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
                                                      const float* __restrict__ bias_p,
                                                      const float* __restrict__ bias_q,
                                                      float* __restrict__ out2,
-                                                     const int32_t* __restrict__ out_rows) {
+                                                     const int32_t* __restrict__ out_rows,
+                                                     float* __restrict__ est, int64_t ldE) {
   constexpr int PITCH = KD + 4;   // 16-B aligned rows; (KD+4) % 64 = 4 keeps b128 column reads conflict free
   constexpr int KH = KD / 2;      // lane half h covers k in [h*KH, (h+1)*KH): any k order is valid
                                   // as long as A and B agree, and this one makes A a contiguous read
@@ -267,6 +268,22 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
         }
       }
       es_tile += part;
+      // ---- E kept for the second contraction (estdot_kernel): 32-row Q tiles, P-major inside a
+      // tile: est[((q/32)*ldE + p)*32 + q%32]; a lane's four register runs are 16-B pieces of
+      // row p's 128-B line, which the lane pair (c, h=0/1) writes whole
+      if (ACT == 0 && est && q0 + sub * 32 < NQ) {     // (sub-tiles wholly past NQ have no E tile)
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+          const int p = p0 + b * 32 + c;
+          if (p < NP) {
+            float* dst = est + ((size_t)((q0 + sub * 32) >> 5) * (size_t)ldE + (size_t)p) * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(dst + 8 * g) =
+                  make_float4(xcur[b][4 * g + 0], xcur[b][4 * g + 1], xcur[b][4 * g + 2], xcur[b][4 * g + 3]);
+          }
+        }
+      }
       // ---- product 2: out^T[k][p] += sum_q Q[q][k] E[q][p] ---------------
 #pragma unroll
       for (int tt = 0; tt < 16; ++tt) {
@@ -341,6 +358,168 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
   }
 }
 
+// Second contraction of the exp terms from the STORED E (written by expdot_kernel, layout above):
+//   out[q][k] += sign * sum_p E[q][p] P[p][k]
+// E is computed once per step (6*B*D*K flop instead of 8) at the price of one write and one
+// read of B*D floats in HBM, which the 288 GB part has room for (chunked by the caller).
+// A wave owns IT = 2 tiles of 32 Q rows as the A operand rows (lane = q, read straight from
+// global memory: one step = the two adjacent 128-B lines of p = 2s, 2s+1), the P rows of a
+// round (32 of them) are staged in LDS as the B operand for all 8 waves; the accumulator has
+// q in its registers and k on the lane, so the epilogue writes 128-B rows.
+// Roofline: MFMA f32, 2*NQ*NP*KD flop; HBM NQ*NP*4 bytes (2.5 TB/s at the MFMA rate).
+template <int KD, int NW>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP, int64_t ldE,
+                                                                 const float* __restrict__ est,
+                                                                 const float* __restrict__ P,
+                                                                 float* __restrict__ out, float sign) {
+  constexpr int MT = KD / 32;
+  constexpr int IT = 2;
+  constexpr int RP = 32;                      // P rows per round
+  constexpr int ZP = KD == 64 ? 96 : 32;      // pitch % 64 == 32: the two lane halves (rows 2s, 2s+1) hit disjoint banks
+  constexpr int FOLD = 16;                    // rounds per fp32 run (two-level accumulation, as in expdot_kernel)
+  constexpr int NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) float zs[2][RP * ZP];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int qtiles = (NQ + 31) / 32;
+  const int qt0 = (blockIdx.x * NW + wid) * IT;
+  // P range of this block: gridDim.y chunks of whole rounds
+  const int rounds = (NP + RP - 1) / RP;
+  const int rpc = (rounds + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rpc, r1 = min(rounds, r0 + rpc);
+  f32x16 acc[IT][MT], tot[IT][MT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[it][m][i] = tot[it][m][i] = 0.f;
+  // stage loader: NT threads move RP*KD floats
+  constexpr int PER4 = (RP * KD / 4 + NT - 1) / NT;
+  float4 stage[PER4];
+  auto gload = [&](int r) {
+#pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+      const int e = (i * NT + t) * 4;
+      const int row = e / KD, k = e % KD;
+      const int p = r * RP + row;
+      stage[i] = (e < RP * KD && p < NP) ? *reinterpret_cast<const float4*>(P + (size_t)p * KD + k)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+      const int e = (i * NT + t) * 4;
+      const int row = e / KD, k = e % KD;
+      if (e < RP * KD) *reinterpret_cast<float4*>(&zs[buf][row * ZP + k]) = stage[i];
+    }
+  };
+  float a0[IT][16], a1[IT][16];
+  // A fragments of round r.  No predicates (a predicated load is a branch and a full wait each):
+  // a wave past the last Q tile reads the last tile (its results are dropped in the epilogue) and
+  // rows past NP are clamped to NP-1 -- their partners in LDS are zeros.  Whole rounds (all but
+  // possibly the last) use immediate offsets from one base address.
+  auto aload = [&](float (&dst)[IT][16], int r) {
+    const bool whole = (r + 1) * RP <= NP;                  // block-uniform
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int qt = min(qt0 + it, qtiles - 1);
+      const float* tile = est + (size_t)qt * (size_t)ldE * 32 + c;
+      if (whole) {
+        const float* base = tile + ((size_t)r * RP + h) * 32;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dst[it][s] = base[s * 64];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dst[it][s] = tile[(size_t)min(r * RP + 2 * s + h, NP - 1) * 32];
+      }
+    }
+  };
+  auto compute = [&](const float (&a)[IT][16], const float* zb) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      float bz[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) bz[m] = zb[(2 * s + h) * ZP + m * 32 + c];
+#pragma unroll
+      for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[it][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it][s], bz[m], acc[it][m], 0, 0, 0);
+    }
+  };
+  auto fold = [&]() {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          tot[it][m][i] += acc[it][m][i];
+          acc[it][m][i] = 0.f;
+        }
+  };
+  if (r0 < r1) {
+    gload(r0);
+    swrite(0);
+    aload(a0, r0);
+  }
+  __syncthreads();
+  // two rounds per trip: the A fragments ping-pong between two register sets (no copies)
+  for (int r = r0; r < r1; r += 2) {
+    const bool more1 = r + 1 < r1, more2 = r + 2 < r1;     // block-uniform
+    if (more1) {
+      gload(r + 1);
+      aload(a1, r + 1);
+    }
+    compute(a0, zs[0]);
+    if (more1) swrite(1);
+    __syncthreads();
+    if (more1) {
+      if (more2) {
+        gload(r + 2);
+        aload(a0, r + 2);
+      }
+      compute(a1, zs[1]);
+      if (more2) swrite(0);
+      __syncthreads();
+    }
+    if ((((r - r0) >> 1) % (FOLD / 2)) == FOLD / 2 - 1) fold();
+  }
+  // epilogue: register i of tile (it, m) is row q = 32*(qt0+it) + rho_h(i), lane c is feature m*32 + c
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    if (qt0 + it >= qtiles) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int q = (qt0 + it) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (q < NQ) atomicAdd(out + (size_t)q * KD + m * 32 + c, sign * (acc[it][m][i] + tot[it][m][i]));
+      }
+  }
+}
+
+#ifndef SPMF_ESTDOT_NW
+#define SPMF_ESTDOT_NW 8
+#endif
+void launch_estdot(int KD, int NQ, int NP, int64_t ldE, const float* est, const float* P, float* out, float sign,
+                   hipStream_t st) {
+  const int qtiles = (NQ + 31) / 32;
+  constexpr int NW = SPMF_ESTDOT_NW;
+  const int nbx = (qtiles + 2 * NW - 1) / (2 * NW);     // NW waves x 2 tiles per workgroup
+  const int rounds = (NP + 31) / 32;
+  int chunks = (768 * 8 / NW) / nbx;                    // 3 rounds of resident workgroups, no partial fourth
+  if (chunks > rounds) chunks = rounds;
+  if (chunks < 1) chunks = 1;
+  dim3 grid(nbx, chunks);
+  if (KD == 64)
+    hipLaunchKernelGGL((estdot_kernel<64, NW>), grid, dim3(NW * 64), 0, st, NQ, NP, ldE, est, P, out, sign);
+  else if (KD == 32)
+    hipLaunchKernelGGL((estdot_kernel<32, NW>), grid, dim3(NW * 64), 0, st, NQ, NP, ldE, est, P, out, sign);
+}
+
 // Mixed likelihood: the dense softplus/sigmoid sums run over the Bernoulli columns only.
 // Vb[j] = V'[cols[j]], bb[j] = phi[cols[j]] (one wave per 64 floats of a row).
 __global__ __launch_bounds__(256) void compact_rows_kernel(int n, int KD, const int32_t* __restrict__ cols,
@@ -371,7 +550,8 @@ void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st) {
   dim3 grid(nbx, chunks);
 #define SPMF_ED_LAUNCH(KD_, ACT_)                                                              \
   hipLaunchKernelGGL((expdot_kernel<KD_, ACT_>), grid, dim3(256), 0, st, a.NP, a.NQ, a.P, a.Q, \
-                     a.out, a.sign, a.esum, a.atomic_out, a.bias_p, a.bias_q, a.out2, a.out_rows)
+                     a.out, a.sign, a.esum, a.atomic_out, a.bias_p, a.bias_q, a.out2, a.out_rows,  \
+                     a.est, a.ldE)
   if (KD == 32 && a.act == 0) SPMF_ED_LAUNCH(32, 0);
   else if (KD == 32) SPMF_ED_LAUNCH(32, 1);
   else if (KD == 64 && a.act == 0) SPMF_ED_LAUNCH(64, 0);
