@@ -14,8 +14,9 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller (torch tensors on
- *    the Python side) unless marked "host"; the library allocates nothing on
- *    the device: the caller supplies the workspace (spmf_workspace_bytes).
+ *    the Python side) unless marked "host"; the caller supplies the workspace
+ *    (spmf_workspace_bytes); the library's only own device allocation is an
+ *    8 MiB scratch for the fixed-order reductions of the surrogate kernels.
  *  - all calls are asynchronous on the hipStream_t passed as `stream`
  *    (void* so the header needs no HIP include); one ctx per (process,
  *    device); calls on one ctx are stream-ordered and not re-entrant.
@@ -149,7 +150,11 @@ int spmf_ctx_set_column_types(spmf_ctx* ctx, const uint8_t* column_is_bernoulli)
 int spmf_ctx_set_bernoulli_columns(spmf_ctx* ctx, const int32_t* cols, int n);
 
 /* Bytes of caller-owned device workspace needed for batches of up to
- * max_rows rows and S draws. */
+ * max_rows rows and S draws.  With SPMF_FLAG_LOG_TRANSFORM this includes the
+ * buffer that keeps E = exp(<z_b, eta_d v_d>) between the two dense contractions
+ * (min(max_rows, chunk) * D floats, chunk chosen so that it stays <= 8 GiB; the
+ * environment variable SPMF_DENSE_E_ONCE=0, read at spmf_ctx_create, selects the
+ * form that recomputes E instead and needs no such buffer). */
 size_t spmf_workspace_bytes(const spmf_ctx* ctx, int64_t max_rows, int S);
 int spmf_ctx_set_workspace(spmf_ctx* ctx, void* workspace, size_t bytes);
 
