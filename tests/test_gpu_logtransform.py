@@ -57,6 +57,26 @@ def test_log_transform_energy_and_grads(B, D, K, S, density, scale_rows):
     np.testing.assert_allclose(z, zr, rtol=1e-5, atol=1e-5 * np.abs(zr).max())
 
 
+@pytest.mark.parametrize("B,D,K,S", [(300, 129, 64, 2), (260, 200, 32, 1)])
+def test_two_launch_form_still_matches_oracle(monkeypatch, B, D, K, S):
+    """SPMF_DENSE_E_ONCE=0 (read at spmf_ctx_create): the form that recomputes E in a second
+    exp launch instead of keeping it in HBM -- same oracle, same contract."""
+    from spmf_amd import PoissonFactorization
+    monkeypatch.setenv("SPMF_DENSE_E_ONCE", "0")
+    cfg, x, params = problem(B, D, K, S, 900 + B + K, 0.05)
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
+                             log_transform=True, column_norms=cfg.eta_i,
+                             initialize_distributions=False, device="cuda", panel_rows=64)
+    m.xi_u_global = cfg.xi_u_global
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    for k, r in pref.items():
+        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
+    for k, r in gref.items():
+        g = grads[k].cpu().double().numpy().reshape(r.shape)
+        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+
+
 def test_log_transform_randomised_sweep():
     from spmf_amd import PoissonFactorization
     rng = np.random.default_rng(77)
