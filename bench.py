@@ -379,13 +379,13 @@ def main():
                 "dense_expdot": ms5[5]}
         KD = max(32, K)
         # algorithmic count: 6*B*D*K -- X = Z W^T once, then the two gradient
-        # products.  log_transform executes exactly that (E is kept in HBM between the two
-        # contractions, SPMF_DENSE_E_ONCE); the Bernoulli form still forms X and sigmoid in
-        # both launches: 8*B*D*K executed
+        # products.  The kernels execute exactly that: E (exp, or the sigmoid of the Bernoulli
+        # logits) is kept in HBM between the two contractions; SPMF_DENSE_E_ONCE=0 selects the
+        # form that computes it in both launches (8*B*D*K executed)
         # (mixed likelihood: the dense sums run over the Bernoulli columns only)
         D_dense = int(mixed_mask.sum()) if mixed_mask is not None else D
         dense_flops = 6.0 * sc.n_rows * D_dense * KD
-        e_once = bool(logt) and os.environ.get("SPMF_DENSE_E_ONCE", "1")[:1] != "0"
+        e_once = os.environ.get("SPMF_DENSE_E_ONCE", "1")[:1] != "0"
         dense_flops_executed = (6.0 if e_once else 8.0) * sc.n_rows * D_dense * KD
         if (logt or mixed_mask is not None) and ms5[5] >= max(ms5[1], ms5[2]):
             dom = "dense_expdot"

@@ -150,8 +150,9 @@ int spmf_ctx_set_column_types(spmf_ctx* ctx, const uint8_t* column_is_bernoulli)
 int spmf_ctx_set_bernoulli_columns(spmf_ctx* ctx, const int32_t* cols, int n);
 
 /* Bytes of caller-owned device workspace needed for batches of up to
- * max_rows rows and S draws.  With SPMF_FLAG_LOG_TRANSFORM this includes the
- * buffer that keeps E = exp(<z_b, eta_d v_d>) between the two dense contractions
+ * max_rows rows and S draws.  With SPMF_FLAG_LOG_TRANSFORM / BERNOULLI / MIXED this
+ * includes the buffer that keeps E = exp(<z_b, eta_d v_d>) (or the sigmoid of the
+ * Bernoulli logits) between the two dense contractions
  * (min(max_rows, chunk) * D floats, chunk chosen so that it stays <= 8 GiB; the
  * environment variable SPMF_DENSE_E_ONCE=0, read at spmf_ctx_create, selects the
  * form that recomputes E instead and needs no such buffer). */

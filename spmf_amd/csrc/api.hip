@@ -179,7 +179,7 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.gzs = o;   o += al(nd * (size_t)rows * KP * sizeof(float));
   k.gzd = o;   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) o += al((size_t)rows * KP * sizeof(float));
   k.est = o;
-  if ((c->flags & SPMF_FLAG_LOG_TRANSFORM) && c->e_once)
+  if ((c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once)
     o += al((size_t)((D + 31) / 32) * 32 * (size_t)est_chunk_rows(c, rows) * sizeof(float));
   k.total = o;
   return k;
@@ -297,7 +297,8 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   c->z = (float*)(c->ws + k.z);
   c->gzs = (float*)(c->ws + k.gzs);
   c->gzd = (float*)(c->ws + k.gzd);
-  c->est = ((c->flags & SPMF_FLAG_LOG_TRANSFORM) && c->e_once) ? (float*)(c->ws + k.est) : nullptr;
+  c->est = ((c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once)
+               ? (float*)(c->ws + k.est) : nullptr;
   c->est_rows = est_chunk_rows(c, rows);
   c->ws_rows = rows;
   c->ws_S = S;
@@ -464,9 +465,10 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         lbias = c->bb;
         orows = c->bcols;
       }
-      if (act == 0 && c->est) {
-        // E once: per row chunk, the Z-stationary exp kernel keeps E and the second
-        // contraction (gV'_d -= sum_b E_bd z_b) reads it back instead of recomputing it
+      if (c->est) {
+        // E once: per row chunk, the Z-stationary kernel keeps E (exp, or the sigmoid of the
+        // Bernoulli logits) and the second contraction (gV'_d -= sum_b E_bd z_b; Bernoulli:
+        // gphi_d -= sum_b E_bd too) reads it back instead of recomputing it
         // (chunks of equal size, whole 128-row workgroups: a short last chunk would run the
         //  chip half empty)
         const int64_t nch = (ct->n_rows + c->est_rows - 1) / c->est_rows;
@@ -474,10 +476,11 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         if (step > c->est_rows) step = c->est_rows;
         for (int64_t r0 = 0; r0 < ct->n_rows; r0 += step) {
           const int nr = (int)((ct->n_rows - r0) < step ? (ct->n_rows - r0) : step);
-          ExpdotArgs ez{nr, Dd, c->z + (size_t)r0 * KP, Wd, c->gzd + (size_t)r0 * KP, 1.f, dacc + 3, 1, 0, 0,
-              nullptr, nullptr, nullptr, nullptr, c->est, (int64_t)nr};
+          ExpdotArgs ez{nr, Dd, c->z + (size_t)r0 * KP, Wd, c->gzd + (size_t)r0 * KP, 1.f, dacc + 3, 1, 0, act,
+              nullptr, act ? lbias : nullptr, nullptr, nullptr, c->est, (int64_t)nr};
           launch_expdot(KP, ez, st);
-          launch_estdot(KP, Dd, nr, (int64_t)nr, c->est, c->z + (size_t)r0 * KP, gVp, -1.f, st);
+          launch_estdot(KP, Dd, nr, (int64_t)nr, c->est, c->z + (size_t)r0 * KP, gVp, -1.f,
+                        act ? gphi_acc : nullptr, orows, st);
         }
       } else {
       // Z-stationary: Q rows are columns d -> bias_q = phi (Bernoulli logits)

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
       // ---- E kept for the second contraction (estdot_kernel): 32-row Q tiles, P-major inside a
       // tile: est[((q/32)*ldE + p)*32 + q%32]; a lane's four register runs are 16-B pieces of
       // row p's 128-B line, which the lane pair (c, h=0/1) writes whole
-      if (ACT == 0 && est && q0 + sub * 32 < NQ) {     // (sub-tiles wholly past NQ have no E tile)
+      if (est && q0 + sub * 32 < NQ) {     // (sub-tiles wholly past NQ have no E tile)
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
           const int p = p0 + b * 32 + c;
@@ -371,7 +371,11 @@ template <int KD, int NW>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP, int64_t ldE,
                                                                  const float* __restrict__ est,
                                                                  const float* __restrict__ P,
-                                                                 float* __restrict__ out, float sign) {
+                                                                 float* __restrict__ out, float sign,
+                                                                 float* __restrict__ out2,
+                                                                 const int32_t* __restrict__ out_rows) {
+  // out2 (Bernoulli: d/dphi): out2[q] += sign * sum_p E[q][p]; out_rows: Q is a compacted
+  // subset of the output rows (mixed likelihood)
   constexpr int MT = KD / 32;
   constexpr int IT = 2;
   constexpr int RP = 32;                      // P rows per round
@@ -388,12 +392,15 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
   const int rpc = (rounds + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rpc, r1 = min(rounds, r0 + rpc);
   f32x16 acc[IT][MT], tot[IT][MT];
+  float rs[IT], rst[IT];            // row sums of E (two-level like the accumulators), out2 only
 #pragma unroll
-  for (int it = 0; it < IT; ++it)
+  for (int it = 0; it < IT; ++it) {
+    rs[it] = rst[it] = 0.f;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[it][m][i] = tot[it][m][i] = 0.f;
+  }
   // stage loader: NT threads move RP*KD floats
   constexpr int PER4 = (RP * KD / 4 + NT - 1) / NT;
   float4 stage[PER4];
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
       }
     }
   };
-  auto compute = [&](const float (&a)[IT][16], const float* zb) {
+  auto compute = [&](const float (&a)[IT][16], const float* zb, int r) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       float bz[MT];
@@ -448,8 +455,21 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
         for (int m = 0; m < MT; ++m)
           acc[it][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it][s], bz[m], acc[it][m], 0, 0, 0);
     }
+    if (out2) {                                  // block-uniform
+      // (rows past NP were read clamped to NP-1: zero partners in the product, but not here)
+      const int nv = NP - r * RP;
+#pragma unroll
+      for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) rs[it] += (2 * s + h < nv) ? a[it][s] : 0.f;
+    }
   };
   auto fold = [&]() {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      rst[it] += rs[it];
+      rs[it] = 0.f;
+    }
 #pragma unroll
     for (int it = 0; it < IT; ++it)
 #pragma unroll
@@ -473,7 +493,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
       gload(r + 1);
       aload(a1, r + 1);
     }
-    compute(a0, zs[0]);
+    compute(a0, zs[0], r);
     if (more1) swrite(1);
     __syncthreads();
     if (more1) {
@@ -481,7 +501,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
         gload(r + 2);
         aload(a0, r + 2);
       }
-      compute(a1, zs[1]);
+      compute(a1, zs[1], r + 1);
       if (more2) swrite(0);
       __syncthreads();
     }
@@ -496,8 +516,18 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int q = (qt0 + it) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (q < NQ) atomicAdd(out + (size_t)q * KD + m * 32 + c, sign * (acc[it][m][i] + tot[it][m][i]));
+        if (q < NQ) {
+          const int row = out_rows ? out_rows[q] : q;
+          atomicAdd(out + (size_t)row * KD + m * 32 + c, sign * (acc[it][m][i] + tot[it][m][i]));
+        }
       }
+    if (out2) {
+      // lane (c, h) summed E[q = 32*(qt0+it) + c][p of half h]
+      float r = rs[it] + rst[it];
+      r += __shfl_xor(r, 32);
+      const int q = (qt0 + it) * 32 + c;
+      if (h == 0 && q < NQ && r != 0.f) atomicAdd(&out2[out_rows ? out_rows[q] : q], sign * r);
+    }
   }
 }
 
@@ -505,7 +535,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
 #define SPMF_ESTDOT_NW 8
 #endif
 void launch_estdot(int KD, int NQ, int NP, int64_t ldE, const float* est, const float* P, float* out, float sign,
-                   hipStream_t st) {
+                   float* out2, const int32_t* out_rows, hipStream_t st) {
   const int qtiles = (NQ + 31) / 32;
   constexpr int NW = SPMF_ESTDOT_NW;
   const int nbx = (qtiles + 2 * NW - 1) / (2 * NW);     // NW waves x 2 tiles per workgroup
@@ -515,9 +545,11 @@ void launch_estdot(int KD, int NQ, int NP, int64_t ldE, const float* est, const 
   if (chunks < 1) chunks = 1;
   dim3 grid(nbx, chunks);
   if (KD == 64)
-    hipLaunchKernelGGL((estdot_kernel<64, NW>), grid, dim3(NW * 64), 0, st, NQ, NP, ldE, est, P, out, sign);
+    hipLaunchKernelGGL((estdot_kernel<64, NW>), grid, dim3(NW * 64), 0, st, NQ, NP, ldE, est, P, out, sign,
+                       out2, out_rows);
   else if (KD == 32)
-    hipLaunchKernelGGL((estdot_kernel<32, NW>), grid, dim3(NW * 64), 0, st, NQ, NP, ldE, est, P, out, sign);
+    hipLaunchKernelGGL((estdot_kernel<32, NW>), grid, dim3(NW * 64), 0, st, NQ, NP, ldE, est, P, out, sign,
+                       out2, out_rows);
 }
 
 // Mixed likelihood: the dense softplus/sigmoid sums run over the Bernoulli columns only.

@@ -72,12 +72,12 @@ struct ExpdotArgs {
   const float *bias_p, *bias_q;  // act 1: logit bias per P row / per Q row (one of them)
   float* out2;         // act 1: out2[p] += sign * sum_q sigmoid (may be null)
   const int32_t* out_rows;   // P is a compacted row subset: out / out2 rows to write (may be null)
-  float* est = nullptr;      // act 0: keep E for launch_estdot (layout: dense.hip), ldE = its P extent
+  float* est = nullptr;      // keep E (exp or sigmoid) for launch_estdot (layout: dense.hip), ldE = its P extent
   int64_t ldE = 0;
 };
 void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st);
 void launch_estdot(int KD, int NQ, int NP, int64_t ldE, const float* est, const float* P, float* out, float sign,
-                   hipStream_t st);
+                   float* out2, const int32_t* out_rows, hipStream_t st);
 void launch_compact_rows(int n, int KD, const int32_t* cols, const float* Vp, const float* phi, float* Vb,
                          float* bb, hipStream_t st);
 
