@@ -64,7 +64,8 @@ extern "C" {
 /* flags for spmf_ctx_create */
 #define SPMF_FLAG_SCALE_ROWS 1u     /* poisson.py:61,644-649 */
 #define SPMF_FLAG_BERNOULLI 4u      /* BernoulliFactorization (mederrata_spmf/bernoulli.py): Bernoulli(logits=rate)
-                                     * likelihood :147-155, Normal priors on v,w :187-216; linear decoder only */
+                                     * likelihood :147-155, Normal priors on v,w :187-216; with SPMF_FLAG_LOG_TRANSFORM
+                                     * the logit is exp(<z, eta v>) - 1 + phi (:60-61) */
 #define SPMF_FLAG_MIXED 8u          /* build-defined (mederrata_spmf/mixed.py is an empty file): per-column likelihood,
                                      * Bernoulli(logits) on the columns flagged by spmf_ctx_set_column_types, Poisson
                                      * on the others; linear decoder only */

@@ -8,7 +8,8 @@ Differences from PoissonFactorization, as in the reference:
 The stored-cell term x*logit is linear (sparse row/column passes without any
 division or log); the sum over ALL cells of softplus(logit) and its gradients
 run on the f32 matrix cores (dense.hip, sigmoid/softplus variant).
-Only the linear decoder is built (log_transform=True raises).  The dense
+Both decoders are built: with log_transform=True the logit is
+exp(<z, eta v>) - 1 + phi (:60-61) and g(x) = log(x/eta + 1) (:49-50).  The dense
 per-cell outputs of log_likelihood_components (:126-155) come from
 spmf_dense_ll (dense_ll.hip).
 """
@@ -36,15 +37,12 @@ class BernoulliFactorization(PoissonFactorization):
             log_transform=False, horshoe_plus=True, column_norms=None,
             count_key="counts", dtype=torch.float64, device=None,
             panel_rows=DEFAULT_PANEL_ROWS, **kwargs):
-        if log_transform:
-            raise NotImplementedError(
-                "BernoulliFactorization with log_transform=True is not built in the HIP path")
         super().__init__(
             latent_dim=latent_dim, feature_dim=feature_dim,
             u_tau_scale=u_tau_scale, s_tau_scale=s_tau_scale,
             symmetry_breaking_decay=symmetry_breaking_decay, strategy=strategy,
             encoder_function=encoder_function, decoder_function=decoder_function,
-            scale_columns=True, scale_rows=False, log_transform=False,
+            scale_columns=True, scale_rows=False, log_transform=log_transform,
             horshoe_plus=horshoe_plus, column_norms=column_norms, count_key=count_key,
             initialize_distributions=True, dtype=dtype, device=device,
             panel_rows=panel_rows, **kwargs)

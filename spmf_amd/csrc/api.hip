@@ -150,6 +150,13 @@ static bool batched_draws(const spmf_ctx* c, int64_t rows, int S) {
   return tables <= (3u << 20) && rowbuf <= (256u << 20);
 }
 
+static int likelihood_code(const spmf_ctx* c) {   // common.h: lik_exp / lik_bern
+  const bool lt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) != 0;
+  if (c->flags & SPMF_FLAG_BERNOULLI) return lt ? 4 : 2;
+  if (c->flags & SPMF_FLAG_MIXED) return 3;
+  return lt ? 1 : 0;
+}
+
 // rows of one E chunk: whole 128-row workgroups of the exp kernel, at most kEstCapBytes
 static int64_t est_chunk_rows(const spmf_ctx* c, int64_t rows) {
   const size_t per_row = (size_t)((c->D + 31) / 32) * 32 * sizeof(float);
@@ -204,9 +211,9 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   c->KP = padded_k(K);
   // the dense exp kernels of the log_transform decoder work on 32-feature MFMA tiles
   if ((flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->KP < 32) c->KP = 32;
-  if ((flags & SPMF_FLAG_LOG_TRANSFORM) && (flags & (SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED))) {
+  if ((flags & SPMF_FLAG_LOG_TRANSFORM) && (flags & SPMF_FLAG_MIXED)) {
     delete c;
-    return SPMF_E_UNSUPPORTED;   // Bernoulli with the exp decoder is not built
+    return SPMF_E_UNSUPPORTED;   // the per-column mix with the exp decoder is not built
   }
   c->flags = flags;
   if (const char* e = getenv("SPMF_DENSE_E_ONCE")) c->e_once = e[0] != '0';
@@ -392,11 +399,11 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
     const float* eta, int parts_mask, void* stream) {
   if (!c || !params || !eta || S < 1) return fail(c, SPMF_E_ARG, "data_pass: bad arguments");
   // likelihood / decoder code of the kernels: 0 Poisson linear, 1 Poisson log_transform, 2 Bernoulli
-  const int logt = (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : ((c->flags & SPMF_FLAG_MIXED) ? 3 : 0));
+  const int logt = likelihood_code(c);
   if (logt == 3 && !c->ctype) return fail(c, SPMF_E_ARG,
       "mixed likelihood: spmf_ctx_set_column_types was not called");
   int rc = check_counts(c, ct);
-  if (!rc && logt == 1 && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG,
+  if (!rc && lik_exp(logt) && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG,
       "counts: log_transform needs gval / pc_gval");
   if (rc) return rc;
   if (ct->n_rows > 0 && ct->nnz > 0 && (!ct->pc_row || !ct->pc_val || !ct->item_ptr || !ct->items || ct->n_panels < 1)) return fail(c, SPMF_E_ARG, "counts: panel-CSC arrays / work items missing");
@@ -433,7 +440,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
     if (first) {
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
     PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c,
-        1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, logt == 1 ? 1 : 0,
+        1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, lik_exp(logt) ? 1 : 0,
         logt == 3 ? c->ctype : nullptr, logt == 3 ? c->dbias : nullptr, nbat};
     launch_prep(KP, pa, st);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
@@ -445,11 +452,11 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
       // cores, then the stored-cell terms (sweep 2) with the dense row term.
-      RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, logt == 1 ? ct->gval : ct->val, rscale, c->Ap, c->Vp, c->phi,
+      RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, lik_exp(logt) ? ct->gval : ct->val, rscale, c->Ap, c->Vp, c->phi,
           dprep, c->z, c->gzs, dacc, 1, logt, nullptr, c->ctype, 1, D, dacc_stride};
       launch_row_pass(KP, r1, st);
       if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
-      const int act = logt >= 2 ? 1 : 0;
+      const int act = logt == 4 ? 2 : (logt >= 2 ? 1 : 0);   // dense.hip ACT
       const float* lbias = logt == 3 ? c->dbias : c->phi;   // mixed: -1e30 masks the Poisson columns
       float* gphi_acc = acc + L.gphi_off(0);
       // mixed likelihood with the Bernoulli column list set: the dense sums run over those
@@ -465,7 +472,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         lbias = c->bb;
         orows = c->bcols;
       }
-      if (c->est) {
+      if (c->est && act != 2) {   // (act 2: E carries exp(X) too, its row sums are not the d/dphi sums)
         // E once: per row chunk, the Z-stationary kernel keeps E (exp, or the sigmoid of the
         // Bernoulli logits) and the second contraction (gV'_d -= sum_b E_bd z_b; Bernoulli:
         // gphi_d -= sum_b E_bd too) reads it back instead of recomputing it
@@ -566,9 +573,6 @@ int spmf_acc_split(const spmf_ctx* c, int64_t off[2], int64_t len[2]) {
   return SPMF_OK;
 }
 
-static int likelihood_code(const spmf_ctx* c) {
-  return (c->flags & SPMF_FLAG_LOG_TRANSFORM) ? 1 : ((c->flags & SPMF_FLAG_BERNOULLI) ? 2 : ((c->flags & SPMF_FLAG_MIXED) ? 3 : 0));
-}
 
 int spmf_prior_async(spmf_ctx* c, int S, double prior_weight, const float* const params[SPMF_NVARS],
     const float* eta, double* parts, float* const grads[SPMF_NVARS], void* stream) {
@@ -683,7 +687,7 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
       "dense_ll: bad arguments");
   const int lik = likelihood_code(c);
   if (lik == 3 && !c->ctype) return fail(c, SPMF_E_ARG, "dense_ll: spmf_ctx_set_column_types was not called");
-  const int logt = lik == 1 ? 1 : 0;
+  const int logt = lik_exp(lik) ? 1 : 0;
   int rc = check_counts(c, ct);
   if (!rc && logt && ct->nnz > 0 && !ct->gval) rc = fail(c, SPMF_E_ARG, "dense_ll: log_transform needs counts.gval");
   if (rc) return rc;
@@ -798,7 +802,7 @@ int spmf_nonfinite_patch(spmf_ctx* c, const spmf_counts* ct, int S, const float*
   for (int i : {0, 1, 2, 7})
     if (!params[i]) return fail(c, SPMF_E_ARG, "nonfinite_patch: params v,w,u,s must be non-null");
   const int logt = likelihood_code(c);
-  if (logt == 1 && ct->nnz > 0 && !ct->gval) return fail(c, SPMF_E_ARG, "nonfinite_patch: log_transform needs counts.gval");
+  if (lik_exp(logt) && ct->nnz > 0 && !ct->gval) return fail(c, SPMF_E_ARG, "nonfinite_patch: log_transform needs counts.gval");
   NfPatchArgs a{c->D, c->K, logt, ct->row_ptr, ct->col_idx, ct->val,
       (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, params[2], params[0], params[1], params[7], eta,
       c->ctype, c->acc, (int64_t)acc_len(c->D, c->KP), c->Dh > 0 ? c->Dh : c->D, io, nlg, ct->n_rows, S};

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
   }
   const float4 vp = ok ? gather4<LPN>(Vp, d, sub) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float ph = ok ? phi[d] : 1.f;
-  const bool bern = LIK == 2 || (LIK == 3 && ok && ctype[d]);   // item's column is Bernoulli
+  const bool bern = LIK == 2 || LIK == 4 || (LIK == 3 && ok && ctype[d]);   // item's column is Bernoulli
   float4 gV = make_float4(0.f, 0.f, 0.f, 0.f), gA = gV;
   float gph = 0.f;
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     const int e = cur + sub;
     rr_ = sub < cnt_ ? pc_row[e] - row_base : 0;
     xx_ = sub < cnt_ ? pc_val[e] : 0.f;
-    gx_ = (LIK == 1 && sub < cnt_) ? pc_gval[e] : 0.f;  // g(x) = log(x/eta+1), data side
+    gx_ = ((LIK == 1 || LIK == 4) && sub < cnt_) ? pc_gval[e] : 0.f;  // g(x) = log(x/eta+1), data side
     cur += cnt_;
   };
 
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
           const int src = grp * LPN + g0 + j;
           const int b = __shfl(rr0, src);
           xv[j] = __shfl(xx0, src);
-          gv[j] = LIK == 1 ? __shfl(gx0, src) : xv[j];
+          gv[j] = (LIK == 1 || LIK == 4) ? __shfl(gx0, src) : xv[j];
           zz[j] = gather4<LPN>(z, b, sub);
           gg[j] = gather4<LPN>(gzs, b, sub);
         }
@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
         for (int j = 0; j < GRP; ++j) {
           if (bern) {
             // Bernoulli: d(x*logit)/dV' = x z_b, d/dphi = x: no rate needed
-            gV = fma4(xv[j], zz[j], gV);
+            // (LIK 4, logit = exp(y) - 1 + phi: the V' weight is x * exp(y))
+            float wv = xv[j];
+            if (LIK == 4) wv *= expf(fminf(group_sum<LPN>(dot4(zz[j], vp)), kYSat));
+            gV = fma4(wv, zz[j], gV);
             gA = fma4(gv[j], gg[j], gA);
             gph += xv[j];
           } else {
@@ -209,7 +212,8 @@ static void launch_col_t(const ColArgs& a, hipStream_t st) {
                      a.n_panels, a.row_base, bpp, a.item_ptr, items, a.pc_row, a.pc_val,       \
                      a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi, a.ctype,          \
                      a.item_mid, a.half_sel, a.B, a.acc_stride)
-  if (a.logt == 3) SPMF_COL_LAUNCH(3);
+  if (a.logt == 4) SPMF_COL_LAUNCH(4);
+  else if (a.logt == 3) SPMF_COL_LAUNCH(3);
   else if (a.logt == 2) SPMF_COL_LAUNCH(2);
   else if (a.logt == 1) SPMF_COL_LAUNCH(1);
   else SPMF_COL_LAUNCH(0);

@@ -23,6 +23,12 @@ constexpr int kDaccHead = 6;
 // so a batch with a few runaway cells still trains -- its gradient pushes their
 // exponents down -- instead of being skipped.  Saturation events are counted
 // (dacc[4], workgroup granularity); while that count is 0 the decoder is exact.
+// Likelihood code of a context (api.hip likelihood_code): 0 Poisson / linear decoder, 1 Poisson /
+// exp decoder (log_transform), 2 Bernoulli(logits) / linear, 3 mixed per column / linear,
+// 4 Bernoulli(logits) / exp decoder (bernoulli.py:60-61: logit = exp(<z, eta v>) - 1 + phi).
+__host__ __device__ constexpr bool lik_exp(int l) { return l == 1 || l == 4; }
+__host__ __device__ constexpr bool lik_bern(int l) { return l == 2 || l == 4; }
+
 constexpr float kYSat = 70.0f;
 // the block sums land in one of kDaccRep replicas (blockIdx % kDaccRep) so the
 // fp64 atomics of thousands of blocks do not serialise on 4+KP addresses;

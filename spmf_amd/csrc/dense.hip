@@ -39,6 +39,8 @@ struct XB {
 };
 
 // ACT 0: E = exp(X)                         esum += sum E          (Poisson, log_transform)
+// ACT 2: l = exp(X) - 1 + bias, E = sigmoid(l) * exp(X) (= d softplus(l)/dX), esum += sum softplus(l),
+//        out2 gets the sums of sigmoid(l)    (Bernoulli logits with the exp decoder, bernoulli.py:60-61)
 // ACT 1: E = sigmoid(X + bias)              esum += sum softplus(X + bias)   (Bernoulli logits,
 //        bernoulli.py:147-155; bias = phi of the column: bias_q when Q rows are columns,
 //        bias_p when P rows are columns); out2[p] += sign * sum_q E (the d/dphi column sums)
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
       pb[b][4 * s4 + 0] = v.x; pb[b][4 * s4 + 1] = v.y;
       pb[b][4 * s4 + 2] = v.z; pb[b][4 * s4 + 3] = v.w;
     }
-    bp[b] = (ACT == 1 && bias_p && p < NP) ? bias_p[p] : 0.f;
+    bp[b] = (ACT >= 1 && bias_p && p < NP) ? bias_p[p] : 0.f;
     colsum[b] = 0.f;                                     // ACT 1: sum_q E for this lane's p
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
   float bstage = 0.f;
   auto gload = [&](int tile, int part) {
     const int q0 = tile * QT + part * 32;
-    if (ACT == 1 && t < 32) bstage = (bias_q && q0 + t < NQ) ? bias_q[q0 + t] : 0.f;
+    if (ACT >= 1 && t < 32) bstage = (bias_q && q0 + t < NQ) ? bias_q[q0 + t] : 0.f;
 #pragma unroll
     for (int i = 0; i < PER4; ++i) {
       const int e = (i * 256 + t) * 4;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
     }
   };
   auto swrite = [&](int buf, int part) {
-    if (ACT == 1 && t < 32) bqs[buf][part * 32 + t] = bstage;
+    if (ACT >= 1 && t < 32) bqs[buf][part * 32 + t] = bstage;
 #pragma unroll
     for (int i = 0; i < PER4; ++i) {
       const int e = (i * 256 + t) * 4;
@@ -208,7 +210,26 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
 #pragma unroll
       for (int b = 0; b < PB; ++b) {
         const int p = p0 + b * 32 + c;
-        if (ACT == 1) {
+        if (ACT == 2) {
+          // l = exp(X) - 1 + bias; E = sigmoid(l) * exp(X); sum softplus(l); colsum = sum sigmoid(l)
+          float pmax = 0.f, plog = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int ql = sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const bool in = !edge || (q0 + ql < NQ && p < NP);
+            const float ex = __expf(fminf(xcur[b][i], kYSat));
+            const float l = ex - 1.f + bp[b] + bqs[buf][ql];
+            const float en = __expf(-fabsf(l));
+            const float d = 1.f + en;
+            const float inv = __builtin_amdgcn_rcpf(d);
+            const float sg = in ? (l >= 0.f ? inv : en * inv) : 0.f;
+            xcur[b][i] = sg * ex;
+            pmax += in ? fmaxf(l, 0.f) : 0.f;
+            plog += in ? __builtin_amdgcn_logf(d) : 0.f;
+            colsum[b] += sg;
+          }
+          part += pmax + 0.69314718056f * plog;
+        } else if (ACT == 1) {
           // softplus(l) = max(l,0) + ln2*log2(1+e^-|l|): the two sums are kept apart
           // so the ln2 factor is applied once per sub-tile
           float pmax = 0.f, plog = 0.f;
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
           }
         }
     }
-    if (ACT == 1 && out2) {
+    if (ACT >= 1 && out2) {
       float cs = colsum[b];
       cs += __shfl_xor(cs, 32);                         // the two lane halves hold disjoint q rows
       if (h == 0 && p < NP && cs != 0.f) atomicAdd(&out2[prow], sign * cs);
@@ -585,9 +606,11 @@ void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st) {
                      a.out, a.sign, a.esum, a.atomic_out, a.bias_p, a.bias_q, a.out2, a.out_rows,  \
                      a.est, a.ldE)
   if (KD == 32 && a.act == 0) SPMF_ED_LAUNCH(32, 0);
-  else if (KD == 32) SPMF_ED_LAUNCH(32, 1);
+  else if (KD == 32 && a.act == 1) SPMF_ED_LAUNCH(32, 1);
+  else if (KD == 32) SPMF_ED_LAUNCH(32, 2);
   else if (KD == 64 && a.act == 0) SPMF_ED_LAUNCH(64, 0);
-  else if (KD == 64) SPMF_ED_LAUNCH(64, 1);
+  else if (KD == 64 && a.act == 1) SPMF_ED_LAUNCH(64, 1);
+  else if (KD == 64) SPMF_ED_LAUNCH(64, 2);
 #undef SPMF_ED_LAUNCH
 }
 

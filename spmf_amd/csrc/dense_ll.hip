@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void dense_rate_kernel(int64_t B, int D, int l
     float y = 0.f;
 #pragma unroll 8
     for (int k = 0; k < KP; ++k) y = fmaf(zs[r][k], vs[dl][k], y);
-    const float rt = (logt == 1 ? expf(fminf(y, kYSat)) - 1.f : y) + phi[d];
+    const float rt = (lik_exp(logt) ? expf(fminf(y, kYSat)) - 1.f : y) + phi[d];
     rate[(size_t)b * D + d] = rt;
-    const bool bern = logt == 2 || (logt == 3 && ctype[d]);
+    const bool bern = lik_bern(logt) || (logt == 3 && ctype[d]);
     // x = 0 cell.  Poisson: 0*log r := 0 (multiply_no_nan) -> -r.  Bernoulli: -softplus(logit)
     ll[(size_t)b * D + d] = bern ? -(fmaxf(rt, 0.f) + log1pf(expf(-fabsf(rt)))) : -rt;
   }
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void dense_fix_kernel(int64_t B, int D, int lo
       const int d = col[i];
       const size_t o = (size_t)b * D + d;
       const float r = rate[o];
-      if (logt == 2 || (logt == 3 && ctype[d])) {
+      if (lik_bern(logt) || (logt == 3 && ctype[d])) {
         // tfd.Bernoulli(logits).log_prob(x) = x*l - softplus(l)  (bernoulli.py:147-155)
         ll[o] = x * r - (fmaxf(r, 0.f) + log1pf(expf(-fabsf(r))));
       } else {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void nonfinite_lgamma_kernel(int64_t B, int D,
     const int start = row_ptr[b], end = row_ptr[b + 1];
     for (int i = start + lane; i < end; i += 64) {
       const int d = col[i];
-      if (logt == 2 || (logt == 3 && ctype[d])) continue;      // Bernoulli cell: no lgamma term
+      if (lik_bern(logt) || (logt == 3 && ctype[d])) continue;      // Bernoulli cell: no lgamma term
       const float r = rate[(size_t)b * D + d];
       const float x = val[i];
       if (x > 0.f && !(r > 0.f && r < INFINITY)) acc += (double)lgammaf(x + 1.f);
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void nonfinite_patch_kernel(
         const float x = val[e];
         const float s0 = s[d], s1 = s[D + d];
         const float w1 = s0 / (s0 + s1);
-        const float a = logt == 1 ? w1 * u[(size_t)d * K + t] : w1 * u[(size_t)d * K + t] / eta[d];
-        const float gx = logt == 1 ? log1pf(x / eta[d]) : x;
+        const float a = lik_exp(logt) ? w1 * u[(size_t)d * K + t] : w1 * u[(size_t)d * K + t] / eta[d];
+        const float gx = lik_exp(logt) ? log1pf(x / eta[d]) : x;
         zk = fmaf(gx, a, zk);
       }
     zs[t] = xi * zk;
@@ -279,9 +279,11 @@ __global__ __launch_bounds__(256) void nonfinite_patch_kernel(
   const float phi = eta[dstar] * (s1 / (s0 + s1)) * w[dstar];
   const float x = xstar_s;
   float cy, cphi;
-  if (logt == 2 || (logt == 3 && ctype[dstar])) {
-    const float sg = 1.f / (1.f + expf(-(y + phi)));
-    cy = cphi = x - sg;
+  if (lik_bern(logt) || (logt == 3 && ctype[dstar])) {
+    const float ey = logt == 4 ? expf(fminf(y, kYSat)) : 1.f;
+    const float sg = 1.f / (1.f + expf(-((logt == 4 ? ey - 1.f : y) + phi)));
+    cphi = x - sg;
+    cy = cphi * ey;
   } else {
     const float ey = logt == 1 ? expf(fminf(y, kYSat)) : 1.f;
     const float r = (logt == 1 ? ey - 1.f : y) + phi;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void nonfinite_patch_kernel(
     const int e = start + i / KP, k = i % KP;
     if (k < K) {
       const int d = col[e];
-      const float gx = logt == 1 ? log1pf(val[e] / eta[d]) : val[e];
+      const float gx = lik_exp(logt) ? log1pf(val[e] / eta[d]) : val[e];
       float* gA = accd + L.gA_off(d >= Dh ? 1 : 0);
       gA[(size_t)d * KP + k] += Nf * cy * xi * gx * vs[k];
     }

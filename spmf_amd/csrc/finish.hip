@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   if (t < KP) {
     // log_transform: the dense kernel already subtracted sum_b E_bd z_b from gV'
     // (mixed, code 3: still needed for the Poisson columns)
-    zsum_s[t] = (!DATA || logt == 1 || logt == 2) ? 0.f : (float)unpack(tail, kDaccHead + t);
+    zsum_s[t] = (!DATA || lik_exp(logt) || lik_bern(logt)) ? 0.f : (float)unpack(tail, kDaccHead + t);
     utau_s[t] = hs ? u_tau_scale : (t < K ? P.p[UTAU_][t] : 1.f);   // hs: scale = u_tau_scale * decay^k
     dec_s[t] = (float)pow((double)decay, (double)t);   // powf is ~1e-6 off at t~60: a systematic part error
     gutau_s[t] = 0.f;
@@ -181,10 +181,10 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     }
     w1s[t] = w1;
     etas_[t] = e;
-    ietas[t] = logt == 1 ? 1.f : 1.f / e;   // A' = w1*u/eta (linear) or w1*u (log_transform)
+    ietas[t] = lik_exp(logt) ? 1.f : 1.f / e;   // A' = w1*u/eta (linear) or w1*u (log_transform)
     GAs[t] = 0.f;
     // column follows the Bernoulli likelihood: all of them (code 2) or by type (mixed, code 3)
-    bern_s[t] = (logt == 2 || (logt == 3 && d < D && ctype[d])) ? 1 : 0;
+    bern_s[t] = (lik_bern(logt) || (logt == 3 && d < D && ctype[d])) ? 1 : 0;
   }
   __syncthreads();
 
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     const double llx = unpack(tail, 0), zsq = unpack(tail, 1);
     // sum of the rate over ALL cells: closed form (linear) or the dense exp sum
     double sum_r = Bglob * dprep[KP];
-    if (logt == 2)
+    if (lik_bern(logt))
       sum_r = unpack(tail, 3);                 // sum over all cells of softplus(logit)
     else if (logt == 1)
       sum_r += unpack(tail, 3) - Bglob * (double)D;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * dprep[k];
       if (logt == 3) sum_r += unpack(tail, 3);   // mixed: + softplus over the Bernoulli columns
     }
-    parts[13] = llx - (logt == 2 ? 0.0 : lgamma_sum) - sum_r;      // single writer
+    parts[13] = llx - (lik_bern(logt) ? 0.0 : lgamma_sum) - sum_r;      // single writer
     parts[12] = Bglob * (double)K * kHalfLog2OverPi - 0.5 * zsq;
     if (nnf_out) {
       nnf_out[0] = unpack(tail, 2);

@@ -113,12 +113,14 @@ struct RowCtx {
     const int cs = __shfl(c, slot);
     float cc = 0.f;
     if (slot < nchunk && xs > 0.f) {
-      if (LIK == 2 || (LIK == 3 && ctype[cs])) {
-        // Bernoulli(logits = <z,V'> + phi) (bernoulli.py:147-155): stored-cell part x*logit
-        const float lg = rmine + (LDSPHI ? lds_dyn()[cs] : phi[cs]);
+      if (LIK == 2 || LIK == 4 || (LIK == 3 && ctype[cs])) {
+        // Bernoulli(logits = f(<z,V'>) + phi) (bernoulli.py:147-155): stored-cell part x*logit;
+        // LIK 4: f = exp - 1 (saturating like the Poisson form)
+        const float ey = LIK == 4 ? expf(fminf(rmine, kYSat)) : 1.f;
+        const float lg = (LIK == 4 ? ey - 1.f : rmine) + (LDSPHI ? lds_dyn()[cs] : phi[cs]);
         if (lg > -INFINITY && lg < INFINITY) {
           ll = fmaf(xs, lg, ll);
-          cc = xs;                                   // d(x*logit)/d<z,V'>
+          cc = LIK == 4 ? xs * ey : xs;              // d(x*logit)/d<z,V'>
         } else {
           nnf += 1.0;
         }
@@ -399,7 +401,8 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, \
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, \
                      a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride)
-  if (a.logt == 3) SPMF_ROW_LAUNCH(3);
+  if (a.logt == 4) SPMF_ROW_LAUNCH(4);
+  else if (a.logt == 3) SPMF_ROW_LAUNCH(3);
   else if (a.logt == 2) SPMF_ROW_LAUNCH(2);
   else if (a.logt == 1) SPMF_ROW_LAUNCH(1);
   else SPMF_ROW_LAUNCH(0);
