@@ -19,8 +19,8 @@ assert lib.spmf_version() == 2 and lib.spmf_sizeof_counts() == C.sizeof(_lib.Cou
 h = C.c_void_p()
 assert lib.spmf_ctx_create(0, 100, 10, 0, C.byref(h)) == -1
 assert lib.spmf_ctx_create(0, 0, 10, 0, C.byref(h)) == -1
-assert lib.spmf_ctx_create(0, 8, 10, _lib.FLAG_LOG_TRANSFORM | _lib.FLAG_BERNOULLI, C.byref(h)) == -4
-for flags in (0, 1, 2 | 1, 4, 8, 16 | 1):
+assert lib.spmf_ctx_create(0, 8, 10, _lib.FLAG_LOG_TRANSFORM | _lib.FLAG_MIXED, C.byref(h)) == -4
+for flags in (0, 1, 2 | 1, 4, 4 | 2, 8, 16 | 1):
     for K in (1, 3, 16, 33, 64):
         assert lib.spmf_ctx_create(0, K, 1000, flags, C.byref(h)) == 0
         kp = lib.spmf_padded_k(h)
