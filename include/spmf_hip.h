@@ -150,11 +150,19 @@ int spmf_ctx_set_column_types(spmf_ctx* ctx, const uint8_t* column_is_bernoulli)
  * all D columns with the Poisson ones masked by a -1e30 logit bias. */
 int spmf_ctx_set_bernoulli_columns(spmf_ctx* ctx, const int32_t* cols, int n);
 
+/* Upper bound in bytes of the buffer that keeps E between the two dense contractions
+ * (log_transform / Bernoulli / mixed contexts; default 8 GiB).  The rows of a batch are
+ * processed in equal chunks that fit it; fewer, larger chunks fill the chip better (at
+ * C4, 500k x 30k: 8 chunks at 8 GiB, one at 64 GiB).  Call before
+ * spmf_workspace_bytes / spmf_ctx_set_workspace: it changes the workspace size. */
+int spmf_ctx_set_e_cap(spmf_ctx* ctx, size_t bytes);
+
 /* Bytes of caller-owned device workspace needed for batches of up to
  * max_rows rows and S draws.  With SPMF_FLAG_LOG_TRANSFORM / BERNOULLI / MIXED this
  * includes the buffer that keeps E = exp(<z_b, eta_d v_d>) (or the sigmoid of the
  * Bernoulli logits) between the two dense contractions
- * (min(max_rows, chunk) * D floats, chunk chosen so that it stays <= 8 GiB; the
+ * (min(max_rows, chunk) * D floats, chunk chosen so that it stays within
+ * spmf_ctx_set_e_cap; the
  * environment variable SPMF_DENSE_E_ONCE=0, read at spmf_ctx_create, selects the
  * form that recomputes E instead and needs no such buffer). */
 size_t spmf_workspace_bytes(const spmf_ctx* ctx, int64_t max_rows, int S);

@@ -130,6 +130,7 @@ SIGNATURES = {
     "spmf_adam_step": (C.c_int, [C.c_void_p, C.POINTER(AdamVar), C.c_int, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
                                  C.c_void_p]),
+    "spmf_ctx_set_e_cap": (C.c_int, [C.c_void_p, C.c_size_t]),
     "spmf_padded_k": (C.c_int, [C.c_void_p]),
     "spmf_z_ptr": (C.c_void_p, [C.c_void_p]),
     "spmf_gz_ptr": (C.c_void_p, [C.c_void_p]),

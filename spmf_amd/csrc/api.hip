@@ -58,7 +58,7 @@ struct spmf_ctx {
   float* est = nullptr;
   int64_t est_rows = 0;           // rows per chunk of the bound workspace
   int e_once = 1;                 // SPMF_DENSE_E_ONCE=0: recompute E in a second launch instead
-  static constexpr size_t kEstCapBytes = (size_t)8 << 30;
+  size_t est_cap_bytes = (size_t)8 << 30;   // spmf_ctx_set_e_cap
   double* scratch = nullptr;
   static constexpr size_t kScratchDoubles = 1u << 20;   // 8 MiB
   void* comm = nullptr;           // ncclComm_t of the row-shard collective (spmf_comm_init)
@@ -160,7 +160,7 @@ static int likelihood_code(const spmf_ctx* c) {   // common.h: lik_exp / lik_ber
 // rows of one E chunk: whole 128-row workgroups of the exp kernel, at most kEstCapBytes
 static int64_t est_chunk_rows(const spmf_ctx* c, int64_t rows) {
   const size_t per_row = (size_t)((c->D + 31) / 32) * 32 * sizeof(float);
-  int64_t cap = (int64_t)(spmf_ctx::kEstCapBytes / per_row) / 128 * 128;
+  int64_t cap = (int64_t)(c->est_cap_bytes / per_row) / 128 * 128;
   if (cap < 128) cap = 128;
   return rows < cap ? rows : cap;
 }
@@ -262,6 +262,13 @@ int spmf_ctx_set_bernoulli_columns(spmf_ctx* c, const int32_t* cols, int n) {
       "set_bernoulli_columns: needs a SPMF_FLAG_MIXED ctx and n indices in [0, D)");
   c->bcols = n > 0 ? cols : nullptr;
   c->n_bcols = n;
+  return SPMF_OK;
+}
+
+int spmf_ctx_set_e_cap(spmf_ctx* c, size_t bytes) {
+  if (!c || bytes < ((size_t)1 << 20)) return fail(c, SPMF_E_ARG, "set_e_cap: at least 1 MiB");
+  c->est_cap_bytes = bytes;
+  c->ws_rows = -1;            // the carve changes: the next call re-binds (and re-checks) the workspace
   return SPMF_OK;
 }
 

@@ -31,6 +31,7 @@ for flags in (0, 1, 2 | 1, 4, 4 | 2, 8, 16 | 1):
             assert n2 > n1 > 0 and lib.spmf_acc_len(h, S) == S * (2 * 1000 * kp + 1000 + 2 * (6 + kp))
         assert lib.spmf_ctx_set_prior(h, 0.0, 1.0, 0.99) == -1 and b"> 0" in lib.spmf_last_error(h)
         assert lib.spmf_ctx_set_prior(h, 0.01, 1.0, 0.99) == 0
+        assert lib.spmf_ctx_set_e_cap(h, 1000) == -1 and lib.spmf_ctx_set_e_cap(h, 1 << 26) == 0
         assert lib.spmf_ctx_set_workspace(h, None, 10) == -1
         assert lib.spmf_ctx_set_workspace(h, 12345, 1 << 20) == -1          # misaligned
         assert lib.spmf_ctx_set_column_split(h, 33) == -1
