@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, (KD == 32 && ACT == 1) ? 2 : 1) void expdot_ke
 // round (32 of them) are staged in LDS as the B operand for all 8 waves; the accumulator has
 // q in its registers and k on the lane, so the epilogue writes 128-B rows.
 // Roofline: MFMA f32, 2*NQ*NP*KD flop; HBM NQ*NP*4 bytes (2.5 TB/s at the MFMA rate).
-template <int KD, int NW>
+template <int KD, int NW, bool RS>   // RS: also the row sums of E (out2)
 __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP, int64_t ldE,
                                                                  const float* __restrict__ est,
                                                                  const float* __restrict__ P,
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
         for (int m = 0; m < MT; ++m)
           acc[it][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it][s], bz[m], acc[it][m], 0, 0, 0);
     }
-    if (out2) {                                  // block-uniform
+    if (RS) {
       // (rows past NP were read clamped to NP-1: zero partners in the product, but not here)
       const int nv = NP - r * RP;
 #pragma unroll
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
   auto fold = [&]() {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      rst[it] += rs[it];
+      if (RS) rst[it] += rs[it];
       rs[it] = 0.f;
     }
 #pragma unroll
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void estdot_kernel(int NQ, int NP,
           atomicAdd(out + (size_t)row * KD + m * 32 + c, sign * (acc[it][m][i] + tot[it][m][i]));
         }
       }
-    if (out2) {
+    if (RS && out2) {
       // lane (c, h) summed E[q = 32*(qt0+it) + c][p of half h]
       float r = rs[it] + rst[it];
       r += __shfl_xor(r, 32);
@@ -565,12 +565,14 @@ void launch_estdot(int KD, int NQ, int NP, int64_t ldE, const float* est, const 
   if (chunks > rounds) chunks = rounds;
   if (chunks < 1) chunks = 1;
   dim3 grid(nbx, chunks);
-  if (KD == 64)
-    hipLaunchKernelGGL((estdot_kernel<64, NW>), grid, dim3(NW * 64), 0, st, NQ, NP, ldE, est, P, out, sign,
-                       out2, out_rows);
-  else if (KD == 32)
-    hipLaunchKernelGGL((estdot_kernel<32, NW>), grid, dim3(NW * 64), 0, st, NQ, NP, ldE, est, P, out, sign,
-                       out2, out_rows);
+#define SPMF_ESTDOT(KD_, RS_)                                                                        \
+  hipLaunchKernelGGL((estdot_kernel<KD_, NW, RS_>), grid, dim3(NW * 64), 0, st, NQ, NP, ldE, est, P, out, \
+                     sign, out2, out_rows)
+  if (KD == 64 && out2) SPMF_ESTDOT(64, true);
+  else if (KD == 64) SPMF_ESTDOT(64, false);
+  else if (KD == 32 && out2) SPMF_ESTDOT(32, true);
+  else if (KD == 32) SPMF_ESTDOT(32, false);
+#undef SPMF_ESTDOT
 }
 
 // Mixed likelihood: the dense softplus/sigmoid sums run over the Bernoulli columns only.
