@@ -154,11 +154,12 @@ class PoissonFactorization:
             h, float(self.u_tau_scale), float(self.s_tau_scale),
             float(self.symmetry_breaking_decay)), "spmf_ctx_set_prior")
         if flags & (_lib.FLAG_LOG_TRANSFORM | _lib.FLAG_BERNOULLI | _lib.FLAG_MIXED):
-            # room for E between the two dense contractions (dense.hip): a quarter of the
-            # device memory that is free now, at most 64 GiB (the library's default is 8 GiB);
-            # fewer, larger row chunks fill the chip better
+            # room for E between the two dense contractions (dense.hip): a third of the device
+            # memory torch can still hand out (free + its own cached blocks), at most 64 GiB
+            # (the library's default is 8 GiB); fewer, larger row chunks fill the chip better
             free, _total = torch.cuda.mem_get_info(self.device)
-            cap = max(1 << 30, min(64 << 30, int(free) // 4))
+            cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+            cap = max(1 << 30, min(64 << 30, (int(free) + max(0, int(cached))) // 3))
             _lib.check(h, lib.spmf_ctx_set_e_cap(h, cap), "spmf_ctx_set_e_cap")
         return h
 
