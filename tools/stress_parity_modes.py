@@ -23,7 +23,7 @@ def check(tag, parts, grads, pref, gref, acc):
         acc[1] = max(acc[1], e)
         if e > 5e-6: print("grad", tag, k, f"{e:.2e}")
 
-for mode in ("logt", "bern", "mixed"):
+for mode in ("logt", "bern", "bernlogt", "mixed"):
     acc = [0.0, 0.0]
     for case in range(N):
         B = int(rng.integers(2, 500)); D = int(rng.integers(2, 600)); K = int(rng.integers(1, 65))
@@ -38,10 +38,11 @@ for mode in ("logt", "bern", "mixed"):
                                          log_transform=True, column_norms=cfg.eta_i,
                                          initialize_distributions=False, device="cuda", panel_rows=P)
                 m.xi_u_global = cfg.xi_u_global
-            elif mode == "bern":
-                cfg, x, params = TB.problem(B, D, K, S, seed, density)
+            elif mode in ("bern", "bernlogt"):
+                lt = mode == "bernlogt"
+                cfg, x, params = (TB.problem_logt if lt else TB.problem)(B, D, K, S, seed, density)
                 m = BernoulliFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
-                                           column_norms=cfg.eta_i, device="cuda", panel_rows=P)
+                                           column_norms=cfg.eta_i, log_transform=lt, device="cuda", panel_rows=P)
             else:
                 cfg, x, params, mask = TM.problem(B, D, K, S, seed, density, sr)
                 m = MixedFactorization(mask, latent_dim=K, u_tau_scale=cfg.u_tau_scale, scale_rows=sr,
