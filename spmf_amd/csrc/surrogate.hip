@@ -373,7 +373,7 @@ __device__ __forceinline__ float gamma_dgda(double a, double x) {
   for (int n = 0; n < 4000; ++n) {
     const double term = R * (lx - psi);
     acc += term;
-    if ((double)n > x && fabs(term) < 1e-10 * fabs(acc) + 1e-300) break;   // the result is stored as fp32
+    if ((double)n > x && fabs(term) < 1e-8 * fabs(acc) + 1e-300) break;    // the result is stored as fp32 (6e-8)
     const double dn = a + (double)(n + 1);
     double rc = (double)__builtin_amdgcn_rcpf((float)dn);
     rc = rc * (2.0 - dn * rc);                 // one Newton step: ~1e-14 relative
@@ -403,19 +403,30 @@ __global__ __launch_bounds__(256) void sample_noise_kernel(SurTable T, int S, ui
   const float a = softplusf(v.t0[i]);
   const float ab = a < 1.f ? a + 1.f : a;              // boost: Gamma(a) = Gamma(a+1) U^(1/a)
   const float d = ab - (1.f / 3.f), cc = rsqrtf(9.f * d);
-  float g = d;                                          // (fallback after 32 rejections: the mode)
+  float g = d;                                          // (fallback after 16 rejected blocks: the mode)
   float ub = 1.f;
-  for (uint32_t att = 0; att < 32; ++att) {
+  // One Philox block serves TWO Marsaglia-Tsang candidates: both Box-Muller normals (cos and sin
+  // branch of the same radius), a uniform each, and the boost uniform from the low bytes that
+  // u01() does not look at.  A lane rejects a candidate 1 time in ~20, so a wave of 64 nearly
+  // always needed a second block with one candidate per block; with two it rarely does.
+  bool done = false;
+  for (uint32_t att = 0; att < 16 && !done; ++att) {
     const uint4 r = philox4x32_10(make_uint4((uint32_t)i, c1 | (att << 24), clo, chi), key);
-    if (att == 0) ub = u01(r.w);
-    const float x = normal_bm(r.x, r.y);
-    const float t = 1.f + cc * x;
-    if (t <= 0.f) continue;
-    const float vv = t * t * t;
-    const float u = u01(r.z);
-    if (logf(u) < 0.5f * x * x + d - d * vv + d * logf(vv)) {
-      g = d * vv;
-      break;
+    if (att == 0)
+      ub = ((float)(((r.x & 0xffu) << 16) | ((r.y & 0xffu) << 8) | (r.z & 0xffu)) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.f * logf(u01(r.x)));
+    float sn, cs;
+    sincospif(2.f * u01(r.y), &sn, &cs);
+#pragma unroll
+    for (int cand = 0; cand < 2; ++cand) {
+      const float x = rad * (cand == 0 ? cs : sn);
+      const float t = 1.f + cc * x;
+      const float vv = t * t * t;
+      const float u = u01(cand == 0 ? r.z : r.w);
+      if (!done && t > 0.f && logf(u) < 0.5f * x * x + d - d * vv + d * logf(vv)) {
+        g = d * vv;
+        done = true;
+      }
     }
   }
   if (a < 1.f) g *= powf(ub, 1.f / a);
