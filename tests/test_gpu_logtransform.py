@@ -77,6 +77,29 @@ def test_two_launch_form_still_matches_oracle(monkeypatch, B, D, K, S):
         assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
 
 
+def test_e_buffer_in_several_row_chunks():
+    """spmf_ctx_set_e_cap small enough that the rows go through the dense kernels in several
+    chunks (at C4 scale the Python class sizes the buffer for ONE chunk, so the chunk loop is
+    exercised here): 4000 rows with a 1 MiB cap = 3 chunks of 1408 / 1408 / 1184 rows."""
+    from spmf_amd import PoissonFactorization, _lib
+    B, D, K, S = 4000, 129, 64, 1
+    cfg, x, params = problem(B, D, K, S, 4321, 0.03)
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
+                             log_transform=True, column_norms=cfg.eta_i,
+                             initialize_distributions=False, device="cuda", panel_rows=512)
+    m.xi_u_global = cfg.xi_u_global
+    lib, h = _lib.load(), m._handle()
+    _lib.check(h, lib.spmf_ctx_set_e_cap(h, 1 << 20), "spmf_ctx_set_e_cap")
+    assert (1 << 20) // (160 * 4) < B          # the cap really is below one chunk of all rows
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    for k, r in pref.items():
+        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
+    for k, r in gref.items():
+        g = grads[k].cpu().double().numpy().reshape(r.shape)
+        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+
+
 def test_log_transform_randomised_sweep():
     from spmf_amd import PoissonFactorization
     rng = np.random.default_rng(77)
