@@ -47,6 +47,35 @@ def test_mixed_energy_and_grads(B, D, K, S, density, sr):
         assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
 
 
+@pytest.mark.parametrize("kind", ["mixed", "bernoulli"])
+def test_sigmoid_e_buffer_in_several_row_chunks(kind):
+    """The sigmoid form of the kept-E path with a small spmf_ctx_set_e_cap: several row chunks, a
+    last chunk that ends inside a 32-row round (row sums of E masked there), and -- mixed -- the
+    scatter through the compacted Bernoulli column list."""
+    from spmf_amd import BernoulliFactorization, MixedFactorization, _lib
+    B, D, K, S = 3001, 90, 32, 1
+    if kind == "mixed":
+        cfg, x, params, mask = problem(B, D, K, S, 5150, 0.04, True)
+        m = MixedFactorization(mask, latent_dim=K, u_tau_scale=cfg.u_tau_scale, scale_rows=True,
+                               column_norms=cfg.eta_i, device="cuda", panel_rows=512)
+        m.xi_u_global = cfg.xi_u_global
+    else:
+        import test_gpu_bernoulli as TB
+        cfg, x, params = TB.problem(B, D, K, S, 5151, 0.04)
+        m = BernoulliFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
+                                   column_norms=cfg.eta_i, device="cuda", panel_rows=512)
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    lib, h = _lib.load(), m._handle()
+    _lib.check(h, lib.spmf_ctx_set_e_cap(h, 1 << 20), "spmf_ctx_set_e_cap")   # 2 chunks of 1536 / 1465 rows
+    assert (1 << 20) // (96 * 4) < B
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    for k, r in pref.items():
+        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
+    for k, r in gref.items():
+        g = grads[k].cpu().double().numpy().reshape(r.shape)
+        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+
+
 def test_mixed_fit_smoke():
     from spmf_amd import MixedFactorization
     rng = np.random.default_rng(0)
