@@ -111,7 +111,11 @@ typedef struct spmf_counts {
   const int32_t* item_ptr;
   const int32_t* items;
   int32_t max_items_per_panel;
-  int32_t reserved_;
+  /* Readable int32/float entries behind the END of the last list in pc_row, pc_val (and
+   * pc_gval).  With pc_pad >= 4*ceil(K/4) - 1 (K padded to 4, 8, 16, 32, 64) the column
+   * pass fetches list entries four at a time (16-B loads that may run past a list's end);
+   * 0 selects the entry-at-a-time fetch, which never reads behind a list. */
+  int32_t pc_pad;
   /* Optional column split of the work items (multi-GPU overlap): inside a panel
    * the items are sorted by column half first (columns < col_split, then the
    * rest), then by length; item_mid[p] is the first item of panel p's upper

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspmf_hip.so")
+#: SPMF_LIB_PATH: another build of the same library (tools/build_variant.sh: kernel experiments)
+LIB_PATH = os.environ.get("SPMF_LIB_PATH") or os.path.join(_HERE, "libspmf_hip.so")
 
 NVARS = 12
 VI_STATE_LEN = 16
@@ -45,7 +46,7 @@ class CountsStruct(C.Structure):
         ("lgamma_sum", C.c_double),
         ("gval", C.c_void_p), ("pc_gval", C.c_void_p),
         ("item_ptr", C.c_void_p), ("items", C.c_void_p),
-        ("max_items_per_panel", C.c_int32), ("reserved_", C.c_int32),
+        ("max_items_per_panel", C.c_int32), ("pc_pad", C.c_int32),
         ("item_mid", C.c_void_p), ("col_split", C.c_int32),
         ("max_items_half", C.c_int32 * 2), ("reserved2_", C.c_int32),
     ]

@@ -528,7 +528,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         ColArgs ca{D, ct->n_panels, ct->row_base, split ? ct->max_items_half[hf] : ct->max_items_per_panel,
             ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc + L.gA_off(hf),
             acc + L.gV_off(hf), acc + L.gphi_off(hf), logt, ct->pc_gval, c->ctype, split ? ct->item_mid : nullptr,
-            split ? hf + 1 : 0, nbat, ct->n_rows, (int64_t)al_};
+            split ? hf + 1 : 0, nbat, ct->n_rows, (int64_t)al_, ct->pc_pad};
         launch_col_pass(KP, ca, st);
       }
     }

@@ -47,6 +47,12 @@
 
 namespace spmf {
 
+#ifndef COL_WIDE
+#define COL_WIDE 1
+#endif
+#ifndef COL_WIDE_WAVES
+#define COL_WIDE_WAVES 4
+#endif
 #ifndef COL_GRP
 #define COL_GRP 4
 #endif
@@ -197,6 +203,164 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
   if (ok && sub == 0 && gph != 0.f) atomicAdd(&gphi[d], gph);
 }
 
+// ---- the same pass with 16-B entry fetches (needs padded panel-CSC arrays) ----
+// LIK: 0 Poisson / linear, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
+template <int KP, int LIK>
+__global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
+    int D, int n_panels, int row_base, int blocks_per_panel,
+    const int32_t* __restrict__ item_ptr, const int4* __restrict__ items,
+    const int32_t* __restrict__ pc_row, const float* __restrict__ pc_val,
+    const float* __restrict__ pc_gval, const float* __restrict__ Vp,
+    const float* __restrict__ phi, const float* __restrict__ z, const float* __restrict__ gzs,
+    float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi,
+    const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel,
+    int64_t Brows, int64_t acc_stride) {
+  if (gridDim.y > 1) {   // S draws per launch
+    const size_t sd = blockIdx.y;
+    Vp += sd * (size_t)D * KP;
+    phi += sd * (size_t)D;
+    z += sd * (size_t)Brows * KP;
+    gzs += sd * (size_t)Brows * KP;
+    gAp += sd * (size_t)acc_stride;
+    gVp += sd * (size_t)acc_stride;
+    gphi += sd * (size_t)acc_stride;
+  }
+  constexpr int LPN = KP / 4;
+  constexpr int NG = 64 / LPN;                        // items per wave
+  constexpr int GRP = LPN < COL_GRP ? LPN : COL_GRP;  // entries gathered back to back
+  __shared__ __attribute__((aligned(16))) float stage[4][NG][2 * KP];
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPN, grp = lane / LPN;
+  const int wid = threadIdx.x >> 6;
+  // block id -> (panel, block of 4*NG items); blockIdx % 8 = panel residue
+  // (batches of fewer than 8 panels use a flat mapping: the residue mapping
+  // would leave the XCDs of the missing residues with empty workgroups only)
+  const int64_t L = blockIdx.x;
+  int p, ib;
+  if (n_panels < 8) {
+    p = (int)(L / blocks_per_panel);
+    ib = (int)(L % blocks_per_panel);
+  } else {
+    const int x = (int)(L & 7);
+    const int64_t q = L >> 3;
+    p = 8 * (int)(q / blocks_per_panel) + x;
+    ib = (int)(q % blocks_per_panel);
+  }
+  if (p >= n_panels) return;                          // block-uniform
+  // item range of this launch: the whole panel, or one column half of it (the host
+  // sorts a panel's items by half first: multi-GPU overlap of the all-reduce)
+  const int ilo = half_sel == 2 ? item_mid[p] : item_ptr[p];
+  const int ihi = half_sel == 1 ? item_mid[p] : item_ptr[p + 1];
+  const int i0 = ilo + ib * 4 * NG;
+  if (i0 >= ihi) return;                              // block-uniform
+  const int it = i0 + wid * NG + grp;
+  const bool ok = it < ihi;
+  int cur = 0, end = 0, d = 0;
+  if (ok) {
+    const int4 im = items[it];
+    cur = im.x;
+    end = im.x + im.y;
+    d = im.z;
+  }
+  const float4 vp = ok ? gather4<LPN>(Vp, d, sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float ph = ok ? phi[d] : 1.f;
+  const bool bern = LIK == 2 || LIK == 4 || (LIK == 3 && ok && ctype[d]);   // item's column is Bernoulli
+  float4 gV = make_float4(0.f, 0.f, 0.f, 0.f), gA = gV;
+  float gph = 0.f;
+
+  // Wide fetch: every lane reads FOUR consecutive entries of its group's list (one 16-B
+  // load per array; list starts are only 4-B aligned), so a fetch covers 4*LPN entries =
+  // one 128-B line per group and array at K = 32, against one 32-B piece of a line per
+  // 8 entries in col_pass_kernel (four times the vector-cache line slots for the same
+  // bytes).  Reads up to 4*LPN - 1 entries past the end of a list: the caller guarantees
+  // that much readable padding behind the panel-CSC arrays (spmf_counts.pc_pad).
+  struct __attribute__((packed, aligned(4))) I4 { int x, y, z, w; };
+  struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+  constexpr int FE = 4 * LPN;                         // entries per fetch and group
+  auto fetch = [&](int (&rr_)[4], float (&xx_)[4], float (&gx_)[4], int& cnt_) {
+    cnt_ = min(FE, end - cur);                        // 0 once the item is exhausted
+    const int e = cur + 4 * sub;
+    I4 r = {0, 0, 0, 0};
+    F4 x = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+    if (4 * sub < cnt_) {
+      r = *reinterpret_cast<const I4*>(pc_row + e);
+      x = *reinterpret_cast<const F4*>(pc_val + e);
+      if (LIK == 1 || LIK == 4) g = *reinterpret_cast<const F4*>(pc_gval + e);
+    }
+    const int left = cnt_ - 4 * sub;                  // valid components of this lane
+    rr_[0] = left > 0 ? r.x - row_base : 0; xx_[0] = left > 0 ? x.x : 0.f; gx_[0] = left > 0 ? g.x : 0.f;
+    rr_[1] = left > 1 ? r.y - row_base : 0; xx_[1] = left > 1 ? x.y : 0.f; gx_[1] = left > 1 ? g.y : 0.f;
+    rr_[2] = left > 2 ? r.z - row_base : 0; xx_[2] = left > 2 ? x.z : 0.f; gx_[2] = left > 2 ? g.z : 0.f;
+    rr_[3] = left > 3 ? r.w - row_base : 0; xx_[3] = left > 3 ? x.w : 0.f; gx_[3] = left > 3 ? g.w : 0.f;
+    cur += cnt_;
+  };
+
+  int rr0[4], rr1[4], cnt0, cnt1;
+  float xx0[4], xx1[4], gx0[4], gx1[4];
+  fetch(rr0, xx0, gx0, cnt0);
+  while (__any(cnt0 > 0)) {
+    fetch(rr1, xx1, gx1, cnt1);                       // one fetch (4*LPN entries) ahead of use
+#pragma unroll
+    for (int g0 = 0; g0 < FE; g0 += GRP) {
+      if (__any(cnt0 > g0)) {                         // wave-uniform
+        float4 zz[GRP], gg[GRP];
+        float xv[GRP], gv[GRP];
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const int q = g0 + j;                       // entry q of the fetch: lane q/4, component q%4
+          const int src = grp * LPN + q / 4;
+          const int b = __shfl(rr0[q % 4], src);
+          xv[j] = __shfl(xx0[q % 4], src);
+          gv[j] = (LIK == 1 || LIK == 4) ? __shfl(gx0[q % 4], src) : xv[j];
+          zz[j] = gather4<LPN>(z, b, sub);
+          gg[j] = gather4<LPN>(gzs, b, sub);
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          if (bern) {
+            float wv = xv[j];
+            if (LIK == 4) wv *= expf(fminf(group_sum<LPN>(dot4(zz[j], vp)), kYSat));
+            gV = fma4(wv, zz[j], gV);
+            gA = fma4(gv[j], gg[j], gA);
+            gph += xv[j];
+          } else {
+            const float y = group_sum<LPN>(dot4(zz[j], vp));
+            const float ey = LIK == 1 ? expf(fminf(y, kYSat)) : 1.f;
+            const float r = (LIK == 1 ? ey - 1.f : y) + ph;
+            const float xr = (r > 0.f && r < INFINITY) ? xv[j] * __builtin_amdgcn_rcpf(r)
+                                                       : (xv[j] > 0.f ? 1.f : 0.f);
+            gV = fma4(LIK == 1 ? xr * ey : xr, zz[j], gV);
+            gA = fma4(gv[j], gg[j], gA);
+            gph += xr;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { rr0[t] = rr1[t]; xx0[t] = xx1[t]; gx0[t] = gx1[t]; }
+    cnt0 = cnt1;
+  }
+  // ---- transpose through LDS so each atomic instruction covers whole rows --
+  float4* st4 = reinterpret_cast<float4*>(&stage[wid][grp][0]);
+  st4[sub] = gV;
+  st4[LPN + sub] = gA;
+  __builtin_amdgcn_wave_barrier();
+  const float* flat = &stage[wid][0][0];
+#pragma unroll
+  for (int i = 0; i < (NG * 2 * KP) / 64; ++i) {
+    const int e = i * 64 + lane;
+    const int c = e / (2 * KP), rem = e % (2 * KP);
+    const int dd = __shfl(d, c * LPN);                // column of group c's item
+    const int okc = __shfl((int)ok, c * LPN);
+    const float v = flat[e];
+    if (okc && v != 0.f) {
+      float* dst = (rem >= KP ? gAp + (size_t)dd * KP + (rem - KP) : gVp + (size_t)dd * KP + rem);
+      atomicAdd(dst, v);
+    }
+  }
+  if (ok && sub == 0 && gph != 0.f) atomicAdd(&gphi[d], gph);
+}
+
 template <int KP>
 static void launch_col_t(const ColArgs& a, hipStream_t st) {
   constexpr int NG = 64 / (KP / 4);
@@ -206,18 +370,23 @@ static void launch_col_t(const ColArgs& a, hipStream_t st) {
   const int64_t nt = (a.n_panels + 7) / 8;
   const int64_t nb = a.n_panels < 8 ? (int64_t)a.n_panels * bpp : nt * bpp * 8;
   const int4* items = reinterpret_cast<const int4*>(a.items);
-#define SPMF_COL_LAUNCH(L_)                                                                    \
-  hipLaunchKernelGGL((col_pass_kernel<KP, L_>), dim3((unsigned)nb, a.S > 1 ? a.S : 1),         \
-                     dim3(256), 0, st, a.D,                                                    \
-                     a.n_panels, a.row_base, bpp, a.item_ptr, items, a.pc_row, a.pc_val,       \
-                     a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, a.gphi, a.ctype,          \
-                     a.item_mid, a.half_sel, a.B, a.acc_stride)
+#define SPMF_COL_ARGS                                                                            \
+  dim3((unsigned)nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, a.D, a.n_panels, a.row_base, bpp,   \
+      a.item_ptr, items, a.pc_row, a.pc_val, a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, \
+      a.gphi, a.ctype, a.item_mid, a.half_sel, a.B, a.acc_stride
+  const bool wide = COL_WIDE && a.pc_pad >= KP - 1;   // 4*LPN - 1 entries of readable padding
+#define SPMF_COL_LAUNCH(L_)                                                              \
+  do {                                                                                   \
+    if (wide) hipLaunchKernelGGL((col_pass_wide_kernel<KP, L_>), SPMF_COL_ARGS);         \
+    else hipLaunchKernelGGL((col_pass_kernel<KP, L_>), SPMF_COL_ARGS);                   \
+  } while (0)
   if (a.logt == 4) SPMF_COL_LAUNCH(4);
   else if (a.logt == 3) SPMF_COL_LAUNCH(3);
   else if (a.logt == 2) SPMF_COL_LAUNCH(2);
   else if (a.logt == 1) SPMF_COL_LAUNCH(1);
   else SPMF_COL_LAUNCH(0);
 #undef SPMF_COL_LAUNCH
+#undef SPMF_COL_ARGS
 }
 
 void launch_col_pass(int KP, const ColArgs& a, hipStream_t st) {

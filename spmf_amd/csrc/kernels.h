@@ -58,6 +58,7 @@ struct ColArgs {
   // z / gzs and s * acc_stride to gAp / gVp / gphi
   int S;
   int64_t B, acc_stride;
+  int pc_pad = 0;           // readable entries behind the last list of pc_row / pc_val / pc_gval
 };
 
 struct ExpdotArgs {

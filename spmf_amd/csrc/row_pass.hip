@@ -36,6 +36,9 @@ namespace spmf {
 #ifndef ROW_MAX_BLOCKS
 #define ROW_MAX_BLOCKS 4096
 #endif
+#ifndef ROW_BAL
+#define ROW_BAL 0
+#endif
 #ifndef ROW_WAVES_PER_SIMD
 #define ROW_WAVES_PER_SIMD 1
 #endif
@@ -65,22 +68,61 @@ struct RowCtx {
   int lane, sub, grp;
 
   // z partial: zacc += sum over the chunk of x * A'_d
+  template <int CNT>
+  __device__ __forceinline__ void s1_group(int c, float x, int g0, float4& zacc) const {
+    float4 a[CNT];
+    float xv[CNT];
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+      const int src = (g0 + j) * NPI + grp;
+      const int d = __shfl(c, src);
+      xv[j] = __shfl(x, src);
+      a[j] = gather4<LPN>(Ap, d, sub);
+    }
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) zacc = fma4(xv[j], a[j], zacc);
+  }
   __device__ __forceinline__ void sweep1(int c, float x, int nchunk, float4& zacc) const {
 #pragma unroll
     for (int g0 = 0; g0 < LPN; g0 += GRP) {
-      if (g0 * NPI < nchunk) {  // wave-uniform
-        float4 a[GRP];
-        float xv[GRP];
+#if ROW_BAL
+      // gather instructions carrying entries in this group of GRP (wave-uniform): the
+      // last group of a chunk issues only those
+      const int cnt = (nchunk - g0 * NPI + NPI - 1) / NPI;
+      if (cnt >= GRP) s1_group<GRP>(c, x, g0, zacc);
+      else if (GRP > 3 && cnt == 3) s1_group<(GRP > 3 ? 3 : 1)>(c, x, g0, zacc);
+      else if (GRP > 2 && cnt == 2) s1_group<(GRP > 2 ? 2 : 1)>(c, x, g0, zacc);
+      else if (cnt >= 1) s1_group<1>(c, x, g0, zacc);
+#else
+      if (g0 * NPI < nchunk) s1_group<GRP>(c, x, g0, zacc);  // wave-uniform
+#endif
+    }
+  }
+
+  // sweep-2 pieces of one group of GRP gather instructions of which CNT carry entries
+  template <int CNT>
+  __device__ __forceinline__ void s2_gather(int c, int g0, const float4& z, float4 (&vv)[LPN],
+                                            float& rmine) const {
 #pragma unroll
-        for (int j = 0; j < GRP; ++j) {
-          const int src = (g0 + j) * NPI + grp;
-          const int d = __shfl(c, src);
-          xv[j] = __shfl(x, src);
-          a[j] = gather4<LPN>(Ap, d, sub);
-        }
+    for (int j = 0; j < CNT; ++j) {
+      const int d = __shfl(c, (g0 + j) * NPI + grp);
+      vv[g0 + j] = gather4<LPN>(Vp, d, sub);
+    }
 #pragma unroll
-        for (int j = 0; j < GRP; ++j) zacc = fma4(xv[j], a[j], zacc);
-      }
+    for (int j = 0; j < CNT; ++j) {
+      const float dot = group_sum<LPN>(dot4(z, vv[g0 + j]));
+      if (sub == g0 + j) rmine = dot;
+    }
+#pragma unroll
+    for (int j = CNT; j < GRP; ++j) vv[g0 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  template <int CNT>
+  __device__ __forceinline__ void s2_back(float cc, int g0, const float4 (&vv)[LPN],
+                                          float4& gz) const {
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+      const float cb = __shfl(cc, grp * LPN + g0 + j);
+      gz = fma4(cb, vv[g0 + j], gz);
     }
   }
 
@@ -91,21 +133,17 @@ struct RowCtx {
     float rmine = 0.f;
 #pragma unroll
     for (int g0 = 0; g0 < LPN; g0 += GRP) {
-      if (g0 * NPI < nchunk) {
-#pragma unroll
-        for (int j = 0; j < GRP; ++j) {
-          const int d = __shfl(c, (g0 + j) * NPI + grp);
-          vv[g0 + j] = gather4<LPN>(Vp, d, sub);
-        }
-#pragma unroll
-        for (int j = 0; j < GRP; ++j) {
-          const float dot = group_sum<LPN>(dot4(z, vv[g0 + j]));
-          if (sub == g0 + j) rmine = dot;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < GRP; ++j) vv[g0 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+#if ROW_BAL
+      const int cnt = (nchunk - g0 * NPI + NPI - 1) / NPI;
+      if (cnt >= GRP) s2_gather<GRP>(c, g0, z, vv, rmine);
+      else if (GRP > 3 && cnt == 3) s2_gather<(GRP > 3 ? 3 : 1)>(c, g0, z, vv, rmine);
+      else if (GRP > 2 && cnt == 2) s2_gather<(GRP > 2 ? 2 : 1)>(c, g0, z, vv, rmine);
+      else if (cnt >= 1) s2_gather<1>(c, g0, z, vv, rmine);
+      else s2_gather<0>(c, g0, z, vv, rmine);
+#else
+      if (g0 * NPI < nchunk) s2_gather<GRP>(c, g0, z, vv, rmine);
+      else s2_gather<0>(c, g0, z, vv, rmine);
+#endif
     }
     // one entry per lane: lane (grp,sub) owns slot sub*NPI+grp
     const int slot = sub * NPI + grp;
@@ -145,13 +183,15 @@ struct RowCtx {
     }
 #pragma unroll
     for (int g0 = 0; g0 < LPN; g0 += GRP) {
-      if (g0 * NPI < nchunk) {
-#pragma unroll
-        for (int j = 0; j < GRP; ++j) {
-          const float cb = __shfl(cc, grp * LPN + g0 + j);
-          gz = fma4(cb, vv[g0 + j], gz);
-        }
-      }
+#if ROW_BAL
+      const int cnt = (nchunk - g0 * NPI + NPI - 1) / NPI;
+      if (cnt >= GRP) s2_back<GRP>(cc, g0, vv, gz);
+      else if (GRP > 3 && cnt == 3) s2_back<(GRP > 3 ? 3 : 1)>(cc, g0, vv, gz);
+      else if (GRP > 2 && cnt == 2) s2_back<(GRP > 2 ? 2 : 1)>(cc, g0, vv, gz);
+      else if (cnt >= 1) s2_back<1>(cc, g0, vv, gz);
+#else
+      if (g0 * NPI < nchunk) s2_back<GRP>(cc, g0, vv, gz);
+#endif
     }
   }
 };
@@ -161,6 +201,21 @@ struct RowCtx {
 // BT: threads per workgroup.  256: phi from global memory.  512 / 1024: phi staged in LDS
 // (4*D bytes of dynamic LDS: two workgroups per CU up to D = 20 480, one up to 40 960),
 // four waves per SIMD either way.
+// Length of the first register chunk of a short row (<= 128 entries).  Balanced: both
+// chunks get half of the row's gather instructions (100 entries: 56 + 44 = 7 + 6
+// instructions instead of 64 + 36 = 8 + 8 with the whole-group guard).
+template <int KP>
+__device__ __forceinline__ int row_first_len(int n) {
+#if ROW_BAL
+  constexpr int NPI = 64 / (KP / 4);
+  if (n <= 64) return n;
+  const int ni = (n + NPI - 1) / NPI;
+  return NPI * ((ni + 1) >> 1);
+#else
+  return n < 64 ? n : 64;
+#endif
+}
+
 template <int KP, int LIK, int BT = 256>
 __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pass_kernel(
     int64_t B, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
@@ -215,9 +270,10 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     start = row_ptr[wave];
     end = row_ptr[wave + 1];
     xi = row_scale ? row_scale[wave] : 1.f;
-    const int i0 = start + lane, i1 = start + 64 + lane;
-    pc0 = i0 < end ? __builtin_nontemporal_load(&col[i0]) : 0;
-    px0 = i0 < end ? __builtin_nontemporal_load(&val[i0]) : 0.f;
+    const int f0 = row_first_len<KP>(end - start);
+    const int i0 = start + lane, i1 = start + f0 + lane;
+    pc0 = lane < f0 ? __builtin_nontemporal_load(&col[i0]) : 0;
+    px0 = lane < f0 ? __builtin_nontemporal_load(&val[i0]) : 0.f;
     pc1 = i1 < end ? __builtin_nontemporal_load(&col[i1]) : 0;
     px1 = i1 < end ? __builtin_nontemporal_load(&val[i1]) : 0.f;
   }
@@ -232,9 +288,10 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     int qc0 = 0, qc1 = 0, nnstart = 0, nnend = 0;
     float qx0 = 0.f, qx1 = 0.f, nnxi = 1.f;
     if (b + nwaves < B) {
-      const int j0 = nstart + lane, j1 = nstart + 64 + lane;
-      qc0 = j0 < nend ? __builtin_nontemporal_load(&col[j0]) : 0;
-      qx0 = j0 < nend ? __builtin_nontemporal_load(&val[j0]) : 0.f;
+      const int f0 = row_first_len<KP>(nend - nstart);
+      const int j0 = nstart + lane, j1 = nstart + f0 + lane;
+      qc0 = lane < f0 ? __builtin_nontemporal_load(&col[j0]) : 0;
+      qx0 = lane < f0 ? __builtin_nontemporal_load(&val[j0]) : 0.f;
       qc1 = j1 < nend ? __builtin_nontemporal_load(&col[j1]) : 0;
       qx1 = j1 < nend ? __builtin_nontemporal_load(&val[j1]) : 0.f;
     }
@@ -250,7 +307,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       // ---- short row: col/val stay in registers for both sweeps ----------
       const int c0 = pc0, c1 = pc1;
       const float x0 = px0, x1 = px1;
-      const int n0 = min(n, 64), n1 = n - 64;
+      const int n0 = row_first_len<KP>(n), n1 = n - n0;
       if (mode != 2) {
         cx.sweep1(c0, x0, n0, zacc);
         if (n1 > 0) cx.sweep1(c1, x1, n1, zacc);

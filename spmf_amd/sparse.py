@@ -24,6 +24,9 @@ from . import _lib
 
 DEFAULT_PANEL_ROWS = 8192
 SEGMENT_ENTRIES = 256     # longest run of one column a single lane group streams
+#: zero entries appended to pc_row / pc_val / pc_gval: the column pass reads list entries
+#: four per lane (spmf_counts.pc_pad, include/spmf_hip.h) and may run this far past a list
+PC_PAD = 64
 
 
 def _as_csr_arrays(x):
@@ -116,8 +119,10 @@ class SparseCounts:
         key = (rows // P) * D + self.col_idx.to(torch.int64)
         # stable: ties keep CSR (ascending row) order -> deterministic lists
         order = torch.sort(key, stable=True).indices
-        self.pc_row = rows[order].to(torch.int32).contiguous()
-        self.pc_val = self.val[order].contiguous()
+        self.pc_row = torch.cat([rows[order].to(torch.int32),
+                                 torch.zeros(PC_PAD, dtype=torch.int32, device=dev)]).contiguous()
+        self.pc_val = torch.cat([self.val[order],
+                                 torch.zeros(PC_PAD, dtype=torch.float32, device=dev)]).contiguous()
         cnt = torch.bincount(key, minlength=nP * D)
         excl = torch.zeros(nP * D + 1, dtype=torch.int64, device=dev)
         excl[1:] = torch.cumsum(cnt, 0)
@@ -236,7 +241,9 @@ class SparseCounts:
             cnt = (ptr[:, 1:] - ptr[:, :-1]).reshape(-1)
             cols = torch.repeat_interleave(
                 torch.arange(nP * D, device=self.device, dtype=torch.int64) % D, cnt)
-            pc_gval = torch.log1p(self.pc_val / eta[cols]).contiguous()
+            pc_gval = torch.cat([torch.log1p(self.pc_val[:self.nnz] / eta[cols]),
+                                 torch.zeros(PC_PAD, dtype=torch.float32,
+                                             device=self.device)]).contiguous()
             held[key] = (eta_dev, gval, pc_gval)
             while len(held) > self._MAX_G_KEYS:
                 old = next(iter(held))
@@ -278,6 +285,7 @@ class SparseCounts:
         cs.items = self.items.data_ptr()
         cs.max_items_per_panel = (int(self.items_per_panel[p0:p1].max())
                                   if self.items.numel() else 0)
+        cs.pc_pad = PC_PAD
         if self.col_split > 0:
             cs.item_mid = self.item_mid.data_ptr() + 4 * p0
             cs.col_split = self.col_split

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libspmf_hip with extra -D flags into spmf_amd/variants/libspmf_<name>.so
+# (kernel experiments: select with SPMF_LIB_PATH; *.so is git-ignored but travels with gpurun).
+# usage: tools/build_variant.sh <name> "<extra flags>"
+set -e
+name=$1; extra=$2
+root=$(cd "$(dirname "$0")/.." && pwd)
+src=$root/spmf_amd/csrc
+out=$root/spmf_amd/variants
+tmp=$(mktemp -d)
+mkdir -p $out
+for f in api prep row_pass col_pass finish stats dense dense_ll surrogate; do
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -DSPMF_BUILD --offload-arch=gfx950 \
+      -Wno-unused-function -I$root/include -I$src $extra -c $src/$f.hip -o $tmp/$f.o ) &
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,--version-script=$src/exports.map $tmp/*.o -o $out/libspmf_$name.so -ldl
+rm -rf $tmp
+echo built $out/libspmf_$name.so

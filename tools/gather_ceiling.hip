@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -114,7 +115,13 @@ int main(int argc, char** argv) {
          (long long)n);
   printf("%-10s %-6s %-7s %-4s %-7s %9s %9s\n", "table_MB", "rowB", "tables", "grp", "blocks", "ms",
          "TB/s");
-  const double table_mb[] = {1.0, 2.56, 4.0, 5.12, 8.0};
+  // argv[2]: comma-separated list of TOTAL resident MB (default: the round-2 sweep);
+  // 0.016 / 0.064 = L1-resident / just past L1: what the per-CU vector cache alone delivers
+  std::vector<double> table_mb = {1.0, 2.56, 4.0, 5.12, 8.0};
+  if (argc > 2) {
+    table_mb.clear();
+    for (char* t = strtok(argv[2], ","); t; t = strtok(nullptr, ",")) table_mb.push_back(atof(t));
+  }
   for (double mb : table_mb) {
     for (int rowb : {128, 256}) {
       for (int tables : {1, 2}) {
