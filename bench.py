@@ -158,6 +158,11 @@ def c1_dense_cpu_baseline():
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries below this script print there too
+    # (RCCL writes a version banner from C when a communicator is created), so file
+    # descriptor 1 is pointed at stderr for the whole run and the line goes to the real one.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -322,6 +327,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     import ctypes as C
+    sat0 = float(model.last_saturated.sum())     # saturation events of the last timed step
     ms5 = (C.c_float * 6)()
     _lib.check(h, lib.spmf_last_timing(h, ms5), "spmf_last_timing")
     lib.spmf_ctx_enable_timing(h, 0)
@@ -331,18 +337,23 @@ def main():
     dt = float(tmax[0])
 
     # extras SURVEY 8(d) asks to report beside the headline (1 GPU only, not `value`):
-    # S=20 draws per step (tests/spmf_test.py:39) and a B~20000-row minibatch
+    # S=20 draws per step (tests/spmf_test.py:39), a B~20000-row minibatch, the 125k-row
+    # shard of the 8-GPU configuration with its N-independent part, a one-rank RCCL
+    # all-reduce of the packed accumulators, and the step again after 50 seeded Adam steps
     extras = {}
+
+    def timed(fn, n, w):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t_) / n
+
+    import ctypes as C
     if world == 1 and not args.no_extras and not logt and mixed_mask is None:
-        def timed(fn, n, w):
-            for _ in range(w):
-                fn()
-            torch.cuda.synchronize()
-            t_ = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return 1e3 * (time.perf_counter() - t_) / n
         torch.manual_seed(gen_seed)
         p20 = model.surrogate_distribution.sample(20)
         extras["S20_ms_per_step"] = timed(lambda: model.energy_and_grads(batch, p20), 2, 1)
@@ -351,6 +362,58 @@ def main():
         mb = {"counts": sc, "panels": (0, npan)}
         extras["minibatch_rows"] = min(sc.n_rows, npan * sc.panel_rows)
         extras["minibatch_ms_per_step"] = timed(lambda: model.energy_and_grads(mb, params), 50, 5)
+        # the per-GPU shard of the 8-GPU run (whole panels: 15 x 8192 = 122 880 rows) on this
+        # one GPU: its step, the kernel taps, and what does not shrink with N (step - row - col)
+        npan_s = max(1, min(sc.n_panels, 125_000 // sc.panel_rows))
+        sb = {"counts": sc, "panels": (0, npan_s)}
+        lib.spmf_ctx_enable_timing(h, 1)
+        sh_ms = timed(lambda: model.energy_and_grads(sb, params), 50, 5)
+        ms_s = (C.c_float * 6)()
+        _lib.check(h, lib.spmf_last_timing(h, ms_s), "spmf_last_timing")
+        lib.spmf_ctx_enable_timing(h, 0)
+        extras["shard125k_rows"] = min(sc.n_rows, npan_s * sc.panel_rows)
+        extras["shard125k_ms_per_step"] = sh_ms
+        extras["shard125k_kernel_ms"] = {"prep": round(ms_s[0], 4), "row_pass": round(ms_s[1], 4),
+                                         "col_pass": round(ms_s[2], 4), "finish": round(ms_s[3], 4)}
+        extras["shard125k_fixed_us"] = 1e3 * (sh_ms - ms_s[1] - ms_s[2])
+        # one-rank RCCL all-reduce of the packed accumulators through the library's own
+        # communicator (the transport of SPMF_BENCH_COMM=lib), back to back on the stream
+        try:
+            from spmf_amd.dist import LibraryComm
+            comm1 = LibraryComm(model, rank=0, world=1)
+            n_acc = int(lib.spmf_acc_len(h, 1))
+            accv = torch.zeros(n_acc, dtype=torch.float32, device=dev)
+            extras["allreduce_1rank_us"] = 1e3 * timed(lambda: comm1.all_reduce_(accv), 200, 20)
+            extras["allreduce_floats"] = n_acc
+            # the multi-GPU step's critical path on one rank: data pass, prior half of the
+            # finish on the side stream, spmf_allreduce, data half of the finish
+            from spmf_amd.dist import ShardReducer
+            red1 = ShardReducer(comm=comm1)
+            red1.set_batch_totals(extras["shard125k_rows"],
+                                  float(sc.row_lgamma[:extras["shard125k_rows"]].sum()))
+            extras["shard125k_1rank_rccl_ms_per_step"] = timed(
+                lambda: model.energy_and_grads(sb, params, all_reduce=red1), 50, 5)
+            _lib.check(h, lib.spmf_comm_destroy(h), "spmf_comm_destroy")
+        except Exception as e:                      # no librccl on the box: report, do not fail
+            extras["allreduce_1rank_us"] = None
+            extras["allreduce_error"] = str(e)[:120]
+    if world == 1 and not args.no_extras:
+        # "surrogate at its init values and after 50 seeded Adam steps" -- the same
+        # energy + gradient step timed again at draws from the trained surrogate
+        from spmf_amd import vi as _vi
+        opt50 = _vi.AdamHIP(model, model.surrogate_distribution.trainable_variables, 1e-2)
+        opt50.init_state(10.0)
+        torch.manual_seed(gen_seed + 50)
+        for _ in range(50):
+            _vi.vi_step_dev(model, opt50, batch, rows_g, S)
+        st50 = opt50.read_state()
+        p50 = model.surrogate_distribution.sample(S)
+        extras["after50_ms_per_step"] = timed(lambda: model.energy_and_grads(batch, p50),
+                                              max(3, min(args.steps, 20)), 2)
+        extras["after50_saturated"] = float(model.last_saturated.sum())
+        extras["after50_steps_applied"] = int(st50[11])
+        extras["after50_loss"] = st50[8]
+        del p50
 
     # extra (not the contract's `value`): the whole VI step -- base noise, surrogate
     # transform + log q, energy + gradient, chain to the trainables, Adam -- per step
@@ -455,6 +518,7 @@ def main():
             "vi_step_ms": vi_ms,
             "also": extras,
             "n_nonfinite": float(nnf.sum()),
+            "saturated": sat0,
             "elbo_x": float(parts["x"][0]),
         }
         if not args.no_cpu_baseline and world == 1 and not logt and mixed_mask is None:
@@ -474,7 +538,7 @@ def main():
             out["also"]["c1_dense_fp64_cpu_threads"] = c1_cores
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 

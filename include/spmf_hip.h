@@ -204,7 +204,12 @@ int64_t spmf_acc_len(const spmf_ctx* ctx, int S); /* floats, all S draws */
  * it runs while the collective leaves the GPU mostly idle (beside the sparse
  * passes it costs them more than it hides: 3.60 -> 3.80 ms on C3).
  * spmf_finish with the same S, parts and grads then joins the side stream and
- * adds the data half only; without this call it does both halves itself. */
+ * adds the data half only; without this call it does both halves itself.
+ * Order: it writes per-workgroup partial sums into the workspace a data pass has
+ * bound, so it must FOLLOW a spmf_data_pass on the current workspace;
+ * spmf_ctx_set_workspace / spmf_ctx_set_e_cap forget that binding, and until the next
+ * data pass spmf_prior_async, spmf_finish and spmf_nonfinite_patch return
+ * SPMF_E_WORKSPACE / SPMF_E_ARG (spmf_acc_ptr: NULL) instead of touching the old buffer. */
 int spmf_prior_async(spmf_ctx* ctx, int S, double prior_weight,
                      const float* const params[SPMF_NVARS], const float* eta, double* parts,
                      float* const grads[SPMF_NVARS], void* stream);
@@ -409,13 +414,16 @@ int spmf_surrogate_bwd_adam_dev(spmf_ctx* ctx, const spmf_sur_var* vars, int nva
  *   [8] loss of the last step  [9] 1 if it was applied, 0 if skipped
  *   [10] sum of applied losses  [11] applied steps  [12] skipped steps
  *   [13] steps gated so far, applied or not (the RNG step counter of spmf_sample_noise)
+ *   [14] saturation events (log_transform decoder: exp evaluated at min(y, 70); counted per
+ *        workgroup) summed over the steps gated since the caller last zeroed it
  * spmf_vi_gate computes loss = -mean_s[x + z + c*(prior - log q)]/rows from the
  * [S,14] parts of spmf_finish and log q of spmf_surrogate_fwd (SURVEY 8a row
  * 14), marks the step skipped when the loss is not finite or a stored cell's
  * log-pmf was not ("Batch loss NaN, skipping",
  * notebooks/factorizing_random_noise.ipynb:122-420), and advances [5..7],
- * [10..12].  spmf_adam_step_dev is spmf_adam_step reading every scalar from
- * state; it does nothing when [9] == 0. */
+ * [10..12], [14].  n_nonfinite is the [2*S] array spmf_finish wrote ([0:S] non-finite stored
+ * cells, [S:2S] saturation events) or NULL.  spmf_adam_step_dev is spmf_adam_step reading
+ * every scalar from state; it does nothing when [9] == 0. */
 #define SPMF_VI_STATE_LEN 16
 int spmf_vi_gate(spmf_ctx* ctx, const double* parts, const double* logq,
                  const double* n_nonfinite, int S, double c, double rows, double* state,

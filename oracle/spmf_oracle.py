@@ -359,6 +359,112 @@ def energy_and_grads(cfg: OracleConfig, counts, params):
             {"data": grads_data, "prior": grads_prior})
 
 
+# ---- the same densities as lists of their additive terms (for energy_grad_scales only) ----
+def _halfnormal_terms(y, scale, normal=False):
+    c = -0.5 * math.log(2.0 * math.pi) if normal else HALF_LOG_2_OVER_PI
+    return [c - torch.log(scale), -0.5 * (y / scale) ** 2]
+
+
+def _inverse_gamma_terms(x, a, b):
+    return [a * torch.log(b) - torch.lgamma(a), -(a + 1.0) * torch.log(x), -b / x]
+
+
+def _sqrt_inverse_gamma_terms(y, a, b):
+    return _inverse_gamma_terms(y * y, a, b) + [math.log(2.0) + torch.log(y)]
+
+
+def prior_log_prob_terms(cfg: OracleConfig, p: Dict[str, torch.Tensor]):
+    """prior_log_prob_parts with every part split into the additive terms of its closed
+    form (name -> list of tensors whose sum is that part's integrand): the pieces of the
+    entry-wise gradient yardstick.  tests/test_oracle.py asserts sum(terms) == part."""
+    K = cfg.latent_dim
+    decay = (cfg.symmetry_breaking_decay ** torch.arange(K, dtype=F64))[None, :]
+    half = torch.tensor(0.5, dtype=F64)
+    one = torch.tensor(1.0, dtype=F64)
+    tenth = torch.tensor(0.1, dtype=F64)
+    out = {}
+    if cfg.likelihood == "bernoulli":
+        out["v"] = _halfnormal_terms(p["v"], tenth, normal=True)
+        out["w"] = _halfnormal_terms(p["w"], one, normal=True)
+    elif cfg.likelihood == "mixed":
+        m = torch.as_tensor(np.asarray(cfg.extra["bernoulli_columns"], dtype=bool))
+        shift = math.log(2.0) * (~m).to(F64)      # HalfNormal = Normal + log 2 on y >= 0
+        out["v"] = _halfnormal_terms(p["v"], tenth, normal=True) + [shift * torch.ones_like(p["v"])]
+        out["w"] = _halfnormal_terms(p["w"], one, normal=True) + [shift * torch.ones_like(p["w"])]
+    else:
+        out["v"] = _halfnormal_terms(p["v"], tenth)
+        out["w"] = _halfnormal_terms(p["w"], one)
+    if not cfg.horseshoe_plus:
+        out["u"] = [abs_horseshoe_log_prob(
+            p["u"], torch.tensor(cfg.u_tau_scale, dtype=F64) * decay * torch.ones_like(p["u"]))]
+        out["s"] = [abs_horseshoe_log_prob(
+            p["s"], torch.tensor(cfg.s_tau_scale, dtype=F64) * torch.ones_like(p["s"]))]
+        return out
+    out["u"] = _halfnormal_terms(p["u"], p["u_eta"] * p["u_tau"] * decay)
+    out["s"] = _halfnormal_terms(p["s"], p["s_eta"] * p["s_tau"])
+    out["u_eta"] = _sqrt_inverse_gamma_terms(p["u_eta"], half, 1.0 / p["u_eta_a"])
+    out["u_eta_a"] = _inverse_gamma_terms(p["u_eta_a"], half, one)
+    out["u_tau"] = _sqrt_inverse_gamma_terms(p["u_tau"], half, 1.0 / p["u_tau_a"])
+    out["u_tau_a"] = _inverse_gamma_terms(
+        p["u_tau_a"], half, torch.tensor(1.0 / cfg.u_tau_scale ** 2, dtype=F64))
+    out["s_eta"] = _sqrt_inverse_gamma_terms(p["s_eta"], half, 1.0 / p["s_eta_a"])
+    out["s_eta_a"] = _inverse_gamma_terms(p["s_eta_a"], half, one)
+    out["s_tau"] = _sqrt_inverse_gamma_terms(p["s_tau"], half, 1.0 / p["s_tau_a"])
+    out["s_tau_a"] = _inverse_gamma_terms(
+        p["s_tau_a"], half, torch.tensor(1.0 / cfg.s_tau_scale ** 2, dtype=F64))
+    return out
+
+
+def _data_pieces(cfg: OracleConfig, x, p):
+    """The additive pieces of the data term whose per-cell contributions to d/d(u, v, w)
+    all carry one sign: (sum of the stored-cell part, minus the sum of the rate part,
+    z prior).  Poisson (poisson.py:178-183): xlogy(x, rate) and -rate; Bernoulli
+    (bernoulli.py:147-155): x*logit and -softplus(logit)."""
+    rate = log_likelihood_components(cfg, x, p["s"], p["u"], p["v"], p["w"])["rate"]
+    if cfg.likelihood == "bernoulli":
+        pos, neg = (x * rate).sum(), -torch.nn.functional.softplus(rate).sum()
+    elif cfg.likelihood == "mixed":
+        m = torch.as_tensor(np.asarray(cfg.extra["bernoulli_columns"], dtype=bool))
+        safe = torch.where(m, torch.ones_like(rate), rate)
+        pos = torch.where(m, x * rate, torch.xlogy(x, safe)).sum()
+        neg = -torch.where(m, torch.nn.functional.softplus(rate), safe).sum()
+    else:
+        pos, neg = torch.xlogy(x, rate).sum(), -rate.sum()
+    theta = encode(cfg, x, p["u"], p["s"])
+    return [pos, neg, (HALF_LOG_2_OVER_PI - 0.5 * theta ** 2).sum()]
+
+
+def energy_grad_scales(cfg: OracleConfig, counts, params, prior_weight: float = 1.0,
+                       data=True, prior=True):
+    """Yardstick for a gradient comparison "within 1e-5 relative" (north_star) that an
+    entry-wise test can use: for every entry of every gradient, the sum over the energy's
+    additive pieces of |d piece / d entry| -- pieces = stored-cell part of the likelihood,
+    minus-rate part, z prior, and every additive term of the twelve prior log-densities
+    (prior_log_prob_terms: -log sigma and -y^2/2sigma^2 are two pieces, so (q^2 - 1)/sigma is
+    measured against (q^2 + 1)/sigma).  The rate is increasing in
+    u, v, w (both decoders; Bernoulli: in v, w), so inside one piece every cell's
+    contribution has the same sign and |d piece| IS the sum of the absolute contributions;
+    where signs do mix inside a piece (s: its two rows pull opposite ways; u under Bernoulli
+    with negative v) this is smaller than that sum, i.e. a stricter yardstick.  A gradient
+    entry that is ~0 only because its contributions cancel is then measured against what
+    cancelled, not against the largest entry of the array."""
+    x = _t(counts)
+    p = {k: _t(v).clone().requires_grad_(True) for k, v in params.items()}
+    names = list(p.keys())
+    pieces = _data_pieces(cfg, x, p) if data else []
+    if prior:
+        for terms in prior_log_prob_terms(cfg, p).values():
+            pieces += [t.sum() * prior_weight for t in terms if t.requires_grad]
+    scale = {n: torch.zeros_like(p[n]) for n in names}
+    for i, piece in enumerate(pieces):
+        g = torch.autograd.grad(piece, [p[n] for n in names], retain_graph=i + 1 < len(pieces),
+                                allow_unused=True)
+        for n, gn in zip(names, g):
+            if gn is not None:
+                scale[n] += gn.detach().abs()
+    return scale
+
+
 # --------------------------------------------------------------------------
 # surrogate posterior as the reference initialises it (poisson.py:403-539).
 # The parameterisation inside bayesianquilts' build_trainable_* is

@@ -165,6 +165,13 @@ static int64_t est_chunk_rows(const spmf_ctx* c, int64_t rows) {
   return rows < cap ? rows : cap;
 }
 
+// E (exp / sigmoid of the logits) is kept between the two dense contractions by the exp and
+// sigmoid forms; Bernoulli + log_transform (code 4: E would have to carry exp(X) too) recomputes
+static bool uses_e_buffer(const spmf_ctx* c) {
+  return (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once &&
+         likelihood_code(c) != 4;
+}
+
 static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   Carve k;
   size_t o = 0;
@@ -172,7 +179,7 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   const size_t nd = batched_draws(c, rows, S) ? (size_t)S : 1;   // per-draw copies
   k.acc = o;   o += al((size_t)S * acc_len(c->D, c->KP) * sizeof(float));
   k.dacc = o;  o += al((size_t)S * kDaccRep * (kDaccHead + KP) * sizeof(double));
-  k.dprep = o; o += al((size_t)S * (KP + 1) * sizeof(double));
+  k.dprep = o; o += al((size_t)S * kPrepSeg * (KP + 1) * sizeof(double));
   const size_t fnb = (D + 31) / 32;                       // workgroups of the finish kernel
   k.ppart = o; o += al((size_t)S * fnb * 12 * sizeof(double));
   k.putau = o; o += al((size_t)S * fnb * KP * sizeof(float));
@@ -186,7 +193,7 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.gzs = o;   o += al(nd * (size_t)rows * KP * sizeof(float));
   k.gzd = o;   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) o += al((size_t)rows * KP * sizeof(float));
   k.est = o;
-  if ((c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once)
+  if (uses_e_buffer(c))
     o += al((size_t)((D + 31) / 32) * 32 * (size_t)est_chunk_rows(c, rows) * sizeof(float));
   k.total = o;
   return k;
@@ -265,10 +272,25 @@ int spmf_ctx_set_bernoulli_columns(spmf_ctx* c, const int32_t* cols, int n) {
   return SPMF_OK;
 }
 
+// Forget the carve of the previous workspace: until the next data pass binds the new one the
+// entry points that only READ a bound workspace (spmf_prior_async, spmf_finish,
+// spmf_nonfinite_patch, spmf_acc_ptr) fail with SPMF_E_WORKSPACE / return NULL instead of
+// touching memory the caller may have freed.
+static void unbind_ws(spmf_ctx* c) {
+  c->ws_rows = -1;
+  c->ws_S = 0;
+  c->acc = nullptr;
+  c->dacc = nullptr;
+  c->dprep = nullptr;
+  c->fpart = nullptr;
+  c->futau = nullptr;
+  c->prior_pending = 0;
+}
+
 int spmf_ctx_set_e_cap(spmf_ctx* c, size_t bytes) {
   if (!c || bytes < ((size_t)1 << 20)) return fail(c, SPMF_E_ARG, "set_e_cap: at least 1 MiB");
   c->est_cap_bytes = bytes;
-  c->ws_rows = -1;            // the carve changes: the next call re-binds (and re-checks) the workspace
+  unbind_ws(c);               // the carve changes: the next data pass re-binds (and re-checks) the workspace
   return SPMF_OK;
 }
 
@@ -283,8 +305,7 @@ int spmf_ctx_set_workspace(spmf_ctx* c, void* workspace, size_t bytes) {
       "workspace must be 256-byte aligned and non-null");
   c->ws = (char*)workspace;
   c->ws_bytes = bytes;
-  c->ws_rows = -1;
-  c->ws_S = 0;
+  unbind_ws(c);
   return SPMF_OK;
 }
 
@@ -311,8 +332,7 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   c->z = (float*)(c->ws + k.z);
   c->gzs = (float*)(c->ws + k.gzs);
   c->gzd = (float*)(c->ws + k.gzd);
-  c->est = ((c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once)
-               ? (float*)(c->ws + k.est) : nullptr;
+  c->est = uses_e_buffer(c) ? (float*)(c->ws + k.est) : nullptr;
   c->est_rows = est_chunk_rows(c, rows);
   c->ws_rows = rows;
   c->ws_S = S;
@@ -428,8 +448,8 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
   if (!split && parts_mask != 3) return fail(c, SPMF_E_ARG, "data_pass_split needs spmf_ctx_set_column_split");
   if (parts_mask != 3 && S != 1) return fail(c, SPMF_E_UNSUPPORTED, "data_pass_split: one draw per step only");
   const bool first = parts_mask & 1, second = parts_mask & 2;
-  // zero acc | dacc | dprep (contiguous in the carve)
-  if (first) launch_zero(c->acc, (size_t)((char*)c->fpart - (char*)c->acc), st);
+  // acc | dacc (contiguous in the carve) are zeroed by the first prep launch of the step,
+  // slice by slice in its tile blocks; dprep is written, not accumulated (prep.hip)
   if (c->timing && first) {
     c->ev_set = (c->ev_set + 1) % spmf_ctx::kSets;
     c->ev = c->evs[c->ev_set];
@@ -442,13 +462,18 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
     const bool tm = c->timing && s + nbat == S;
     float* acc = c->acc + (size_t)s * al_;
     double* dacc = c->dacc + (size_t)s * dacc_stride;
-    double* dprep = c->dprep + (size_t)s * (KP + 1);
+    double* dprep = c->dprep + (size_t)s * kPrepSeg * (KP + 1);
     float* gVp = acc + L.gV_off(0);
+    bool packed = false;
     if (first) {
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], st));
     PrepArgs pa{D, c->K, params[2] + s * var_size(c, 2), params[0] + s * var_size(c, 0), params[1] + s * var_size(c,
         1), params[7] + s * var_size(c, 7), eta, c->Ap, c->Vp, c->phi, dprep, lik_exp(logt) ? 1 : 0,
         logt == 3 ? c->ctype : nullptr, logt == 3 ? c->dbias : nullptr, nbat};
+    if (s == 0) {
+      pa.zero_p = c->acc;
+      pa.zero_bytes = (size_t)((char*)c->dprep - (char*)c->acc);
+    }
     launch_prep(KP, pa, st);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
     const float* rscale = (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr;
@@ -529,12 +554,23 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
             ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc + L.gA_off(hf),
             acc + L.gV_off(hf), acc + L.gphi_off(hf), logt, ct->pc_gval, c->ctype, split ? ct->item_mid : nullptr,
             split ? hf + 1 : 0, nbat, ct->n_rows, (int64_t)al_, ct->pc_pad};
-        launch_col_pass(KP, ca, st);
+        if (hf == (split ? 1 : 0)) {
+          // the fp64 scalars of the row pass are complete before this launch starts: its
+          // extra first block folds them into the accumulator tail (the former pack launch)
+          ca.pack_dacc = dacc;
+          ca.pack_tail = acc + L.tail_off();
+          ca.dacc_stride = dacc_stride;
+          packed = launch_col_pass(KP, ca, st);
+        } else {
+          launch_col_pass(KP, ca, st);
+        }
       }
     }
     if (second) {
-      PackArgs pk{KP, dacc, acc + L.tail_off(), nbat, dacc_stride, (int64_t)al_};
-      launch_pack(pk, st);
+      if (!packed) {
+        PackArgs pk{KP, dacc, acc + L.tail_off(), nbat, dacc_stride, (int64_t)al_};
+        launch_pack(pk, st);
+      }
       if (tm) {
         HIPCHK(c, hipEventRecord(c->ev[3], st));
         c->ev_valid = 1;
@@ -675,7 +711,6 @@ int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float*
   rc = bind_ws(c, ct->n_rows, 1);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  launch_zero(c->dprep, (c->KP + 1) * sizeof(double), st);
   PrepArgs pa{c->D, c->K, u, nullptr, nullptr, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt, nullptr, nullptr};
   launch_prep(c->KP, pa, st);
   RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val,
@@ -702,7 +737,6 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
   rc = bind_ws(c, ct->n_rows, 1);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  launch_zero(c->dprep, (c->KP + 1) * sizeof(double), st);
   PrepArgs pa{c->D, c->K, u, v, w, s, eta, c->Ap, c->Vp, c->phi, c->dprep, logt, nullptr, nullptr};
   launch_prep(c->KP, pa, st);
   RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val,

@@ -57,6 +57,22 @@ namespace spmf {
 #define COL_GRP 4
 #endif
 
+// The extra first block of a launch (pack_dacc != null): fold the kDaccRep replicas of the row
+// pass's fp64 scalars into the accumulator tail as (hi, lo) float pairs, so that ONE fp32
+// all-reduce finishes the step.  The row pass is a previous launch: its sums are complete.
+template <int KP>
+__device__ __forceinline__ void pack_block(const double* __restrict__ dacc, float* __restrict__ tail) {
+  const int i = threadIdx.x;
+  if (i < kDaccHead + KP) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < kDaccRep; ++r) v += dacc[(size_t)r * (kDaccHead + KP) + i];
+    const float hi = (float)v;
+    tail[2 * i] = hi;
+    tail[2 * i + 1] = (float)(v - (double)hi);
+  }
+}
+
 // LIK: 0 Poisson / linear, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
 template <int KP, int LIK>
 __global__ __launch_bounds__(256) void col_pass_kernel(
@@ -67,7 +83,12 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     const float* __restrict__ phi, const float* __restrict__ z, const float* __restrict__ gzs,
     float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi,
     const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel,
-    int64_t Brows, int64_t acc_stride) {
+    int64_t Brows, int64_t acc_stride, const double* __restrict__ pack_dacc,
+    float* __restrict__ pack_tail, int64_t dacc_stride) {
+  if (pack_dacc && blockIdx.x == 0) {
+    pack_block<KP>(pack_dacc + (size_t)blockIdx.y * dacc_stride, pack_tail + (size_t)blockIdx.y * acc_stride);
+    return;
+  }
   if (gridDim.y > 1) {   // S draws per launch
     const size_t sd = blockIdx.y;
     Vp += sd * (size_t)D * KP;
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
   // block id -> (panel, block of 4*NG items); blockIdx % 8 = panel residue
   // (batches of fewer than 8 panels use a flat mapping: the residue mapping
   // would leave the XCDs of the missing residues with empty workgroups only)
-  const int64_t L = blockIdx.x;
+  const int64_t L = (int64_t)blockIdx.x - (pack_dacc ? 1 : 0);   // block 0 is the pack block when asked
   int p, ib;
   if (n_panels < 8) {
     p = (int)(L / blocks_per_panel);
@@ -214,7 +235,12 @@ __global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
     const float* __restrict__ phi, const float* __restrict__ z, const float* __restrict__ gzs,
     float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi,
     const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel,
-    int64_t Brows, int64_t acc_stride) {
+    int64_t Brows, int64_t acc_stride, const double* __restrict__ pack_dacc,
+    float* __restrict__ pack_tail, int64_t dacc_stride) {
+  if (pack_dacc && blockIdx.x == 0) {
+    pack_block<KP>(pack_dacc + (size_t)blockIdx.y * dacc_stride, pack_tail + (size_t)blockIdx.y * acc_stride);
+    return;
+  }
   if (gridDim.y > 1) {   // S draws per launch
     const size_t sd = blockIdx.y;
     Vp += sd * (size_t)D * KP;
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
   // block id -> (panel, block of 4*NG items); blockIdx % 8 = panel residue
   // (batches of fewer than 8 panels use a flat mapping: the residue mapping
   // would leave the XCDs of the missing residues with empty workgroups only)
-  const int64_t L = blockIdx.x;
+  const int64_t L = (int64_t)blockIdx.x - (pack_dacc ? 1 : 0);   // block 0 is the pack block when asked
   int p, ib;
   if (n_panels < 8) {
     p = (int)(L / blocks_per_panel);
@@ -362,18 +388,20 @@ __global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
 }
 
 template <int KP>
-static void launch_col_t(const ColArgs& a, hipStream_t st) {
+static bool launch_col_t(const ColArgs& a, hipStream_t st) {
   constexpr int NG = 64 / (KP / 4);
   const int per_block = 4 * NG;
   const int bpp = (a.max_items_per_panel + per_block - 1) / per_block;
-  if (bpp < 1) return;
+  if (bpp < 1) return false;
   const int64_t nt = (a.n_panels + 7) / 8;
-  const int64_t nb = a.n_panels < 8 ? (int64_t)a.n_panels * bpp : nt * bpp * 8;
+  // + 1: the pack block (kernels: blockIdx.x == 0, the item blocks shift by one)
+  const int64_t nb = (a.n_panels < 8 ? (int64_t)a.n_panels * bpp : nt * bpp * 8) + (a.pack_dacc ? 1 : 0);
   const int4* items = reinterpret_cast<const int4*>(a.items);
 #define SPMF_COL_ARGS                                                                            \
   dim3((unsigned)nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, a.D, a.n_panels, a.row_base, bpp,   \
       a.item_ptr, items, a.pc_row, a.pc_val, a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, \
-      a.gphi, a.ctype, a.item_mid, a.half_sel, a.B, a.acc_stride
+      a.gphi, a.ctype, a.item_mid, a.half_sel, a.B, a.acc_stride, a.pack_dacc, a.pack_tail,     \
+      a.dacc_stride
   const bool wide = COL_WIDE && a.pc_pad >= KP - 1;   // 4*LPN - 1 entries of readable padding
 #define SPMF_COL_LAUNCH(L_)                                                              \
   do {                                                                                   \
@@ -387,16 +415,17 @@ static void launch_col_t(const ColArgs& a, hipStream_t st) {
   else SPMF_COL_LAUNCH(0);
 #undef SPMF_COL_LAUNCH
 #undef SPMF_COL_ARGS
+  return true;
 }
 
-void launch_col_pass(int KP, const ColArgs& a, hipStream_t st) {
+bool launch_col_pass(int KP, const ColArgs& a, hipStream_t st) {
   switch (KP) {
-    case 4: launch_col_t<4>(a, st); break;
-    case 8: launch_col_t<8>(a, st); break;
-    case 16: launch_col_t<16>(a, st); break;
-    case 32: launch_col_t<32>(a, st); break;
-    case 64: launch_col_t<64>(a, st); break;
-    default: break;
+    case 4: return launch_col_t<4>(a, st);
+    case 8: return launch_col_t<8>(a, st);
+    case 16: return launch_col_t<16>(a, st);
+    case 32: return launch_col_t<32>(a, st);
+    case 64: return launch_col_t<64>(a, st);
+    default: return false;
   }
 }
 

@@ -30,6 +30,10 @@ __host__ __device__ constexpr bool lik_exp(int l) { return l == 1 || l == 4; }
 __host__ __device__ constexpr bool lik_bern(int l) { return l == 2 || l == 4; }
 
 constexpr float kYSat = 70.0f;
+// The prep kernel's closed-form column sums (veta[KP], phisum) are written as kPrepSeg
+// partial sums over column segments, dprep[seg][KP+1]: one writer per slot (no atomics,
+// no zero fill), and every reader folds the segments in index order (prep_sum).
+constexpr int kPrepSeg = 8;
 // the block sums land in one of kDaccRep replicas (blockIdx % kDaccRep) so the
 // fp64 atomics of thousands of blocks do not serialise on 4+KP addresses;
 // the pack kernel folds the replicas.
@@ -59,6 +63,13 @@ struct AccLayout {
 };
 __host__ __device__ inline int64_t acc_len(int D, int KP) {
   return (int64_t)2 * D * KP + D + acc_tail_len(KP);
+}
+
+__device__ __forceinline__ double prep_sum(const double* __restrict__ dprep, int KP, int i) {
+  double t = 0.0;
+#pragma unroll
+  for (int g = 0; g < kPrepSeg; ++g) t += dprep[(size_t)g * (KP + 1) + i];
+  return t;
 }
 
 __device__ __forceinline__ float4 shfl4(float4 v, int src) {

@@ -42,6 +42,58 @@ __device__ __forceinline__ double unpack(const float* tail, int i) {
   return (double)tail[2 * i] + (double)tail[2 * i + 1];
 }
 
+// fp64 log for the log-densities.  The library routine is ~100 fp64 instructions; a block of
+// this kernel is one wave per SIMD working through a few thousand dependent instructions, so
+// the kernel's time IS that chain.  Arguments here are positive, finite fp32 values (or
+// products of two): x = m 2^e with m in [sqrt(1/2), sqrt(2)), t = (m-1)/(m+1), |t| <= 0.1716,
+// log m = 2t (1 + t^2/3 + ... + t^22/23): truncation 0.0295^12/25 ~ 2e-20 relative.  The
+// series and the range reduction are restated in numpy and compared with np.log in
+// tests/test_host.py::test_finish_fast_log_series; the device path (v_rcp_f64 + two Newton
+// steps) is covered by every GPU parity test of the energy parts.  Zero, negative, infinite and
+// NaN arguments take the library log, so a parameter that underflowed still yields -inf / NaN.
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);      // v_rcp_f64: ~1e-8 relative
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_log(double x) {
+  if (__builtin_expect(!(x > 0.0) || x > 1.7e308, 0)) return log(x);
+  const long long bits = __double_as_longlong(x);
+  int e = (int)((bits >> 52) & 0x7ff) - 1023;
+  double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);   // [1, 2)
+  if (m > 1.4142135623730951) {
+    m *= 0.5;
+    e += 1;
+  }
+  const double t = (m - 1.0) * fast_rcp(m + 1.0);
+  const double t2 = t * t;
+  double p = 1.0 / 23.0;
+  p = fma(p, t2, 1.0 / 21.0);
+  p = fma(p, t2, 1.0 / 19.0);
+  p = fma(p, t2, 1.0 / 17.0);
+  p = fma(p, t2, 1.0 / 15.0);
+  p = fma(p, t2, 1.0 / 13.0);
+  p = fma(p, t2, 1.0 / 11.0);
+  p = fma(p, t2, 1.0 / 9.0);
+  p = fma(p, t2, 1.0 / 7.0);
+  p = fma(p, t2, 1.0 / 5.0);
+  p = fma(p, t2, 1.0 / 3.0);
+  p = fma(p, t2, 1.0);
+  return fma((double)e, kLog2, 2.0 * t * p);
+}
+// decay^t for integer t >= 0 by squaring (pow() is several hundred fp64 instructions and sat
+// on every block's prologue)
+__device__ __forceinline__ double ipow(double b, int t) {
+  double r = 1.0;
+  while (t) {
+    if (t & 1) r *= b;
+    b *= b;
+    t >>= 1;
+  }
+  return r;
+}
+
 // The log-densities (the energy PARTS) are evaluated in fp64: a part is a sum
 // of O(D*K) terms of either sign, so fp32 term error would be amplified by the
 // cancellation (seen: 2.6e-5 relative on a 4307-term part).  Gradients stay fp32.
@@ -49,8 +101,8 @@ __device__ __forceinline__ double unpack(const float* tail, int i) {
 __device__ __forceinline__ void halfnormal(float y, float sig, double& lp, float& gy, float& gs) {
   const float is = 1.f / sig;
   const float q = y * is;
-  const double qd = (double)y / (double)sig;
-  lp = kHalfLog2OverPi - log((double)sig) - 0.5 * qd * qd;
+  const double qd = (double)y * fast_rcp((double)sig);
+  lp = kHalfLog2OverPi - fast_log((double)sig) - 0.5 * qd * qd;
   gy = -q * is;
   gs = (q * q - 1.f) * is;
 }
@@ -59,7 +111,7 @@ __device__ __forceinline__ void sqrt_ig(float y, float a, double& lp, float& gy,
   const float iy = 1.f / y, ia = 1.f / a;
   const float t = ia * iy * iy;  // 1/(a y^2)
   const double yd = (double)y, ad = (double)a;
-  lp = -0.5 * log(ad) - kLgammaHalf - 2.0 * log(yd) - 1.0 / (ad * yd * yd) + kLog2;
+  lp = -0.5 * fast_log(ad) - kLgammaHalf - 2.0 * fast_log(yd) - fast_rcp(ad * yd * yd) + kLog2;
   gy = -2.f * iy + 2.f * t * iy;
   ga = -0.5f * ia + t * ia;
 }
@@ -68,7 +120,7 @@ __device__ __forceinline__ void ig_half(float a, float beta, float half_log_beta
                                         float& ga) {
   const float ia = 1.f / a;
   const double ad = (double)a;
-  lp = 0.5 * log((double)beta) - kLgammaHalf - 1.5 * log(ad) - (double)beta / ad;
+  lp = 0.5 * fast_log((double)beta) - kLgammaHalf - 1.5 * fast_log(ad) - (double)beta * fast_rcp(ad);
   ga = -1.5f * ia + beta * ia * ia;
 }
 
@@ -127,7 +179,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       if (G.p[i]) G.p[i] += sd * (size_t)VS.v[i];
     }
     if (acc) acc += sd * (size_t)acc_stride;
-    if (dprep) dprep += sd * (size_t)(KP + 1);
+    if (dprep) dprep += sd * (size_t)kPrepSeg * (KP + 1);
     parts += sd * 14;
     if (nnf_out) nnf_out += sd;
   }
@@ -164,11 +216,11 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     // (mixed, code 3: still needed for the Poisson columns)
     zsum_s[t] = (!DATA || lik_exp(logt) || lik_bern(logt)) ? 0.f : (float)unpack(tail, kDaccHead + t);
     utau_s[t] = hs ? u_tau_scale : (t < K ? P.p[UTAU_][t] : 1.f);   // hs: scale = u_tau_scale * decay^k
-    dec_s[t] = (float)pow((double)decay, (double)t);   // powf is ~1e-6 off at t~60: a systematic part error
+    dec_s[t] = (float)ipow(decay, t);   // powf is ~1e-6 off at t~60: a systematic part error
     gutau_s[t] = 0.f;
     if (PRIOR) {
-      lsc_s[t] = log((double)utau_s[t]) + (double)t * log(decay);
-      scd_s[t] = (double)utau_s[t] * pow((double)decay, (double)t);
+      lsc_s[t] = fast_log((double)utau_s[t]) + (double)t * fast_log(decay);
+      scd_s[t] = (double)utau_s[t] * ipow(decay, t);
     }
   }
   if (t < FTD) {
@@ -236,9 +288,9 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
         const float sc = utau_s[k] * dec_s[k];
         // the three log-densities share their fp64 logs (software fp64 log is what
         // this kernel's time goes to): log sig = log ue + log(utau_k dec_k)
-        const double Lue = log((double)ue), Lua = log((double)ua);
+        const double Lue = fast_log((double)ue), Lua = fast_log((double)ua);
         const float sig = ue * sc, is = 1.f / sig, q = u * is;
-        const double qd = (double)u / ((double)ue * scd_s[k]);
+        const double qd = (double)u * fast_rcp((double)ue * scd_s[k]);
         part[U_] += kHalfLog2OverPi - (Lue + lsc_s[k]) - 0.5 * qd * qd;
         const float gy = -q * is, gs = (q * q - 1.f) * is;
         G.p[U_][i] = du + pw * gy;
@@ -246,10 +298,10 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
         const float iy = 1.f / ue, ia = 1.f / ua;
         const float tt = ia * iy * iy;                       // 1/(ua ue^2)
         part[UETA_] += -0.5 * Lua - kLgammaHalf - 2.0 * Lue
-                       - 1.0 / ((double)ua * (double)ue * (double)ue) + kLog2;
+                       - fast_rcp((double)ua * (double)ue * (double)ue) + kLog2;
         const float gy2 = -2.f * iy + 2.f * tt * iy, ga2 = -0.5f * ia + tt * ia;
         G.p[UETA_][i] = pw * (gs * sc + gy2);
-        part[UETAA_] += -kLgammaHalf - 1.5 * Lua - 1.0 / (double)ua;   // InvGamma(1/2, 1)
+        part[UETAA_] += -kLgammaHalf - 1.5 * Lua - fast_rcp((double)ua);   // InvGamma(1/2, 1)
         const float ga3 = -1.5f * ia + ia * ia;
         G.p[UETAA_][i] = pw * (ga2 + ga3);
       } else {
@@ -415,13 +467,13 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   if (DATA && blockIdx.x == 0 && t == 0) {
     const double llx = unpack(tail, 0), zsq = unpack(tail, 1);
     // sum of the rate over ALL cells: closed form (linear) or the dense exp sum
-    double sum_r = Bglob * dprep[KP];
+    double sum_r = Bglob * prep_sum(dprep, KP, KP);
     if (lik_bern(logt))
       sum_r = unpack(tail, 3);                 // sum over all cells of softplus(logit)
     else if (logt == 1)
       sum_r += unpack(tail, 3) - Bglob * (double)D;
     else {
-      for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * dprep[k];
+      for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * prep_sum(dprep, KP, k);
       if (logt == 3) sum_r += unpack(tail, 3);   // mixed: + softplus over the Bernoulli columns
     }
     parts[13] = llx - (lik_bern(logt) ? 0.0 : lgamma_sum) - sum_r;      // single writer

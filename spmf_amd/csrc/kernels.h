@@ -9,13 +9,17 @@ struct PrepArgs {
   int D, K;
   const float *u, *v, *w, *s, *eta;
   float *Ap, *Vp, *phi;
-  double* dprep;  // [KP+1]: veta[KP], phisum   (zeroed by the caller)
+  double* dprep;  // [kPrepSeg][KP+1]: partial sums of veta[KP], phisum (written, not accumulated;
+                  // readers fold the segments: common.h prep_sum)
   int logt;       // log_transform: A' = w1*u (g(x) is data side), V' = eta*v^T
   const uint8_t* ctype;  // mixed likelihood: 1 = Bernoulli column (may be null)
   float* dbias;          // mixed likelihood: dense-kernel logit bias per column (may be null)
   // S > 1: the launch covers S draws (gridDim.y); pointers are those of draw 0, draw s adds
-  // s * D*K to u / v, s * D to w, s * 2D to s, s * D*KP to Ap / Vp, s * D to phi, s * (KP+1) to dprep
+  // s * D*K to u / v, s * D to w, s * 2D to s, s * D*KP to Ap / Vp, s * D to phi, s * kPrepSeg*(KP+1) to dprep
   int S;
+  // optional zero fill folded into the launch (the step's acc | dacc): 16-byte multiple, or null
+  void* zero_p = nullptr;
+  size_t zero_bytes = 0;
 };
 void launch_prep(int KP, const PrepArgs& a, hipStream_t st);
 
@@ -34,7 +38,7 @@ struct RowArgs {
   const float* gzd;    // mode 2: per-row dense term sum_d E_bd V'_d  [B,KP]
   const uint8_t* ctype;  // likelihood code 3 (mixed): column types
   // S > 1 (mode 0 only): S draws per launch (gridDim.y); draw s adds s * D*KP to Ap / Vp, s * D to
-  // phi, s * (KP+1) to dprep, s * B*KP to z / gzs, s * dacc_stride to dacc
+  // phi, s * kPrepSeg*(KP+1) to dprep, s * B*KP to z / gzs, s * dacc_stride to dacc
   int S, D;
   int64_t dacc_stride;
 };
@@ -59,6 +63,11 @@ struct ColArgs {
   int S;
   int64_t B, acc_stride;
   int pc_pad = 0;           // readable entries behind the last list of pc_row / pc_val / pc_gval
+  // optional: one extra block folds the row pass's fp64 scalar block (kDaccRep replicas) into
+  // the accumulator tail as (hi, lo) float pairs -- what pack_kernel does as its own launch
+  const double* pack_dacc = nullptr;
+  float* pack_tail = nullptr;
+  int64_t dacc_stride = 0;
 };
 
 struct ExpdotArgs {
@@ -115,7 +124,7 @@ struct NfPatchArgs {
 };
 void launch_nonfinite_patch(int KP, const NfPatchArgs& a, hipStream_t st);
 void launch_nonfinite_lgamma(const DenseLLArgs& a, double* out, hipStream_t st);   // uses B, D, logt, ctype, CSR, rate
-void launch_col_pass(int KP, const ColArgs& a, hipStream_t st);
+bool launch_col_pass(int KP, const ColArgs& a, hipStream_t st);   // true: launched, with the pack block if asked
 
 struct PackArgs {
   int KP;
@@ -143,7 +152,7 @@ struct FinishArgs {
   const uint8_t* ctype;  // likelihood code 3 (mixed): column types
   int Dh;                // column split of the accumulator layout (0 / D = none; multiple of 32)
   // S > 1: S draws per launch (gridDim.y); draw s adds s * vstride[i] to params[i] / grads[i],
-  // s * acc_stride to acc, s * (KP+1) to dprep, s * 14 to parts, s to n_nonfinite
+  // s * acc_stride to acc, s * kPrepSeg*(KP+1) to dprep, s * 14 to parts, s to n_nonfinite
   int S;
   int64_t acc_stride;
   int64_t vstride[12];

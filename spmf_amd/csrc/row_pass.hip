@@ -229,7 +229,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     Ap += sd * (size_t)Dcols * KP;
     Vp += sd * (size_t)Dcols * KP;
     phi += sd * (size_t)Dcols;
-    dprep += sd * (size_t)(KP + 1);
+    dprep += sd * (size_t)kPrepSeg * (KP + 1);
     z += sd * (size_t)B * KP;
     gzs += sd * (size_t)B * KP;
     dacc += sd * (size_t)dacc_stride;
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
 
   float4 veta4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (!encode_only && (mode != 2 || LIK == 3 || !gzd))
-    veta4 = make_float4((float)dprep[sub * 4 + 0], (float)dprep[sub * 4 + 1],
-                        (float)dprep[sub * 4 + 2], (float)dprep[sub * 4 + 3]);
+    veta4 = make_float4((float)prep_sum(dprep, KP, sub * 4 + 0), (float)prep_sum(dprep, KP, sub * 4 + 1),
+                        (float)prep_sum(dprep, KP, sub * 4 + 2), (float)prep_sum(dprep, KP, sub * 4 + 3));
   double ll_acc = 0.0, zsq_acc = 0.0, nnf_acc = 0.0;
   float4 zsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -402,16 +402,28 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
   }
 }
 
+// false: the device does not grant the dynamic LDS this form needs (the caller then launches
+// the 256-thread form, which reads phi from global memory)
 template <int KP, int LIK, int BT>
-static void launch_row_lds(const RowArgs& a, hipStream_t st) {
+static bool launch_row_lds(const RowArgs& a, hipStream_t st) {
   const size_t lds = std::max((size_t)a.D * 4, (size_t)(BT / 64) * KP * sizeof(double));
-  static size_t lds_allowed = 64 * 1024;      // opt in to more dynamic LDS as far as needed
-  if (lds > lds_allowed) {
-    if (hipFuncSetAttribute((const void*)row_pass_kernel<KP, LIK, BT>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      (void)hipGetLastError();                  // not granted: clear, the launch below reports
-    } else {
-      lds_allowed = lds;
+  // opt in to more than 64 KB of dynamic LDS.  The attribute is per DEVICE (and this is one
+  // instantiation per process), so the grant is remembered per device ordinal.
+  constexpr int kMaxDev = 64;
+  static size_t granted[kMaxDev] = {};
+  if (lds > 64 * 1024) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+      (void)hipGetLastError();
+      return false;
+    }
+    if (lds > __atomic_load_n(&granted[dev], __ATOMIC_RELAXED)) {
+      if (hipFuncSetAttribute((const void*)row_pass_kernel<KP, LIK, BT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+      }
+      __atomic_store_n(&granted[dev], lds, __ATOMIC_RELAXED);
     }
   }
   const int64_t want = (a.B + (BT / 64) - 1) / (BT / 64);
@@ -427,6 +439,7 @@ static void launch_row_lds(const RowArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((row_pass_kernel<KP, LIK, BT>), dim3(nb, a.S > 1 ? a.S : 1), dim3(BT), lds, st,
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z,
                      a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride);
+  return true;
 }
 
 #ifndef ROW_LDS_PHI
@@ -443,14 +456,9 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
     if (ROW_LDS_PHI && a.mode != 1 && (a.logt == 0 || a.logt == 1) && a.B >= 4096) {
       const size_t need = (size_t)a.D * 4;
       if (need <= 80 * 1024) {
-        if (a.logt == 0) launch_row_lds<KP, 0, 512>(a, st);
-        else launch_row_lds<KP, 1, 512>(a, st);
-        return;
-      }
-      if (need <= 160 * 1024 - 1024) {
-        if (a.logt == 0) launch_row_lds<KP, 0, 1024>(a, st);
-        else launch_row_lds<KP, 1, 1024>(a, st);
-        return;
+        if (a.logt == 0 ? launch_row_lds<KP, 0, 512>(a, st) : launch_row_lds<KP, 1, 512>(a, st)) return;
+      } else if (need <= 160 * 1024 - 1024) {
+        if (a.logt == 0 ? launch_row_lds<KP, 0, 1024>(a, st) : launch_row_lds<KP, 1, 1024>(a, st)) return;
       }
     }
   }

@@ -446,13 +446,15 @@ __global__ void vi_gate_kernel(const double* __restrict__ parts, const double* _
                                const double* __restrict__ nnf, int S, double c, double rows,
                                double* __restrict__ state) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double acc = 0.0, bad = 0.0;
+  double acc = 0.0, bad = 0.0, sat = 0.0;
   for (int s = 0; s < S; ++s) {
     double prior = 0.0;
     for (int i = 0; i < 12; ++i) prior += parts[s * 14 + i];
     acc += parts[s * 14 + 13] + parts[s * 14 + 12] + c * (prior - logq[s]);
     bad += nnf ? nnf[s] : 0.0;
+    sat += nnf ? nnf[S + s] : 0.0;     // spmf_finish: [S + s] = saturation events of draw s
   }
+  state[14] += sat;
   const double loss = -(acc / S) / rows;
   const bool ok = (loss - loss == 0.0) && bad == 0.0;      // finite and no non-finite cell
   state[13] += 1.0;                                        // RNG step counter (spmf_sample_noise)

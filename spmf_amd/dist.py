@@ -17,13 +17,40 @@ import torch
 import torch.distributed as dist
 
 
-def shard_bounds(total_rows: int, world: int, rank: int, granule: int = 1):
+def shard_bounds(total_rows: int, world: int, rank: int, granule: int = 1, row_ptr=None):
     """Contiguous [r0, r1) of this rank; shard edges fall on multiples of
-    ``granule`` rows (generator chunks / panels) and cover every row once."""
+    ``granule`` rows (generator chunks / panels) and cover every row once.
+
+    Without ``row_ptr`` the shards hold equal counts of granules.  With the CSR
+    row-pointer array of the whole matrix (``row_ptr[total_rows]`` = nnz; numpy,
+    torch or a list) the edges are the granule boundaries nearest to equal STORED
+    counts (SURVEY 8e "nnz-balanced split points"): a step's time follows the
+    stored entries of the shard, so deep / shallow row blocks no longer make one
+    rank the slowest.  Edges stay strictly increasing while there are at least
+    ``world`` granules, so no rank is left without rows."""
     units = -(-total_rows // granule)
-    u0 = units * rank // world
-    u1 = units * (rank + 1) // world
-    return min(total_rows, u0 * granule), min(total_rows, u1 * granule)
+    if row_ptr is None:
+        u0 = units * rank // world
+        u1 = units * (rank + 1) // world
+        return min(total_rows, u0 * granule), min(total_rows, u1 * granule)
+    import numpy as np
+    rp = np.asarray(row_ptr.cpu() if hasattr(row_ptr, "cpu") else row_ptr, dtype=np.int64)
+    if rp.shape[0] != total_rows + 1:
+        raise ValueError("row_ptr must have total_rows + 1 entries")
+    edges_rows = np.minimum(np.arange(units + 1, dtype=np.int64) * granule, total_rows)
+    cum = rp[edges_rows] - rp[0]                  # stored entries before each granule boundary
+    nnz = int(cum[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = nnz * r / world
+        j = int(np.searchsorted(cum, target))     # first boundary with cum >= target
+        if j > 0 and (j > units or target - cum[j - 1] <= cum[min(j, units)] - target):
+            j -= 1
+        lo = cuts[-1] + 1 if units >= world else cuts[-1]
+        hi = units - (world - r) if units >= world else units
+        cuts.append(int(min(max(j, lo), max(hi, lo))))
+    cuts.append(units)
+    return int(edges_rows[min(cuts[rank], units)]), int(edges_rows[min(cuts[rank + 1], units)])
 
 
 class LibraryComm:
@@ -139,14 +166,18 @@ class ShardReducer:
         if work is not None:
             work.wait()                       # the current stream waits, not the host
 
+    def _nccl(self):
+        """torch.distributed is up AND its backend is RCCL (device tensors only)."""
+        return dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+
     def totals(self, rows, lgamma_sum):
         """Global (rows, lgamma) of the batch, as __call__ returns them."""
         if self.rows_global is None:
-            dev = torch.device("cuda", torch.cuda.current_device()) \
-                if self.active and dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            dev = torch.device("cuda", torch.cuda.current_device()) if self._nccl() \
+                else torch.device("cpu")
             tot = torch.tensor([float(rows), float(lgamma_sum)], dtype=torch.float64, device=dev)
             if self.active:
-                self._sum(tot)
+                self._sum(tot)       # fp64: torch.distributed's job; a no-op with a library comm alone
             return int(round(float(tot[0]))), float(tot[1])
         return self.rows_global, self.lgamma_global
 
@@ -167,12 +198,14 @@ class ShardReducer:
     # ---- replicated state ------------------------------------------------------
     def sync_replicas(self, tensors, src=0):
         """Broadcast rank `src`'s copy of the replicated tensors (surrogate
-        trainables, Adam moments).  Every rank applies the same update to identical
-        all-reduced gradients, but the finish kernel's cross-block float atomics
-        (u_tau gradient, energy parts) are order dependent in the last bit, so the
-        replicas can drift apart over thousands of steps; the driver calls this
-        every few hundred steps (one small broadcast)."""
-        if not self.active:
+        trainables, Adam moments).  Every rank applies the same update to the same
+        all-reduced accumulators and the finish kernel sums across blocks in a fixed
+        order, so the replicas are expected to stay bit-identical; the driver still
+        re-broadcasts every few hundred steps (one small broadcast) as a guard against
+        anything rank dependent upstream (replicas_max_abs_diff measures it).  Needs a
+        torch.distributed process group: with one rank, or with a library communicator
+        alone, there is nothing to broadcast."""
+        if not self.active or self.world == 1 or not dist.is_initialized():
             return
         for t in tensors:
             if dist.get_backend(self.group) != "nccl" and t.is_cuda:
@@ -189,8 +222,11 @@ class ShardReducer:
         for t in tensors:
             ref = t.detach().clone()
             self.sync_replicas([ref])
-            d = (t.detach() - ref).abs().max().reshape(1).double().cpu() if t.numel() else torch.zeros(1, dtype=torch.float64)
-            if self.active:
+            d = (t.detach() - ref).abs().max().reshape(1).double() if t.numel() \
+                else torch.zeros(1, dtype=torch.float64, device=t.device)
+            if dist.is_initialized() and self.world > 1:
+                if not self._nccl():
+                    d = d.cpu()                  # gloo reduces host tensors, RCCL device tensors
                 dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.group)
             worst = max(worst, float(d))
         return worst

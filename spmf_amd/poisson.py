@@ -135,7 +135,7 @@ class PoissonFactorization:
     # ------------------------------------------------------------------
     # native context
     # ------------------------------------------------------------------
-    def _new_ctx(self):
+    def _new_ctx(self, aux=False):
         if self.device.type != "cuda":
             raise SpmfError(
                 "the HIP hot path needs a GPU device (no CPU fallback)")
@@ -153,7 +153,11 @@ class PoissonFactorization:
         _lib.check(h, lib.spmf_ctx_set_prior(
             h, float(self.u_tau_scale), float(self.s_tau_scale),
             float(self.symmetry_breaking_decay)), "spmf_ctx_set_prior")
-        if flags & (_lib.FLAG_LOG_TRANSFORM | _lib.FLAG_BERNOULLI | _lib.FLAG_MIXED):
+        if aux:
+            # the replacement rule's scan context never runs a data pass: keep its E buffer
+            # (part of every workspace of a dense-term context) at the library's minimum
+            _lib.check(h, lib.spmf_ctx_set_e_cap(h, 1 << 20), "spmf_ctx_set_e_cap")
+        elif flags & (_lib.FLAG_LOG_TRANSFORM | _lib.FLAG_BERNOULLI | _lib.FLAG_MIXED):
             # room for E between the two dense contractions (dense.hip): a third of the device
             # memory torch can still hand out (free + its own cached blocks), at most 64 GiB
             # (the library's default is 8 GiB); fewer, larger row chunks fill the chip better
@@ -177,7 +181,7 @@ class PoissonFactorization:
         accumulators the patch + finish that follow still need."""
         lib = _lib.load()
         if getattr(self, "_aux_ctx", None) is None:
-            self._aux_ctx = self._new_ctx()
+            self._aux_ctx = self._new_ctx(aux=True)
             self._aux_ws = None
             self._after_aux_ctx(self._aux_ctx)
         need = lib.spmf_workspace_bytes(self._aux_ctx, int(rows), 1)

@@ -277,6 +277,7 @@ class AdamHIP:
 
     def reset_epoch_counters(self):
         self.state[10:13].zero_()
+        self.state[14:15].zero_()
 
     @torch.no_grad()
     def step_dev(self, grads):
@@ -498,6 +499,18 @@ class PlateauController:
         return "quit" if self.decays >= self.max_decay_steps else "plateau"
 
 
+def _warn_saturated(model, events, verbose):
+    """The log_transform decoder evaluates exp(min(y, 70)) (csrc/common.h kYSat): a step with
+    exponents in (70, 709) trains on values and gradients that differ from the fp64 reference
+    (poisson.py:52-53) instead of being skipped.  Say so once per epoch while it happens, and
+    keep the running count on the model (``model.saturated_events``)."""
+    model.saturated_events = getattr(model, "saturated_events", 0.0) + float(events)
+    if events and verbose:
+        print(f"Decoder saturated: exp(y) evaluated at min(y, 70) in {int(events)} workgroup "
+              "events this epoch -- values and gradients of those steps differ from the fp64 "
+              "reference (poisson.py:52-53) until the exponents come down")
+
+
 def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=8,
         sample_batches=1, num_steps=100, num_epochs=None, rel_tol=1e-6, abs_tol=1e-10,
         learning_rate=0.01, clip_value=10.0, max_decay_steps=25, lr_decay_factor=0.99,
@@ -520,7 +533,7 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
         runner = StepRunner(model, opt, dataset_size, sample_size,
                             use_graph=kwargs.get("use_graph", True))
     for ep in range(epochs):
-        tot, nb = 0.0, 0
+        tot, nb, ep_sat = 0.0, 0, 0.0
         if device_loop:
             # no host read-back inside the epoch: the loss sum, the applied and
             # the skipped step counts live in the optimiser's device state
@@ -529,6 +542,7 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
                 runner.step(batch)
             st = opt.read_state()
             tot, nb, skipped = st[10], int(st[11]), int(st[12])
+            ep_sat = st[14]
             if verbose and skipped:
                 print(f"Batch loss NaN, skipping ({skipped} batches)")
             if skipped:
@@ -554,10 +568,12 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
                 opt.step(grads, clip_value)
                 tot += lv
                 nb += 1
+                ep_sat += float(model.last_saturated.sum())
                 # row shards: keep the replicated trainables and Adam moments bit-identical
                 # (ShardReducer.sync_replicas explains why they can drift)
                 if sync_every and hasattr(all_reduce, "sync_replicas") and opt.t % sync_every == 0:
                     all_reduce.sync_replicas(list(sur.trainable_variables) + opt.m + opt.v)
+        _warn_saturated(model, ep_sat, verbose)
         if nb == 0:
             # every batch of the epoch was skipped (non-finite loss): returning
             # quietly would look like a converged fit

@@ -14,7 +14,7 @@ import torch
 from oracle import spmf_oracle as O
 
 
-def data_term(cfg, X_csr, params, chunk=1024):
+def data_term(cfg, X_csr, params, chunk=1024, scales=False):
     """'x', 'z' and d(x+z)/d(u,v,w,s) for ONE draw.  ``params``: name ->
     [1,*shape] float64 arrays (fp32-exact values); X_csr: scipy CSR."""
     names = ("u", "v", "w", "s")
@@ -23,6 +23,9 @@ def data_term(cfg, X_csr, params, chunk=1024):
     B = X_csr.shape[0]
     tot_x, tot_z = 0.0, 0.0
     grads = {k: torch.zeros_like(p[k]) for k in names}
+    # per additive piece (stored-cell part, minus-rate part, z prior): its gradient summed over
+    # the chunks; sum over pieces of |.| is oracle.energy_grad_scales' entry-wise yardstick
+    piece_g = [{k: torch.zeros_like(p[k]) for k in names} for _ in range(3)] if scales else None
     for r0 in range(0, B, chunk):
         x = torch.as_tensor(X_csr[r0:r0 + chunk].toarray().astype(np.float64))
         ll = O.log_likelihood_components(cfg, x, p["s"], p["u"], p["v"], p["w"])["log_likelihood"]
@@ -30,13 +33,31 @@ def data_term(cfg, X_csr, params, chunk=1024):
         theta = O.encode(cfg, x, p["u"], p["s"])
         px = ll.sum()
         pz = (O.HALF_LOG_2_OVER_PI - 0.5 * theta ** 2).sum()
+        if scales:
+            pieces = O._data_pieces(cfg, x, p)
+            for i, piece in enumerate(pieces):
+                gi = torch.autograd.grad(piece, [p[k] for k in names], retain_graph=True,
+                                         allow_unused=True)     # the z prior does not see v, w
+                for k, gk in zip(names, gi):
+                    if gk is not None:
+                        piece_g[i][k] += gk
+            del pieces
         g = torch.autograd.grad(px + pz, [p[k] for k in names])
         for k, gk in zip(names, g):
             grads[k] += gk
         tot_x += float(px)
         tot_z += float(pz)
         del x, ll, theta, px, pz, g
-    return {"x": tot_x, "z": tot_z, "grads": {k: v.numpy() for k, v in grads.items()}}
+    out = {"x": tot_x, "z": tot_z, "grads": {k: v.numpy() for k, v in grads.items()}}
+    if scales:
+        out["scales"] = {k: sum(pg[k].abs() for pg in piece_g).numpy() for k in names}
+    return out
+
+
+def prior_scales(cfg, params, prior_weight=1.0):
+    """Entry-wise yardstick of the prior gradients (oracle.energy_grad_scales, prior half)."""
+    sc = O.energy_grad_scales(cfg, None, params, prior_weight=prior_weight, data=False)
+    return {k: v.numpy() for k, v in sc.items()}
 
 
 def prior_term(cfg, params):

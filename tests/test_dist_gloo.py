@@ -108,6 +108,70 @@ def test_shard_bounds_cover_rows_once():
             assert a[1] == b[0]
 
 
+def test_shard_bounds_balance_stored_entries():
+    """SURVEY 8e "nnz-balanced split points": with the row pointers, shard edges are the
+    granule boundaries nearest to equal stored counts (deep rows first, shallow rows after:
+    equal row counts would give rank 0 three times the entries of the last rank)."""
+    from spmf_amd.dist import shard_bounds
+    rng = np.random.default_rng(3)
+    lens = np.concatenate([rng.poisson(300, 5000), rng.poisson(50, 15000)])
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    total, g = 20000, 1000
+    for world in (1, 2, 4, 8):
+        edges = [shard_bounds(total, world, r, g, row_ptr=rp) for r in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == total
+        for a, b in zip(edges[:-1], edges[1:]):
+            assert a[1] == b[0] and a[0] < a[1]
+        assert all(e[0] % g == 0 for e in edges)
+        nnz = np.array([rp[b] - rp[a] for a, b in edges], dtype=np.float64)
+        even = np.array([rp[b] - rp[a] for a, b in
+                         (shard_bounds(total, world, r, g) for r in range(world))], dtype=np.float64)
+        # never worse than the equal-rows split, and within one granule of deep rows of ideal
+        assert nnz.max() <= even.max() + 1e-9
+        assert nnz.max() - nnz.mean() <= 300 * g
+    # torch row pointers and a list work too; a wrong length is refused
+    a = shard_bounds(total, 4, 1, g, row_ptr=torch.as_tensor(rp))
+    assert a == shard_bounds(total, 4, 1, g, row_ptr=list(rp))
+    with pytest.raises(ValueError):
+        shard_bounds(total, 4, 1, g, row_ptr=rp[:-1])
+    # fewer granules than ranks: still a cover without overlap (some ranks get no rows)
+    edges = [shard_bounds(3000, 4, r, 1000, row_ptr=np.arange(3001)) for r in range(4)]
+    assert edges[0][0] == 0 and edges[-1][1] == 3000
+    assert all(x[1] == y[0] for x, y in zip(edges[:-1], edges[1:]))
+
+
+def test_shard_reducer_with_a_library_comm_alone_on_one_rank():
+    """with only a LibraryComm (no torch.distributed process group) the reducer
+    is active; totals / sync_replicas / replicas_max_abs_diff / gather_scalar must not ask
+    torch.distributed for a backend.  The comm here is a stand-in that records calls (the real
+    one needs RCCL and a GPU: tests/test_gpu_two_rank.py)."""
+    from spmf_amd.dist import ShardReducer
+    assert not dist.is_initialized()
+
+    class FakeComm:
+        rank, world = 0, 1
+
+        def __init__(self):
+            self.calls = 0
+
+        def all_reduce_(self, t):
+            self.calls += 1
+
+    comm = FakeComm()
+    red = ShardReducer(comm=comm)
+    assert red.active and red.world == 1 and red.rank == 0
+    assert red.totals(120, 3.5) == (120, 3.5)          # rows_global unset: computed, not raised
+    red.set_batch_totals(500, 9.0)
+    assert red.totals(120, 3.5) == (500, 9.0)
+    t = torch.arange(6, dtype=torch.float32)
+    red.sync_replicas([t])                               # nothing to broadcast with one rank
+    assert red.replicas_max_abs_diff([t, torch.zeros(0)]) == 0.0
+    assert red.gather_scalar(2.5, device=torch.device("cpu")) == [2.5]
+    acc = torch.ones(8, dtype=torch.float32)
+    assert red(acc, 120, 3.5) == (500, 9.0)
+    assert comm.calls == 0                               # host tensors never go to the library comm
+
+
 @pytest.mark.timeout(180)
 @pytest.mark.parametrize("world", [2, 4])
 def test_gloo_allreduce_matches_unsharded_oracle(world):

@@ -71,6 +71,7 @@ def test_hip_path_matches_golden(f):
     assert float(nnf.sum()) == 0
     for k in parts:
         np.testing.assert_allclose(got[k].cpu().numpy(), parts[k], rtol=1e-5, atol=1e-5)
-    for k in grads:
-        g = gg[k].cpu().double().numpy().reshape(grads[k].shape)
-        assert np.abs(g - grads[k]).max() <= 1e-5 * np.abs(grads[k]).max(), k
+    # entry by entry against 1e-5 of the sum of |contributions| (tests/_gradcheck.py)
+    from _gradcheck import assert_grads_entrywise
+    assert_grads_entrywise(gg, grads, O.energy_grad_scales(cfg, x, params), 1e-5,
+                           os.path.basename(f))

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import spmf_oracle as O
+from _gradcheck import assert_grads_entrywise
 
 pytestmark = pytest.mark.gpu
 
@@ -39,9 +40,7 @@ def test_bernoulli_energy_and_grads(B, D, K, S, density):
     for k, r in pref.items():
         np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                    err_msg=k)
-    for k, r in gref.items():
-        g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+    assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "")
 
 
 def problem_logt(B, D, K, S, seed, density):
@@ -68,9 +67,7 @@ def test_bernoulli_log_transform_energy_and_grads(B, D, K, S, density):
     for k, r in pref.items():
         np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                    err_msg=k)
-    for k, r in gref.items():
-        g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+    assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "")
     # per-cell outputs (bernoulli.py:126-155): 'rate' is the logit
     T = torch.as_tensor
     got = m.log_likelihood_components(s=T(params["s"]), u=T(params["u"]), v=T(params["v"]),
@@ -99,9 +96,7 @@ def test_bernoulli_log_transform_sweep_and_fit():
         for k, r in pref.items():
             np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                        err_msg=f"{tag} {k}")
-        for k, r in gref.items():
-            g = grads[k].cpu().double().numpy().reshape(r.shape)
-            assert np.abs(g - r.numpy()).max() <= 1e-5 * max(np.abs(r.numpy()).max(), 1e-30), f"{tag} {k}"
+        assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, tag)
     X = (rng.random((400, 20)) < 0.2).astype(np.float64)
     m = BernoulliFactorization(latent_dim=2, feature_dim=20, u_tau_scale=1 / math.sqrt(8000),
                                log_transform=True, device="cuda", panel_rows=100)
@@ -143,6 +138,4 @@ def test_bernoulli_randomised_sweep():
         for k, r in pref.items():
             np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                        err_msg=f"{tag} {k}")
-        for k, r in gref.items():
-            g = grads[k].cpu().double().numpy().reshape(r.shape)
-            assert np.abs(g - r.numpy()).max() <= 1e-5 * max(np.abs(r.numpy()).max(), 1e-30), (tag, k)
+        assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, tag)

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import spmf_oracle as O
+from _gradcheck import assert_grads_entrywise
 
 pytestmark = pytest.mark.gpu
 
@@ -48,9 +49,7 @@ def test_log_transform_energy_and_grads(B, D, K, S, density, scale_rows):
     for k, r in pref.items():
         np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                    err_msg=k)
-    for k, r in gref.items():
-        g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+    assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "")
     T = torch.as_tensor
     z = m.encode(x, u=T(params["u"]), s=T(params["s"])).cpu().numpy()
     zr = O.encode(cfg, T(x), T(params["u"]), T(params["s"])).numpy()
@@ -72,9 +71,7 @@ def test_two_launch_form_still_matches_oracle(monkeypatch, B, D, K, S):
     parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
     for k, r in pref.items():
         np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
-    for k, r in gref.items():
-        g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+    assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "")
 
 
 def test_e_buffer_in_several_row_chunks():
@@ -95,9 +92,7 @@ def test_e_buffer_in_several_row_chunks():
     parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
     for k, r in pref.items():
         np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
-    for k, r in gref.items():
-        g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+    assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "")
 
 
 def test_log_transform_randomised_sweep():
@@ -121,9 +116,7 @@ def test_log_transform_randomised_sweep():
         for k, r in pref.items():
             np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                        err_msg=f"{tag} {k}")
-        for k, r in gref.items():
-            g = grads[k].cpu().double().numpy().reshape(r.shape)
-            assert np.abs(g - r.numpy()).max() <= 1e-5 * max(np.abs(r.numpy()).max(), 1e-30), (tag, k)
+        assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, tag)
 
 
 def test_log_transform_fit_smoke():
@@ -144,3 +137,36 @@ def test_log_transform_fit_smoke():
     assert np.mean(losses[-3:]) < losses[0]
     z = m.encode(X)
     assert tuple(z.shape) == (N, K) and bool(torch.isfinite(z).all())
+
+
+def test_fit_reports_decoder_saturation(capsys):
+    """a step whose exponents exceed kYSat = 70 (csrc/common.h) trains on
+    exp(min(y, 70)); the device-gated loop must not do that silently.  A tiny xi_u_global makes
+    the row scales -- and with them <z, eta v> -- huge at the initial values: the saturation
+    count reaches the VI state ([14]), fit prints the warning and keeps the running count."""
+    from spmf_amd import PoissonFactorization
+    rng = np.random.default_rng(6)
+    N, D, K = 300, 40, 3
+    X = rng.poisson(3.0, size=(N, D)).astype(np.float64)
+    colmean = np.maximum(X.mean(0, keepdims=True), 1e-3)
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(N * D),
+                             log_transform=True, column_norms=colmean, device="cuda", panel_rows=128)
+    m.xi_u_global = 1e-7 * float(colmean.sum())
+    torch.manual_seed(2)
+    params = m.surrogate_distribution.sample(1)
+    m.energy_and_grads({"counts": X}, params)
+    assert float(m.last_saturated.sum()) > 0            # the premise: this point saturates
+    losses = m.fit(lambda: [{"counts": X}], dataset_size=N, sample_size=2, num_steps=3,
+                   learning_rate=1e-3, rel_tol=1e-12, verbose=True)
+    out = capsys.readouterr().out
+    assert "Decoder saturated" in out and "min(y, 70)" in out
+    assert m.saturated_events > 0
+    assert len(losses) == 3 and all(math.isfinite(v) for v in losses)
+    # a model that never saturates says nothing and counts nothing
+    m2 = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(N * D),
+                              log_transform=True, column_norms=colmean, device="cuda", panel_rows=128)
+    m2.xi_u_global = float(colmean.sum())
+    m2.fit(lambda: [{"counts": X}], dataset_size=N, sample_size=2, num_steps=2,
+           learning_rate=1e-3, rel_tol=1e-12, verbose=True)
+    assert "Decoder saturated" not in capsys.readouterr().out
+    assert getattr(m2, "saturated_events", 0.0) == 0.0

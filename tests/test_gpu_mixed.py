@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import spmf_oracle as O
+from _gradcheck import assert_grads_entrywise
 
 pytestmark = pytest.mark.gpu
 
@@ -42,9 +43,7 @@ def test_mixed_energy_and_grads(B, D, K, S, density, sr):
     for k, r in pref.items():
         np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5,
                                    err_msg=k)
-    for k, r in gref.items():
-        g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+    assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "")
 
 
 @pytest.mark.parametrize("kind", ["mixed", "bernoulli"])
@@ -71,9 +70,7 @@ def test_sigmoid_e_buffer_in_several_row_chunks(kind):
     parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
     for k, r in pref.items():
         np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
-    for k, r in gref.items():
-        g = grads[k].cpu().double().numpy().reshape(r.shape)
-        assert np.abs(g - r.numpy()).max() <= 1e-5 * np.abs(r.numpy()).max(), k
+    assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "")
 
 
 def test_mixed_fit_smoke():

@@ -380,3 +380,55 @@ def test_abs_horseshoe_branch_parts_and_gradients():
         assert abs(float(grads[name][idx]) - fd) <= 1e-6 * max(1.0, abs(fd)), (name, fd)
     st = O.surrogate_initial_state(cfg)
     assert tuple(st) == O.VAR_ORDER_ABS and float(st["u"]["loc"][0, 0]) == -9.0
+
+
+# ---- the entry-wise gradient yardstick (oracle.energy_grad_scales, tests/_gradcheck.py) ----
+@pytest.mark.parametrize("lik,hp,logt", [("poisson", True, False), ("poisson", False, False),
+                                         ("poisson", True, True), ("bernoulli", True, False)])
+def test_prior_terms_sum_to_the_parts(lik, hp, logt):
+    rng = np.random.default_rng(11)
+    B, D, K, S = 12, 9, 3, 2
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(B * D),
+                         log_transform=logt)
+    cfg.likelihood, cfg.horseshoe_plus = lik, hp
+    cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = 3.0
+    p = {k: torch.as_tensor(v) for k, v in O.random_params(cfg, S, 5).items()}
+    parts, terms = O.prior_log_prob_parts(cfg, p), O.prior_log_prob_terms(cfg, p)
+    assert set(parts) == set(terms)
+    for k in parts:
+        tot = sum((t * torch.ones_like(p[k])).sum((-1, -2)) for t in terms[k])
+        np.testing.assert_allclose(tot.numpy(), parts[k].numpy(), rtol=1e-12, atol=1e-10)
+
+
+def test_gradient_yardstick_is_the_sum_of_absolute_cell_contributions():
+    """For u, v, w every cell's contribution to one piece has the same sign, so the yardstick
+    must equal the brute-force sum over cells of |d ll_cell / d entry| + |d z-prior| + the
+    prior terms; it always dominates |gradient|; entries nothing contributes to get 0."""
+    rng = np.random.default_rng(12)
+    B, D, K = 6, 5, 2
+    x = ((rng.random((B, D)) < 0.5) * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    x[:, 3] = 0.0
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(B * D))
+    cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = 3.0
+    params = O.random_params(cfg, 1, 13)
+    _, grads, _ = O.energy_and_grads(cfg, x, params)
+    sc = O.energy_grad_scales(cfg, x, params)
+    for k in grads:
+        assert bool((grads[k].abs() <= sc[k] * (1 + 1e-12) + 1e-300).all()), k
+    # brute force over cells for the data term of v: stored part and rate part separately
+    dsc = O.energy_grad_scales(cfg, x, params, prior=False)
+    p = {k: torch.as_tensor(v).clone().requires_grad_(True) for k, v in params.items()}
+    xt = torch.as_tensor(x)
+    rate = O.log_likelihood_components(cfg, xt, p["s"], p["u"], p["v"], p["w"])["rate"]
+    brute = torch.zeros_like(p["v"])
+    for b in range(B):
+        for d in range(D):
+            for piece in (torch.xlogy(xt[b, d], rate[0, b, d]), -rate[0, b, d]):
+                g, = torch.autograd.grad(piece, p["v"], retain_graph=True, allow_unused=True)
+                if g is not None:
+                    brute += g.abs()
+    np.testing.assert_allclose(dsc["v"].numpy(), brute.detach().numpy(), rtol=1e-12, atol=1e-300)
+    # column 3 holds no entry: d(stored part)/dv is 0 there, only the rate part remains
+    assert float(dsc["v"][0, :, 3].min()) > 0
