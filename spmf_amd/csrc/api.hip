@@ -58,6 +58,9 @@ struct spmf_ctx {
   float* est = nullptr;
   int64_t est_rows = 0;           // rows per chunk of the bound workspace
   int e_once = 1;                 // SPMF_DENSE_E_ONCE=0: recompute E in a second launch instead
+  int dense3 = 1;                 // exp sums on the bf16 matrix cores with three-way split operands
+                                  // (dense3.hip; Poisson log_transform at KP = 64 only);
+                                  // SPMF_DENSE_BF16X3=0 selects the exact-f32 MFMA kernels (dense.hip)
   size_t est_cap_bytes = (size_t)8 << 30;   // spmf_ctx_set_e_cap
   double* scratch = nullptr;
   static constexpr size_t kScratchDoubles = 1u << 20;   // 8 MiB
@@ -167,9 +170,13 @@ static int64_t est_chunk_rows(const spmf_ctx* c, int64_t rows) {
 
 // E (exp / sigmoid of the logits) is kept between the two dense contractions by the exp and
 // sigmoid forms; Bernoulli + log_transform (code 4: E would have to carry exp(X) too) recomputes
+// the bf16x3 form of the exp sums (dense3.hip) covers the Poisson exp decoder at KP = 64
+static bool uses_dense3(const spmf_ctx* c) {
+  return c->dense3 && likelihood_code(c) == 1 && c->KP == 64;
+}
 static bool uses_e_buffer(const spmf_ctx* c) {
   return (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once &&
-         likelihood_code(c) != 4;
+         likelihood_code(c) != 4 && !uses_dense3(c);
 }
 
 static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
@@ -224,6 +231,7 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   }
   c->flags = flags;
   if (const char* e = getenv("SPMF_DENSE_E_ONCE")) c->e_once = e[0] != '0';
+  if (const char* e = getenv("SPMF_DENSE_BF16X3")) c->dense3 = e[0] != '0';
   *out = c;
   return SPMF_OK;
 }
@@ -504,7 +512,21 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         lbias = c->bb;
         orows = c->bcols;
       }
-      if (c->est && act != 2) {   // (act 2: E carries exp(X) too, its row sums are not the d/dphi sums)
+      if (uses_dense3(c) && !compact) {
+        // bf16x3: E is recomputed by the second launch (at this matrix rate a B*D*4-byte round
+        // trip through HBM would be the bound)
+        ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, 1, 0, 0, nullptr, nullptr, nullptr,
+            nullptr};
+        launch_expdot3(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E
+        const int nbx3 = (Dd + 255) / 256;
+        const int qt3 = (int)((ct->n_rows + 63) / 64);
+        int ch3 = (512 + nbx3 - 1) / nbx3;                 // ~2 workgroups of 8 waves per CU
+        if (ch3 > qt3) ch3 = qt3;
+        if (ch3 < 1) ch3 = 1;
+        ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr,
+            nullptr};
+        launch_expdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+      } else if (c->est && act != 2) {   // (act 2: E carries exp(X) too, its row sums are not the d/dphi sums)
         // E once: per row chunk, the Z-stationary kernel keeps E (exp, or the sigmoid of the
         // Bernoulli logits) and the second contraction (gV'_d -= sum_b E_bd z_b; Bernoulli:
         // gphi_d -= sum_b E_bd too) reads it back instead of recomputing it

@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
             gph += xv[j];
           } else {
             const float y = group_sum<LPN>(dot4(zz[j], vp));
-            const float ey = LIK == 1 ? expf(fminf(y, kYSat)) : 1.f;   // saturating: common.h kYSat
-            const float r = (LIK == 1 ? ey - 1.f : y) + ph;
+            float ey = 1.f;                                            // saturating: common.h kYSat
+            const float r = (LIK == 1 ? expm1_dec(fminf(y, kYSat), ey) : y) + ph;
             // r <= 0 / NaN cells were counted by the row pass; the replacement rule
             // (poisson.py:606-616) drops such a cell whole, so it gets weight +1 to cancel
             // the -1 that the closed-form sum over ALL cells gives it (finish kernel)
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
             gph += xv[j];
           } else {
             const float y = group_sum<LPN>(dot4(zz[j], vp));
-            const float ey = LIK == 1 ? expf(fminf(y, kYSat)) : 1.f;
-            const float r = (LIK == 1 ? ey - 1.f : y) + ph;
+            float ey = 1.f;
+            const float r = (LIK == 1 ? expm1_dec(fminf(y, kYSat), ey) : y) + ph;
             const float xr = (r > 0.f && r < INFINITY) ? xv[j] * __builtin_amdgcn_rcpf(r)
                                                        : (xv[j] > 0.f ? 1.f : 0.f);
             gV = fma4(LIK == 1 ? xr * ey : xr, zz[j], gV);

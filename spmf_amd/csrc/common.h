@@ -30,6 +30,29 @@ __host__ __device__ constexpr bool lik_exp(int l) { return l == 1 || l == 4; }
 __host__ __device__ constexpr bool lik_bern(int l) { return l == 2 || l == 4; }
 
 constexpr float kYSat = 70.0f;
+// exp(y) - 1 of the log_transform decoder (poisson.py:52-53) for an exponent already clamped
+// at kYSat; `ey` returns exp(y) (the derivative).  The difference formed in fp32 loses its
+// leading digits for small |y| -- a rarely expressed gene has eta = 1e-3 and y ~ 1e-5, where
+// expf(y) - 1.f keeps two digits -- while the fp64 reference keeps them all: the rate
+// r = exp(y) - 1 + phi of such a column, and with it x/r in three gradients, was off by up to
+// 1e-3 relative (found by the entry-wise gradient check on the C4 slice).  Series below 1/4
+// (next term y^8/9! < 5e-11 relative), exp - 1 above (relative error <= 4.6 ulp there).
+__device__ __forceinline__ float expm1_dec(float y, float& ey) {
+  float p = 1.f / 40320.f;
+  p = fmaf(p, y, 1.f / 5040.f);
+  p = fmaf(p, y, 1.f / 720.f);
+  p = fmaf(p, y, 1.f / 120.f);
+  p = fmaf(p, y, 1.f / 24.f);
+  p = fmaf(p, y, 1.f / 6.f);
+  p = fmaf(p, y, 0.5f);
+  p = fmaf(p, y, 1.f);
+  const float e = expf(y);
+  const bool small = fabsf(y) < 0.25f;
+  const float em1 = small ? y * p : e - 1.f;
+  ey = small ? 1.f + em1 : e;
+  return em1;
+}
+
 // The prep kernel's closed-form column sums (veta[KP], phisum) are written as kPrepSeg
 // partial sums over column segments, dprep[seg][KP+1]: one writer per slot (no atomics,
 // no zero fill), and every reader folds the segments in index order (prep_sum).

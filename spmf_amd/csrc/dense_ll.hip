@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void dense_rate_kernel(int64_t B, int D, int l
     float y = 0.f;
 #pragma unroll 8
     for (int k = 0; k < KP; ++k) y = fmaf(zs[r][k], vs[dl][k], y);
-    const float rt = (lik_exp(logt) ? expf(fminf(y, kYSat)) - 1.f : y) + phi[d];
+    float ey_;
+    const float rt = (lik_exp(logt) ? expm1_dec(fminf(y, kYSat), ey_) : y) + phi[d];
     rate[(size_t)b * D + d] = rt;
     const bool bern = lik_bern(logt) || (logt == 3 && ctype[d]);
     // x = 0 cell.  Poisson: 0*log r := 0 (multiply_no_nan) -> -r.  Bernoulli: -softplus(logit)
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(256) void nonfinite_patch_kernel(
     cphi = x - sg;
     cy = cphi * ey;
   } else {
-    const float ey = logt == 1 ? expf(fminf(y, kYSat)) : 1.f;
-    const float r = (logt == 1 ? ey - 1.f : y) + phi;
+    float ey = 1.f;
+    const float r = (logt == 1 ? expm1_dec(fminf(y, kYSat), ey) : y) + phi;
     cphi = x / r - 1.f;
     cy = cphi * ey;
   }

@@ -86,6 +86,9 @@ struct ExpdotArgs {
   int64_t ldE = 0;
 };
 void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st);
+// dense3.hip: the same operator (act 0, KD = 64, no biases / E store) on the bf16 matrix cores with
+// three-way split operands; false = this shape is not covered (use launch_expdot)
+bool launch_expdot3(int KD, const ExpdotArgs& a, hipStream_t st);
 void launch_estdot(int KD, int NQ, int NP, int64_t ldE, const float* est, const float* P, float* out, float sign,
                    float* out2, const int32_t* out_rows, hipStream_t st);
 void launch_compact_rows(int n, int KD, const int32_t* cols, const float* Vp, const float* phi, float* Vb,

@@ -154,8 +154,9 @@ struct RowCtx {
       if (LIK == 2 || LIK == 4 || (LIK == 3 && ctype[cs])) {
         // Bernoulli(logits = f(<z,V'>) + phi) (bernoulli.py:147-155): stored-cell part x*logit;
         // LIK 4: f = exp - 1 (saturating like the Poisson form)
-        const float ey = LIK == 4 ? expf(fminf(rmine, kYSat)) : 1.f;
-        const float lg = (LIK == 4 ? ey - 1.f : rmine) + (LDSPHI ? lds_dyn()[cs] : phi[cs]);
+        float ey = 1.f;
+        const float fy = LIK == 4 ? expm1_dec(fminf(rmine, kYSat), ey) : rmine;
+        const float lg = fy + (LDSPHI ? lds_dyn()[cs] : phi[cs]);
         if (lg > -INFINITY && lg < INFINITY) {
           ll = fmaf(xs, lg, ll);
           cc = LIK == 4 ? xs * ey : xs;              // d(x*logit)/d<z,V'>
@@ -164,8 +165,9 @@ struct RowCtx {
         }
       } else {
         // linear decoder: r = <z,V'> + phi; log_transform: r = exp(<z,V'>) - 1 + phi
-        const float ey = LIK == 1 ? expf(fminf(rmine, kYSat)) : 1.f;
-        const float r = (LIK == 1 ? ey - 1.f : rmine) + (LDSPHI ? lds_dyn()[cs] : phi[cs]);
+        float ey = 1.f;
+        const float fy = LIK == 1 ? expm1_dec(fminf(rmine, kYSat), ey) : rmine;
+        const float r = fy + (LDSPHI ? lds_dyn()[cs] : phi[cs]);
         if (r > 0.f && r < INFINITY) {
           ll = fmaf(xs, logf(r), ll);
           cc = xs * ey * __builtin_amdgcn_rcpf(r);   // d(x log r)/d<z,V'>

