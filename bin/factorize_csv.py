@@ -52,6 +52,38 @@ def build_parser():
     return parser
 
 
+def save_encoding_figure(encoding, rate_draws, filename):
+    """The reference CLI's PDF (bin/factorize_csv.py:141-185): left, the [D, K] encoding matrix
+    as a heat map (item 0 at the bottom); right, per item the 95 % (thin) and 65 % (thick)
+    intervals and the median of the background rate over the surrogate draws
+    (``rate_draws``: [n_draws, D]) -- what arviz.plot_forest shows there."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    encoding = np.asarray(encoding)
+    D, K = encoding.shape
+    fig, ax = plt.subplots(1, 2, figsize=(14, 8))
+    pcm = ax[0].imshow(encoding[::-1, :], vmin=0, cmap="Blues", aspect="auto")
+    ax[0].set_yticks(np.arange(D))
+    ax[0].set_yticklabels(np.arange(D)[::-1])
+    ax[0].set_ylabel("item")
+    ax[0].set_xlabel("factor dimension")
+    ax[0].set_xticks(np.arange(K))
+    ax[0].set_xticklabels(np.arange(K))
+    fig.colorbar(pcm, ax=ax[0], orientation="vertical")
+    q = np.quantile(np.asarray(rate_draws, dtype=np.float64), [0.025, 0.175, 0.5, 0.825, 0.975], axis=0)
+    y = np.arange(D)
+    ax[1].hlines(y, q[0], q[4], color="C0", linewidth=1)
+    ax[1].hlines(y, q[1], q[3], color="C0", linewidth=3)
+    ax[1].plot(q[2], y, "o", color="white", markeredgecolor="C0", markersize=4)
+    ax[1].set_yticks(y)
+    ax[1].set_xlabel("background rate")
+    ax[1].set_title("65% and 95% CI")
+    ax[1].axvline(1.0, linestyle="dashed", color="black")
+    fig.savefig(filename, bbox_inches="tight")
+    plt.close(fig)
+
+
 def main(argv=None):
     args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
     if args.csv_file is None:
@@ -114,14 +146,27 @@ def main(argv=None):
     filename += f"_lt_{_LOG_TRANSFORM}_rn_{_ROW_NORMALIZE}.pkl"
     factor.save(filename)
 
+    # the reference's figure (bin/factorize_csv.py:141-185): encoding heat map + background-rate
+    # intervals.  arviz is not needed: its forest plot is the 65 % and 95 % quantile intervals
+    # of the surrogate draws, computed here with numpy.
+    filename = f"{_FILENAME}_{_DIMENSION}D_encoding_"
+    filename += f"lt_{_LOG_TRANSFORM}_rn_{_ROW_NORMALIZE}.pdf"
     try:
         import matplotlib  # noqa: F401
-        import arviz  # noqa: F401
-        have_plot = True
     except ImportError:
-        have_plot = False
-    if not have_plot:
-        print("Skipping the figure with the encodings (matplotlib/arviz not installed)")
+        print("Skipping the figure with the encodings (matplotlib is not installed)")
+    else:
+        print("Saving figure with the encodings")
+        draws = factor.surrogate_distribution.sample(250)
+        w = draws['w'].reshape(250, -1).double().cpu().numpy()
+        eta = np.asarray(factor.eta_i.cpu() if hasattr(factor.eta_i, "cpu") else factor.eta_i,
+                         dtype=np.float64).reshape(1, -1)
+        if 's' in draws:
+            sd = draws['s'].double().cpu().numpy()
+            rate = w * (sd[:, -1, :] / sd.sum(-2)) * eta
+        else:
+            rate = w * eta
+        save_encoding_figure(factor.encoding_matrix().cpu().numpy(), rate, filename)
 
     print("Generating representations")
     filename = f"{_FILENAME}_{_DIMENSION}D_representation"

@@ -247,8 +247,10 @@ int spmf_comm_init(spmf_ctx* ctx, const void* id128, int rank, int world);
 int spmf_allreduce(spmf_ctx* ctx, float* buf, int64_t n, void* stream);
 int spmf_comm_destroy(spmf_ctx* ctx);
 
-/* Phase 2: chain the accumulators to d/d(u,v,w,s), add the horseshoe-plus
- * prior (poisson.py:228-377) parts and gradients for all 12 variables, and
+/* Phase 2: chain the accumulators to d/d(u,v,w,s), add the prior's parts and
+ * gradients -- the horseshoe-plus hierarchy over all 12 variables (poisson.py:228-377)
+ * or, for a context created with SPMF_FLAG_ABS_HORSESHOE, the AbsHorseshoe priors on u
+ * and s with v, w as before (poisson.py:378-398; variables 0, 1, 2, 7 only) -- and
  * finish the 14 energy parts.  n_rows_global / lgamma_sum_global are the
  * batch totals over all shards (= this shard's when single GPU).
  *   parts[S][14] fp64 (unweighted), grads[i] has the shape of params[i]

@@ -47,3 +47,19 @@ def test_scrnaseq_cli_defaults_match_reference_script():
     a = mod.build_parser().parse_args(["--counts", "x_counts.npy"])
     assert (a.dimension, a.batch_size, a.epoch) == (3, 256, 500)
     assert (a.learning_rate, a.abs_tol, a.rel_tol, a.clip_value) == (0.01, 1e-3, 1e-3, 10.0)
+
+
+def test_encoding_figure_is_written_without_arviz(tmp_path):
+    """bin/factorize_csv.py:141-185 of the reference saves a PDF of the encodings and the
+    background-rate intervals; here it needs matplotlib only (the forest plot is the 65 % /
+    95 % quantile intervals of the surrogate draws)."""
+    import numpy as np
+    import pytest
+    pytest.importorskip("matplotlib")
+    rng = np.random.default_rng(0)
+    enc = np.abs(rng.normal(size=(12, 3)))
+    rate = np.abs(rng.normal(1.0, 0.1, size=(250, 12)))
+    out = tmp_path / "toy_3D_encoding_lt_False_rn_False.pdf"
+    _cli().save_encoding_figure(enc, rate, str(out))
+    data = out.read_bytes()
+    assert data[:5] == b"%PDF-" and len(data) > 2000
