@@ -45,6 +45,7 @@ WORKLOADS = {
            "C5: 200k x 10k, even columns Poisson (1% nnz), odd columns Bernoulli(0.05), K=32, mixed"),
 }
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (datasheet; ~1.25 PF measured on random data)
 
 
 def algorithmic_bytes(nnz, B, D, K, S):
@@ -450,6 +451,12 @@ def main():
         dense_flops = 6.0 * sc.n_rows * D_dense * KD
         e_once = os.environ.get("SPMF_DENSE_E_ONCE", "1")[:1] != "0"
         dense_flops_executed = (6.0 if e_once else 8.0) * sc.n_rows * D_dense * KD
+        # K = 64 Poisson log_transform: the bf16x3 kernel (csrc/dense3.hip) unless switched off:
+        # two launches x 88 bf16 MFMAs of 32x32x16 per 64 x 32 cells (6 + 5 partial products)
+        bf16x3 = (logt and mixed_mask is None and KD == 64
+                  and os.environ.get("SPMF_DENSE_BF16X3", "1")[:1] != "0")
+        if bf16x3:
+            dense_flops_executed = 2.0 * 88 * 32768 / (64 * 32) * sc.n_rows * D_dense
         if (logt or mixed_mask is not None) and ms5[5] >= max(ms5[1], ms5[2]):
             dom = "dense_expdot"
             achieved = dense_flops / (ms5[5] * 1e-3) / 1e12
@@ -457,6 +464,13 @@ def main():
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                     "executed_tflops": dense_flops_executed / (ms5[5] * 1e-3) / 1e12}
+            if bf16x3:
+                # achieved / peak / frac stay the ALGORITHMIC 6*B*D*K against the f32-MFMA peak
+                # (no credit for a bf16 peak; > 1 means the work left that pipe); what the bf16 pipe
+                # itself issues, against its dense datasheet peak, is reported beside it
+                roof["executed_pipe"] = "bf16 (three-way split operands, csrc/dense3.hip)"
+                roof["executed_peak"] = MFMA_BF16_PEAK_TFLOPS
+                roof["executed_frac"] = roof["executed_tflops"] / MFMA_BF16_PEAK_TFLOPS
         else:
             dom = "col_pass" if ms5[2] >= ms5[1] else "row_pass"
             dom_bytes = (b_col if dom == "col_pass" else b_row) / S   # taps cover one draw

@@ -520,7 +520,10 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         launch_expdot3(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E
         const int nbx3 = (Dd + 255) / 256;
         const int qt3 = (int)((ct->n_rows + 63) / 64);
-        int ch3 = (512 + nbx3 - 1) / nbx3;                 // ~2 workgroups of 8 waves per CU
+        // one 110 KB workgroup per CU: size the Q chunks so that the launch is a whole number of
+        // rounds of 256 workgroups (6 of them; 5 chunks = 590 workgroups ran 2.3 rounds, the last
+        // one a third full)
+        int ch3 = (6 * 256 + nbx3 / 2) / nbx3;
         if (ch3 > qt3) ch3 = qt3;
         if (ch3 < 1) ch3 = 1;
         ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr,

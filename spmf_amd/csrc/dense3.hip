@@ -18,16 +18,27 @@
 // matrix rate that round trip (120 GB per step at C4) would be the bound.
 //
 // Layout.  A workgroup is 8 waves; each wave owns 32 rows of P as the B operand of
-//     X = Q_tile P_tile^T                 (A = rows of Q from LDS, 4 k-steps x 6 products)
+//     X = Q_tile P_tile^T                 (A = rows of Q from LDS, 4 k-steps x 6 products;
+//                                          a1 b1 and the five small products accumulate apart)
 // so X has the P row on the lane and the Q row in the 16 accumulator registers; E = exp(X),
-// split in registers, is the B operand of
-//     out^T[k, p] += sum_q Q^T[k, q] E[q, p]   (A = columns of Q from LDS, 2 x 2 x 6 MFMAs)
-// with the k order of a step fixed by the accumulator's row order (cdna guide, "an
-// accumulator tile as the next MFMA's operand": element j of lane half h is row
-// 16 s + 8 (j >> 2) + 4 h + (j & 3)).  A Q tile (64 rows) is split once while it is staged and
-// kept in LDS as two images per plane: [q][k] for the first product and [k][q in that row
-// order] for the second, both with 144-byte rows (36 dwords: the 16 lanes of a ds_read_b128
-// service group then cover all 64 banks).
+// split in registers into TWO planes, is the B operand of
+//     out^T[k, p] += sum_q Q^T[k, q] E[q, p]   (A = columns of Q from LDS, 2 x 2 x 5 MFMAs)
+// with the k order of a step fixed by the accumulator's row order (cdna guide, "an accumulator
+// tile as the next MFMA's operand": element j of lane half h is row 16 s + 8 (j >> 2) + 4 h +
+// (j & 3)).  A Q tile (128 rows) is split once while it is staged -- a thread owns 8 consecutive k
+// of a row: two 16-byte loads, three 16-byte LDS stores -- and kept in LDS as ONE image per
+// plane, [q][k] with 144-byte rows (36 dwords: the 16 lanes of a ds_read_b128 service group
+// cover all 64 banks).  The first product reads its A fragments as rows (ds_read_b128), the
+// second reads the same image column-wise with the transposing LDS load ds_read_b64_tr_b16
+// (two 4-row blocks per fragment: rows 16 s2 + 4 h .. + 3 and 16 s2 + 8 + 4 h .. + 3).  Two
+// buffers of 3 x 18 KB: one barrier per 176 MFMAs and wave.
+// Measured on C4 (two launches): 43.1 ms serial body, six products everywhere, E in three planes,
+// two LDS images of 64-row tiles -> 38.3 pipelined body + two-plane E -> 33.8 staging loads at
+// immediate offsets + paired conversions + launches sized to whole rounds of workgroups -> 31.3
+// one image + transposing loads + 128-row tiles.  88 MFMAs per 64 x 32 cells = 1.35 PFLOP/s of
+// bf16 issue, at the rate the guide measures for bf16 GEMMs on random data (1.25 PFLOP/s: the
+// chip lowers its clock under matrix load); without the exp/split vector work 31.4 -> 28 ms,
+// without restaging ~ the same: what is left is the clock.
 #include "common.h"
 #include "kernels.h"
 
@@ -41,9 +52,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kQT3 = 64;          // Q rows per stage
 constexpr int kPitch3 = 144;      // bytes per LDS row (128 of data + 16)
-constexpr int kNW3 = 8;           // waves per workgroup
 
 // two floats -> one register of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
@@ -67,27 +76,24 @@ __device__ __forceinline__ Split3 split3(float x) {
 
 }  // namespace
 
-// One Q tile (two 32-row sub-tiles) for one wave, branch free (EDGE is a template
-// parameter) so that the whole body is ONE scheduling region, written in the order the
-// in-order issue should see it:
-//   A(s0)                       24 MFMAs, nothing to overlap yet
-//   A(s1)  beside  exp/split(s0)    the VALU work of a sub-tile fits the issue slots 24 MFMAs leave
-//   C(s0)  beside  exp/split(s1)
-//   C(s1)  beside  the split + LDS writes of the NEXT tile's staging registers
-// A(.) = X = Q_sub P^T (6 partial products per k-step; a1 b1 and the five small ones accumulate
-// apart and are added once: measured, the entry-wise gradient error at exponents of 45 - 60
-// falls from 1.1 - 1.6e-5 to 6 - 8e-6, below the exact-f32 kernel's 1.6 - 2.3e-5);
-// C(.) = out^T += Q^T E with E in TWO planes: |E - (e1 + e2)| <= 2^-18 E term by term, all terms of
-// the sum positive, so 3.8e-6 of the result at worst; e1 (q1 + q2 + q3) + e2 (q1 + q2) = 5 MFMAs.
+// One Q tile (four 32-row sub-tiles) for one wave, branch free (EDGE is a template parameter) so
+// that the whole body is ONE scheduling region, written in the order the in-order issue should
+// see it (A = first product of a sub-tile, E = exp + split, C = second product):
+//   A0 | A1 + E0 | C0 | A2 + E1 | C1 | A3 + E2 | C2 + E3 | C3
+// with sched_group_barrier asking for one MFMA per few vector instructions where both are present.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int kQT3 = 128;
+
 template <int KD, bool EDGE>
-__device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ img_row,
-                                             const unsigned char* __restrict__ img_col,
-                                             const bf16x8 (&pb)[KD / 16][3], f32x16 (&acc)[KD / 32],
-                                             float& es_tile, float& xmax, int r, int h, int q0, int NQ, bool p_in) {
-  constexpr int KS = KD / 16, MT = KD / 32;
+__device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ img, uint32_t lds_tr_base,
+                                              const bf16x8 (&pb)[KD / 16][3], f32x16 (&acc)[KD / 32],
+                                              float& es_tile, float& xmax, int r, int h, int q0, int NQ,
+                                              bool p_in) {
+  constexpr int KS = KD / 16, MT = KD / 32, NSUB = kQT3 / 32;
   constexpr int IMG = kQT3 * kPitch3;
-  f32x16 xh[2], xl[2];
-  u32x4 eb[2][2][2];             // [sub][s2][plane]: 8 bf16 = the B fragment of one k-step
+  f32x16 xh[NSUB], xl[NSUB];
+  u32x4 eb[NSUB][2][2];          // [sub][s2][plane]
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto productA = [&](int sub) {
 #pragma unroll
@@ -95,8 +101,7 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
       bf16x8 a[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        a[pl] = *reinterpret_cast<const bf16x8*>(img_row + pl * IMG + (32 * sub + r) * kPitch3 + (16 * s + 8 * h) * 2);
-      // (the first MFMA of each chain takes the constant 0 as its accumulator: no register zeroing)
+        a[pl] = *reinterpret_cast<const bf16x8*>(img + pl * IMG + (32 * sub + r) * kPitch3 + (16 * s + 8 * h) * 2);
       xl[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], pb[s][0], s == 0 ? zero16 : xl[sub], 0, 0, 0);
       xl[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], pb[s][1], xl[sub], 0, 0, 0);
       xl[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], pb[s][2], xl[sub], 0, 0, 0);
@@ -106,31 +111,31 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
     }
   };
   auto expsplit = [&](int sub) {
-    float part = 0.f;
+    f32x2 part2 = {0.f, 0.f};
+    constexpr float kLog2e = 1.4426950408889634f;
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
-      float x0 = xh[sub][i] + xl[sub][i], x1 = xh[sub][i + 1] + xl[sub][i + 1];
-      float e0, e1;
+      const f32x2 xa = {xh[sub][i], xh[sub][i + 1]}, xb = {xl[sub][i], xl[sub][i + 1]};
+      f32x2 x = xa + xb;
       if (EDGE) {
         const int qa = q0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const bool in0 = p_in && qa < NQ, in1 = p_in && qa + 1 < NQ;
-        x0 = in0 ? x0 : 0.f;
-        x1 = in1 ? x1 : 0.f;
-        e0 = in0 ? __expf(fminf(x0, kYSat)) : 0.f;
-        e1 = in1 ? __expf(fminf(x1, kYSat)) : 0.f;
-      } else {
-        e0 = __expf(fminf(x0, kYSat));
-        e1 = __expf(fminf(x1, kYSat));
+        x[0] = (p_in && qa < NQ) ? x[0] : -INFINITY;          // exp -> 0, and never the maximum
+        x[1] = (p_in && qa + 1 < NQ) ? x[1] : -INFINITY;
       }
-      xmax = __builtin_fmaxf(xmax, __builtin_fmaxf(x0, x1));
-      part += e0 + e1;
-      // two planes, two elements per register: cvt_pk, unpack (shift / mask), subtract, cvt_pk
-      const uint32_t p1 = pack_bf16(e0, e1);
-      const uint32_t p2 = pack_bf16(e0 - bf16_lo(p1), e1 - bf16_hi(p1));
+      xmax = __builtin_fmaxf(xmax, __builtin_fmaxf(x[0], x[1]));
+      const f32x2 y = x * kLog2e;
+      f32x2 e;
+      e[0] = __builtin_amdgcn_exp2f(fminf(y[0], kYSat * kLog2e));
+      e[1] = __builtin_amdgcn_exp2f(fminf(y[1], kYSat * kLog2e));
+      part2 += e;
+      const uint32_t p1 = pack_bf16(e[0], e[1]);
+      const f32x2 hi = {bf16_lo(p1), bf16_hi(p1)};
+      const f32x2 rr = e - hi;
+      const uint32_t p2 = pack_bf16(rr[0], rr[1]);
       eb[sub][i >> 3][0][(i & 7) >> 1] = p1;
       eb[sub][i >> 3][1][(i & 7) >> 1] = p2;
     }
-    es_tile += part;
+    es_tile += part2[0] + part2[1];
   };
   auto productC = [&](int sub) {
 #pragma unroll
@@ -139,9 +144,16 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
       for (int m = 0; m < MT; ++m) {
         bf16x8 a[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          a[pl] = *reinterpret_cast<const bf16x8*>(img_col + pl * IMG + (32 * m + r) * kPitch3 +
-                                                   (32 * sub + 16 * s2 + 8 * h) * 2);
+        for (int pl = 0; pl < 3; ++pl) {
+          // lds_tr_base: this lane's address inside a 4-row x 16-column block (rows = q, columns = k)
+          const uint32_t ad = lds_tr_base + pl * IMG + (32 * sub + 16 * s2) * kPitch3 + 32 * m * 2;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(uintptr_t)ad);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(uintptr_t)(ad + 8 * kPitch3));
+          const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          a[pl] = __builtin_bit_cast(bf16x8, both);
+        }
         const bf16x8 e1v = __builtin_bit_cast(bf16x8, eb[sub][s2][0]);
         const bf16x8 e2v = __builtin_bit_cast(bf16x8, eb[sub][s2][1]);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], e2v, acc[m], 0, 0, 0);
@@ -151,46 +163,62 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], e1v, acc[m], 0, 0, 0);
       }
   };
+  // issue order: A0 | A1 + E0 | C0 | A2 + E1 | C1 | A3 + E2 | C2 + E3 | C3
   productA(0);
   productA(1);
   expsplit(0);
-  // issue order wanted: one MFMA of A(s1), then ~6 VALU of exp/split(s0), 24 times
 #pragma unroll
   for (int i = 0; i < 24; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
   }
   productC(0);
+  productA(2);
   expsplit(1);
+#pragma unroll
+  for (int i = 0; i < 44; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+  }
+  productC(1);
+  productA(3);
+  expsplit(2);
+#pragma unroll
+  for (int i = 0; i < 44; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+  }
+  productC(2);
+  expsplit(3);
 #pragma unroll
   for (int i = 0; i < 20; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
   }
-  productC(1);
+  productC(3);
 }
 
 template <int KD>
-__global__ __launch_bounds__(kNW3 * 64, 2) void expdot3_kernel(int NP, int NQ, const float* __restrict__ P,
-                                                               const float* __restrict__ Q,
-                                                               float* __restrict__ out, float sign,
-                                                               double* __restrict__ esum, int atomic_out) {
-  static_assert(KD == 64, "expdot3: K padded to 64 (BASELINE config 4); other K use the f32-MFMA kernels");
-  constexpr int KS = KD / 16;     // k-steps of the first product
-  constexpr int MT = KD / 32;     // 32-feature tiles of the second
-  constexpr int IMG = kQT3 * kPitch3;          // bytes of one plane of one image (64 rows either way)
-  // [buffer][image: 0 rows of Q, 1 columns of Q][plane]
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][3][IMG];
+__global__ __launch_bounds__(512, 2) void expdot3_kernel(int NP, int NQ, const float* __restrict__ P,
+                                                          const float* __restrict__ Q, float* __restrict__ out,
+                                                          float sign, double* __restrict__ esum, int atomic_out) {
+  static_assert(KD == 64, "expdot3b: K padded to 64");
+  constexpr int KS = KD / 16, MT = KD / 32, NW = 8, NT = NW * 64;
+  constexpr int IMG = kQT3 * kPitch3;
+  constexpr int NPC = kQT3 * (KD / 8) / NT;    // (row, 8 k) pieces per loader thread
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][IMG];
   __shared__ double red[16];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int p0 = (blockIdx.x * kNW3 + wid) * 32;
-  const int p = p0 + r;
+  const int p = (blockIdx.x * NW + wid) * 32 + r;
   const int ntiles = (NQ + kQT3 - 1) / kQT3;
   const int tpc = (ntiles + gridDim.y - 1) / gridDim.y;
   const int tile0 = blockIdx.y * tpc, tile1 = min(ntiles, tile0 + tpc);
+  // transposed-read lane address inside a block: lane 4 q' + pp of a 16-lane group supplies
+  // row q' (+ 4 h: the lane half's rows), columns 16 g16 + 4 pp .. + 3
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&lds[0][0][0];
+  const uint32_t tr_lane = (uint32_t)((((lane & 15) >> 2) + 4 * h) * kPitch3 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
 
-  // ---- P fragments: B operand of the first product, B[k = 16 s + 8 h + j][col r] -------
   bf16x8 pb[KS][3];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -207,9 +235,7 @@ __global__ __launch_bounds__(kNW3 * 64, 2) void expdot3_kernel(int NP, int NQ, c
       pb[s][0][j] = sp.a; pb[s][1][j] = sp.b; pb[s][2][j] = sp.c;
     }
   }
-  // two-level accumulation as in dense.hip: runs of FOLD tiles (512 terms) in the MFMA
-  // accumulator, finished runs summed in `tot`
-  constexpr int FOLD = 8;
+  constexpr int FOLD = 4;                       // 4 tiles of 128 = runs of 512 terms, as before
   f32x16 acc[MT], tot[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -218,35 +244,45 @@ __global__ __launch_bounds__(kNW3 * 64, 2) void expdot3_kernel(int NP, int NQ, c
   double es = 0.0;
   float xmax = 0.f;
 
-  // ---- stage loader: thread (kcol, g) moves Q[8 rows of group g][kcol] ------------------
-  // group g = (a, b): rows 16 a + 4 b + {0..3} and 16 a + 8 + 4 b + {0..3} -- the eight rows
-  // whose slots in the column image are contiguous (16 a + 8 b .. + 7)
-  const int kcol = t % KD, g = t / KD, ga = g >> 1, gb = g & 1;
-  float stage[8];
+  // ---- stage loader: piece pc = t + NT j: row pc / 8 of the tile, k = 8 (pc % 8) .. + 7 -------
+  float4 st0[NPC], st1[NPC];
   auto gload = [&](int tile) {
     const int q0 = tile * kQT3;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int q = q0 + 16 * ga + 8 * (i >> 2) + 4 * gb + (i & 3);
-      stage[i] = q < NQ ? Q[(size_t)q * KD + kcol] : 0.f;
+    for (int j = 0; j < NPC; ++j) {
+      const int pc = t + NT * j, row = pc >> 3, k8 = (pc & 7) * 8;
+      // rows past NQ read the last row (always in bounds) and are zeroed: no branch, no
+      // exec masking around the loads
+      const int qr = min(q0 + row, NQ - 1);
+      const float* src = Q + (size_t)qr * KD + k8;
+      const float keep = q0 + row < NQ ? 1.f : 0.f;
+      const float4 a = *reinterpret_cast<const float4*>(src);
+      const float4 b = *reinterpret_cast<const float4*>(src + 4);
+      st0[j] = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
+      st1[j] = make_float4(b.x * keep, b.y * keep, b.z * keep, b.w * keep);
     }
   };
   auto swrite = [&](int buf) {
-    bf16x8 c3[3];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const Split3 sp = split3(stage[i]);
-      c3[0][i] = sp.a; c3[1][i] = sp.b; c3[2][i] = sp.c;
-      const int ql = 16 * ga + 8 * (i >> 2) + 4 * gb + (i & 3);
-      // row image: [q][k]
-      *reinterpret_cast<__bf16*>(&lds[buf][0][0][ql * kPitch3 + kcol * 2]) = sp.a;
-      *reinterpret_cast<__bf16*>(&lds[buf][0][1][ql * kPitch3 + kcol * 2]) = sp.b;
-      *reinterpret_cast<__bf16*>(&lds[buf][0][2][ql * kPitch3 + kcol * 2]) = sp.c;
+    for (int j = 0; j < NPC; ++j) {
+      const int pc = t + NT * j, row = pc >> 3, k8 = (pc & 7) * 8;
+      const float v[8] = {st0[j].x, st0[j].y, st0[j].z, st0[j].w, st1[j].x, st1[j].y, st1[j].z, st1[j].w};
+      u32x4 c3[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x0 = v[2 * e], x1 = v[2 * e + 1];
+        const uint32_t p1 = pack_bf16(x0, x1);
+        x0 -= bf16_lo(p1);
+        x1 -= bf16_hi(p1);
+        const uint32_t p2 = pack_bf16(x0, x1);
+        x0 -= bf16_lo(p2);
+        x1 -= bf16_hi(p2);
+        c3[0][e] = p1; c3[1][e] = p2; c3[2][e] = pack_bf16(x0, x1);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<u32x4*>(&lds[buf][pl][row * kPitch3 + k8 * 2]) = c3[pl];
     }
-    // column image: [k][slot], the eight slots of this group are one 16-byte piece
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      *reinterpret_cast<bf16x8*>(&lds[buf][1][pl][kcol * kPitch3 + (16 * ga + 8 * gb) * 2]) = c3[pl];
   };
 
   if (tile0 < tile1) {
@@ -254,17 +290,18 @@ __global__ __launch_bounds__(kNW3 * 64, 2) void expdot3_kernel(int NP, int NQ, c
     swrite(0);
   }
   __syncthreads();
-  const bool p_edge = (int)(blockIdx.x * kNW3 * 32 + kNW3 * 32) > NP;      // block-uniform
+  const bool p_edge = (int)(blockIdx.x * NW * 32 + NW * 32) > NP;      // block-uniform
   for (int tile = tile0; tile < tile1; ++tile) {
     const int buf = (tile - tile0) & 1;
     const bool more = tile + 1 < tile1;                    // block-uniform
     if (more) gload(tile + 1);                             // lands under this tile's MFMAs
     const int q0 = tile * kQT3;
     float es_tile = 0.f;
+    const uint32_t trb = lds0 + buf * 3 * IMG + tr_lane;
     if (p_edge || q0 + kQT3 > NQ)
-      expdot3_tile<KD, true>(&lds[buf][0][0][0], &lds[buf][1][0][0], pb, acc, es_tile, xmax, r, h, q0, NQ, p < NP);
+      expdot3_tile<KD, true>(&lds[buf][0][0], trb, pb, acc, es_tile, xmax, r, h, q0, NQ, p < NP);
     else
-      expdot3_tile<KD, false>(&lds[buf][0][0][0], &lds[buf][1][0][0], pb, acc, es_tile, xmax, r, h, q0, NQ, true);
+      expdot3_tile<KD, false>(&lds[buf][0][0], trb, pb, acc, es_tile, xmax, r, h, q0, NQ, true);
     es += (double)es_tile;
     if (((tile - tile0) % FOLD) == FOLD - 1) {             // block-uniform: close the run
 #pragma unroll
@@ -278,7 +315,6 @@ __global__ __launch_bounds__(kNW3 * 64, 2) void expdot3_kernel(int NP, int NQ, c
     if (more) swrite(buf ^ 1);
     __syncthreads();
   }
-  // ---- store: lane holds features (i&3) + 8(i>>2) + 4h (+ 32 m) of row p ------------------
   if (p < NP) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -299,7 +335,6 @@ __global__ __launch_bounds__(kNW3 * 64, 2) void expdot3_kernel(int NP, int NQ, c
   if (esum) {
     const double tsum = block_sum(es, red);
     if (t == 0) atomicAdd(esum, tsum);
-    // esum[1] = dacc[4]: workgroups in which an exponent exceeded kYSat (dense.hip)
     const double ts = block_sum(xmax > kYSat ? 1.0 : 0.0, red);
     if (t == 0 && ts != 0.0) atomicAdd(esum + 1, 1.0);
   }
@@ -307,10 +342,10 @@ __global__ __launch_bounds__(kNW3 * 64, 2) void expdot3_kernel(int NP, int NQ, c
 
 bool launch_expdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
   if (KD != 64 || a.act != 0 || a.bias_p || a.bias_q || a.out2 || a.out_rows || a.est) return false;
-  const int nbx = (a.NP + kNW3 * 32 - 1) / (kNW3 * 32);
   const int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
-  hipLaunchKernelGGL((expdot3_kernel<64>), dim3(nbx, chunks), dim3(kNW3 * 64), 0, st, a.NP, a.NQ, a.P, a.Q,
-                     a.out, a.sign, a.esum, a.atomic_out);
+  const int nbx = (a.NP + 255) / 256;
+  hipLaunchKernelGGL((expdot3_kernel<64>), dim3(nbx, chunks), dim3(512), 0, st, a.NP, a.NQ, a.P, a.Q, a.out,
+                     a.sign, a.esum, a.atomic_out);
   return true;
 }
 

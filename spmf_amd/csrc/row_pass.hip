@@ -36,9 +36,6 @@ namespace spmf {
 #ifndef ROW_MAX_BLOCKS
 #define ROW_MAX_BLOCKS 4096
 #endif
-#ifndef ROW_BAL
-#define ROW_BAL 0
-#endif
 #ifndef ROW_WAVES_PER_SIMD
 #define ROW_WAVES_PER_SIMD 1
 #endif
@@ -85,17 +82,7 @@ struct RowCtx {
   __device__ __forceinline__ void sweep1(int c, float x, int nchunk, float4& zacc) const {
 #pragma unroll
     for (int g0 = 0; g0 < LPN; g0 += GRP) {
-#if ROW_BAL
-      // gather instructions carrying entries in this group of GRP (wave-uniform): the
-      // last group of a chunk issues only those
-      const int cnt = (nchunk - g0 * NPI + NPI - 1) / NPI;
-      if (cnt >= GRP) s1_group<GRP>(c, x, g0, zacc);
-      else if (GRP > 3 && cnt == 3) s1_group<(GRP > 3 ? 3 : 1)>(c, x, g0, zacc);
-      else if (GRP > 2 && cnt == 2) s1_group<(GRP > 2 ? 2 : 1)>(c, x, g0, zacc);
-      else if (cnt >= 1) s1_group<1>(c, x, g0, zacc);
-#else
       if (g0 * NPI < nchunk) s1_group<GRP>(c, x, g0, zacc);  // wave-uniform
-#endif
     }
   }
 
@@ -133,17 +120,8 @@ struct RowCtx {
     float rmine = 0.f;
 #pragma unroll
     for (int g0 = 0; g0 < LPN; g0 += GRP) {
-#if ROW_BAL
-      const int cnt = (nchunk - g0 * NPI + NPI - 1) / NPI;
-      if (cnt >= GRP) s2_gather<GRP>(c, g0, z, vv, rmine);
-      else if (GRP > 3 && cnt == 3) s2_gather<(GRP > 3 ? 3 : 1)>(c, g0, z, vv, rmine);
-      else if (GRP > 2 && cnt == 2) s2_gather<(GRP > 2 ? 2 : 1)>(c, g0, z, vv, rmine);
-      else if (cnt >= 1) s2_gather<1>(c, g0, z, vv, rmine);
-      else s2_gather<0>(c, g0, z, vv, rmine);
-#else
       if (g0 * NPI < nchunk) s2_gather<GRP>(c, g0, z, vv, rmine);
       else s2_gather<0>(c, g0, z, vv, rmine);
-#endif
     }
     // one entry per lane: lane (grp,sub) owns slot sub*NPI+grp
     const int slot = sub * NPI + grp;
@@ -185,15 +163,7 @@ struct RowCtx {
     }
 #pragma unroll
     for (int g0 = 0; g0 < LPN; g0 += GRP) {
-#if ROW_BAL
-      const int cnt = (nchunk - g0 * NPI + NPI - 1) / NPI;
-      if (cnt >= GRP) s2_back<GRP>(cc, g0, vv, gz);
-      else if (GRP > 3 && cnt == 3) s2_back<(GRP > 3 ? 3 : 1)>(cc, g0, vv, gz);
-      else if (GRP > 2 && cnt == 2) s2_back<(GRP > 2 ? 2 : 1)>(cc, g0, vv, gz);
-      else if (cnt >= 1) s2_back<1>(cc, g0, vv, gz);
-#else
       if (g0 * NPI < nchunk) s2_back<GRP>(cc, g0, vv, gz);
-#endif
     }
   }
 };
@@ -203,21 +173,6 @@ struct RowCtx {
 // BT: threads per workgroup.  256: phi from global memory.  512 / 1024: phi staged in LDS
 // (4*D bytes of dynamic LDS: two workgroups per CU up to D = 20 480, one up to 40 960),
 // four waves per SIMD either way.
-// Length of the first register chunk of a short row (<= 128 entries).  Balanced: both
-// chunks get half of the row's gather instructions (100 entries: 56 + 44 = 7 + 6
-// instructions instead of 64 + 36 = 8 + 8 with the whole-group guard).
-template <int KP>
-__device__ __forceinline__ int row_first_len(int n) {
-#if ROW_BAL
-  constexpr int NPI = 64 / (KP / 4);
-  if (n <= 64) return n;
-  const int ni = (n + NPI - 1) / NPI;
-  return NPI * ((ni + 1) >> 1);
-#else
-  return n < 64 ? n : 64;
-#endif
-}
-
 template <int KP, int LIK, int BT = 256>
 __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pass_kernel(
     int64_t B, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
@@ -272,7 +227,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     start = row_ptr[wave];
     end = row_ptr[wave + 1];
     xi = row_scale ? row_scale[wave] : 1.f;
-    const int f0 = row_first_len<KP>(end - start);
+    const int f0 = min(end - start, 64);
     const int i0 = start + lane, i1 = start + f0 + lane;
     pc0 = lane < f0 ? __builtin_nontemporal_load(&col[i0]) : 0;
     px0 = lane < f0 ? __builtin_nontemporal_load(&val[i0]) : 0.f;
@@ -290,7 +245,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     int qc0 = 0, qc1 = 0, nnstart = 0, nnend = 0;
     float qx0 = 0.f, qx1 = 0.f, nnxi = 1.f;
     if (b + nwaves < B) {
-      const int f0 = row_first_len<KP>(nend - nstart);
+      const int f0 = min(nend - nstart, 64);
       const int j0 = nstart + lane, j1 = nstart + f0 + lane;
       qc0 = lane < f0 ? __builtin_nontemporal_load(&col[j0]) : 0;
       qx0 = lane < f0 ? __builtin_nontemporal_load(&val[j0]) : 0.f;
@@ -309,7 +264,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       // ---- short row: col/val stay in registers for both sweeps ----------
       const int c0 = pc0, c1 = pc1;
       const float x0 = px0, x1 = px1;
-      const int n0 = row_first_len<KP>(n), n1 = n - n0;
+      const int n0 = min(n, 64), n1 = n - 64;
       if (mode != 2) {
         cx.sweep1(c0, x0, n0, zacc);
         if (n1 > 0) cx.sweep1(c1, x1, n1, zacc);

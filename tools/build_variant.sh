@@ -9,11 +9,13 @@ src=$root/spmf_amd/csrc
 out=$root/spmf_amd/variants
 tmp=$(mktemp -d)
 mkdir -p $out
+pids=()
 for f in api prep row_pass col_pass finish stats dense dense3 dense_ll surrogate; do
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -DSPMF_BUILD --offload-arch=gfx950 \
-      -Wno-unused-function -I$root/include -I$src $extra -c $src/$f.hip -o $tmp/$f.o ) &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -DSPMF_BUILD --offload-arch=gfx950 \
+      -Wno-unused-function -I$root/include -I$src $extra -c $src/$f.hip -o $tmp/$f.o &
+  pids+=($!)
 done
-wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,--version-script=$src/exports.map $tmp/*.o -o $out/libspmf_$name.so -ldl
+for p in "${pids[@]}"; do wait $p || { echo "build_variant: a compile failed"; rm -rf $tmp; exit 1; }; done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,--version-script=$src/exports.map -Wl,--no-undefined $tmp/*.o -o $out/libspmf_$name.so -ldl
 rm -rf $tmp
 echo built $out/libspmf_$name.so
