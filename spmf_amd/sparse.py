@@ -123,6 +123,7 @@ class SparseCounts:
                                  torch.zeros(PC_PAD, dtype=torch.int32, device=dev)]).contiguous()
         self.pc_val = torch.cat([self.val[order],
                                  torch.zeros(PC_PAD, dtype=torch.float32, device=dev)]).contiguous()
+        self.pc_pad = PC_PAD       # what batch_struct reports (0 selects the entry-at-a-time fetch)
         cnt = torch.bincount(key, minlength=nP * D)
         excl = torch.zeros(nP * D + 1, dtype=torch.int64, device=dev)
         excl[1:] = torch.cumsum(cnt, 0)
@@ -285,7 +286,7 @@ class SparseCounts:
         cs.items = self.items.data_ptr()
         cs.max_items_per_panel = (int(self.items_per_panel[p0:p1].max())
                                   if self.items.numel() else 0)
-        cs.pc_pad = PC_PAD
+        cs.pc_pad = int(self.pc_pad)
         if self.col_split > 0:
             cs.item_mid = self.item_mid.data_ptr() + 4 * p0
             cs.col_split = self.col_split

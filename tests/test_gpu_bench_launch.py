@@ -34,8 +34,11 @@ def _last_json(text):
     raise AssertionError("no JSON line in:\n" + text[-2000:])
 
 
-@pytest.mark.timeout(600)
-def test_torchrun_one_rank_rccl_library_comm_matches_the_plain_run():
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("transport", ["lib", "torch"])
+def test_torchrun_one_rank_rccl_matches_the_plain_run(transport):
+    """transport "torch": the driver's own launch (no SPMF_BENCH_COMM: torch.distributed's RCCL
+    process group moves the accumulators); "lib": the library's communicator (spmf_allreduce)."""
     args = ["bench.py", "--gpus", "1", "--workload", "small", "--steps", "3", "--warmup", "1",
             "--no-cpu-baseline", "--no-extras"]
     env = dict(os.environ)
@@ -46,7 +49,10 @@ def test_torchrun_one_rank_rccl_library_comm_matches_the_plain_run():
                            text=True, timeout=280)
     assert plain.returncode == 0, plain.stderr[-2000:]
     ref = _last_json(plain.stdout)
-    env["SPMF_BENCH_COMM"] = "lib"
+    if transport == "lib":
+        env["SPMF_BENCH_COMM"] = "lib"
+    else:
+        env.pop("SPMF_BENCH_COMM", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)

@@ -305,3 +305,28 @@ def test_column_split_step_equals_unsplit(K):
     assert_close_grads(grads1, gref, scales)
     with pytest.raises(ValueError):
         m1.enable_column_split(50)
+
+
+@pytest.mark.parametrize("K", [3, 16, 32, 64])
+def test_column_pass_without_list_padding_uses_the_narrow_fetch(K):
+    """spmf_counts.pc_pad = 0 (a C-ABI caller whose panel-CSC arrays carry no padding): the library
+    must fall back to the entry-at-a-time fetch, which never reads behind a list, and give the same
+    gradients as the 16-byte fetches (both against the oracle, entry by entry)."""
+    from spmf_amd import SparseCounts
+    cfg, x, params = make_problem(300, 150, K, 1, 4400 + K, 0.25, empty=True)
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    scales = O.energy_grad_scales(cfg, x, params)
+    out = {}
+    for pad in (None, 0):
+        m = build_model(cfg, panel_rows=64)
+        sc = SparseCounts.from_any(x, "cuda", 64)
+        if pad is not None:
+            sc.pc_pad = pad
+        parts, grads, nnf = m.energy_and_grads({"counts": sc}, params)
+        assert float(nnf.sum()) == 0
+        assert_close_parts(parts, pref)
+        assert_close_grads(grads, gref, scales, tag=f"pc_pad={pad}")
+        out[pad] = grads
+    for k in ("u", "v", "w", "s"):
+        a, b = out[None][k].double(), out[0][k].double()
+        assert float((a - b).abs().max()) <= 1e-5 * float(scales[k].max())
