@@ -34,10 +34,31 @@ def _sqrt_inv_gamma(y, conc, scale):
     return _inv_gamma(y * y, conc, scale) + math.log(2.0) + torch.log(y)
 
 
+def _abs_horseshoe(y, scale):
+    """bayesianquilts AbsHorseshoe (poisson.py:382,391) = tfd.Horseshoe(scale).log_prob folded onto
+    y >= 0; TFP's closed-form approximation of the HalfCauchy-Normal marginal, the same
+    constants as csrc/finish.hip abs_horseshoe."""
+    g, b, h_inf, pw = 0.5614594835668851, 1.0420764938351215, 1.0801359952503342, 1.0919284281983377
+    t = 0.5 * (y / scale) ** 2
+    q = (20.0 / 47.0) * t ** pw
+    h = 1.0 / (1.0 + t ** 1.5) + h_inf * q / (1.0 + q)
+    a = (math.log1p(-g) - math.log(g)) - t / (1.0 - g)
+    return (-torch.nn.functional.softplus(a) + torch.log(torch.log1p(g / t - (1.0 - g) / (h + b * t) ** 2))
+            - 0.5 * math.log(2.0 * math.pi ** 3) - torch.log(g * scale) + math.log(2.0))
+
+
 def prior_parts(model, p):
-    """The prior of create_distributions (poisson.py:228-377, horseshoe-plus)."""
+    """The prior of create_distributions: the horseshoe-plus hierarchy (poisson.py:228-377) or,
+    with horshoe_plus=False, AbsHorseshoe on u and s (poisson.py:378-398)."""
     if not model.horseshoe_plus:
-        raise NotImplementedError("custom encoder/decoder callables with horshoe_plus=False")
+        dt, dev = p["u"].dtype, p["u"].device
+        K = model.latent_dim
+        decay = (model.symmetry_breaking_decay ** torch.arange(K, dtype=dt, device=dev))[None, :]
+        one = torch.ones((), dtype=dt, device=dev)
+        sm = lambda t: t.sum((-1, -2))
+        return {"v": sm(_halfnormal(p["v"], 0.1 * one)), "w": sm(_halfnormal(p["w"], one)),
+                "u": sm(_abs_horseshoe(p["u"], model.u_tau_scale * decay * torch.ones_like(p["u"]))),
+                "s": sm(_abs_horseshoe(p["s"], model.s_tau_scale * torch.ones_like(p["s"])))}
     dt = p["u"].dtype
     K = model.latent_dim
     decay = (model.symmetry_breaking_decay ** torch.arange(K, dtype=dt, device=p["u"].device))[None, :]
@@ -53,6 +74,35 @@ def prior_parts(model, p):
     return out
 
 
+def _rate(model, x, p, enc, dec, eta):
+    s = p["s"]
+    weights = s / s.sum(-2, keepdim=True)
+    A = weights[..., 0, :].unsqueeze(-1) * p["u"]                      # poisson.py:652-666
+    phi = eta * weights[..., 1, :].unsqueeze(-2) * p["w"]              # :680-701
+    theta = torch.matmul(enc(x), A)                                    # :640-643
+    if model.scale_rows:
+        theta = theta * (x.sum(-1, keepdim=True) / float(model.xi_u_global))
+    return theta, dec(torch.matmul(theta, p["v"])) + phi               # :174-177
+
+
+def log_likelihood_components(model, x_dense, s, u, v, w):
+    """poisson.py:156-184 for user callables: {'log_likelihood', 'rate'} as [S,B,D] float32 on the
+    model's device (no sample axis when the parameters have none)."""
+    dev, dt = model.device, torch.float64
+    enc, dec = model._custom_codec
+    p = {k: torch.as_tensor(t, device=dev).to(dt) for k, t in (("s", s), ("u", u), ("v", v), ("w", w))}
+    single = p["u"].dim() == 2
+    if single:
+        p = {k: t.unsqueeze(0) for k, t in p.items()}
+    x = x_dense.to(dev, dt)
+    _, rate = _rate(model, x, p, enc, dec, model._eta_device().to(dt))
+    ll = torch.xlogy(x, rate) - torch.lgamma(x + 1.0) - rate          # tfd.Poisson.log_prob
+    rate, ll = rate.to(torch.float32), ll.to(torch.float32)
+    if single:
+        rate, ll = rate[0], ll[0]
+    return {"log_likelihood": ll, "rate": rate}
+
+
 def energy_and_grads(model, x_dense, params, prior_weight=1.0):
     """parts (name -> [S] float64) and d(x + z + prior_weight*prior)/d(param)
     (float32, the shapes of ``params``) for a dense batch [B,D] on the device."""
@@ -66,14 +116,7 @@ def energy_and_grads(model, x_dense, params, prior_weight=1.0):
     x = x_dense.to(dev, dt)
     eta = model._eta_device().to(dt)
     parts = prior_parts(model, p)
-    s = p["s"]
-    weights = s / s.sum(-2, keepdim=True)
-    A = weights[..., 0, :].unsqueeze(-1) * p["u"]                      # poisson.py:652-666
-    phi = eta * weights[..., 1, :].unsqueeze(-2) * p["w"]              # :680-701
-    theta = torch.matmul(enc(x), A)                                    # :640-643
-    if model.scale_rows:
-        theta = theta * (x.sum(-1, keepdim=True) / float(model.xi_u_global))
-    rate = dec(torch.matmul(theta, p["v"])) + phi                      # :174-177
+    theta, rate = _rate(model, x, p, enc, dec, eta)
     bad = (x > 0) & ~((rate > 0) & torch.isfinite(rate))
     safe = torch.where(bad, torch.ones_like(rate), rate)
     ll = torch.xlogy(x, safe) - torch.lgamma(x + 1.0) - safe           # tfd.Poisson.log_prob

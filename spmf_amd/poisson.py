@@ -125,12 +125,15 @@ class PoissonFactorization:
             x = x[r0:r0 + cs.n_rows]
         parts, grads, nbad = custom_codec.energy_and_grads(self, x, params, prior_weight)
         S = nbad.shape[0]
-        block = torch.stack([parts[n] for n in PART_ORDER], 1).contiguous()
+        zero = torch.zeros(S, dtype=torch.float64, device=self.device)
+        # (horshoe_plus=False has four variables: the other parts are 0, like the kernels')
+        block = torch.stack([parts.get(n, zero) for n in PART_ORDER], 1).contiguous()
         self._last_parts = block
         self.last_saturated = torch.zeros(S, dtype=torch.float64, device=self.device)
         shapes = var_shapes(self.feature_dim, self.latent_dim)
         grads = {n: g.reshape((S,) + shapes[n]).contiguous() for n, g in grads.items()}
-        return {n: block[:, i] for i, n in enumerate(PART_ORDER)}, grads, nbad
+        return {n: block[:, i] for i, n in enumerate(PART_ORDER)
+                if n in ("z", "x") or n in self.var_order}, grads, nbad
 
     # ------------------------------------------------------------------
     # native context
@@ -474,8 +477,14 @@ class PoissonFactorization:
         (poisson.py:156-184): {'log_likelihood': [S,B,D], 'rate': [S,B,D]}
         (no sample axis when the parameters have none)."""
         if self._custom_codec is not None:
-            raise NotImplementedError(
-                "log_likelihood_components with custom encoder/decoder callables is not built")
+            from . import custom_codec
+            sc, cs = self._batch(data)
+            xd = sc.to_dense()
+            pr = data.get("panels") if isinstance(data, dict) else None
+            if pr is not None:
+                r0 = pr[0] * sc.panel_rows
+                xd = xd[r0:r0 + cs.n_rows]
+            return custom_codec.log_likelihood_components(self, xd, s, u, v, w)
         lib, h = _lib.load(), self._handle()
         sc, cs = self._batch(data)
         S, P = self._pack_params({"s": s, "u": u, "v": v, "w": w}, names=("s", "u", "v", "w"))

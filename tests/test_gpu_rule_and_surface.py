@@ -473,3 +473,46 @@ def test_finish_is_deterministic_given_the_accumulators():
     p2, g2, _ = m.energy_and_grads({"counts": x}, params)
     for k in g1:
         assert float((g1[k] - g2[k]).abs().max()) <= 1e-6 * float(g1[k].abs().max()), k
+
+
+def test_custom_callables_with_abs_horseshoe_and_dense_surface():
+    """Corners that used to raise: user callables together with horshoe_plus=False
+    (poisson.py:94-97 + :378-398) and log_likelihood_components of such a model (:156-184).
+    Callables equal to the built-in pair must reproduce the oracle's AbsHorseshoe energy and the
+    HIP model's dense surface."""
+    from spmf_amd import PoissonFactorization
+    rng = np.random.default_rng(31)
+    B, D, K, S = 40, 18, 3, 2
+    x = ((rng.random((B, D)) < 0.3) * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(B * D))
+    cfg.horseshoe_plus = False
+    cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = 4.2
+    params = O.random_params(cfg, S, 32, fp32_exact=True)
+    eta = cfg.eta_i.to("cuda")
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale, column_norms=cfg.eta_i,
+                             horshoe_plus=False, initialize_distributions=False, device="cuda", panel_rows=16,
+                             encoder_function=lambda t: t / eta.to(t.dtype),
+                             decoder_function=lambda y: y * eta.to(y.dtype))
+    m.xi_u_global = cfg.xi_u_global
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    assert float(nnf.sum()) == 0 and set(parts) == set(pref) == {"v", "w", "u", "s", "z", "x"}
+    for k, r in pref.items():
+        np.testing.assert_allclose(parts[k].cpu().numpy(), r.numpy(), rtol=1e-9, err_msg=k)
+    from _gradcheck import assert_grads_entrywise
+    assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "custom+abs-horseshoe")
+    # dense surface of a callable model == the HIP model's (same built-in pair)
+    hip = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale, column_norms=cfg.eta_i,
+                               horshoe_plus=False, initialize_distributions=False, device="cuda", panel_rows=16)
+    hip.xi_u_global = cfg.xi_u_global
+    pp = {k: T(v) for k, v in params.items()}
+    a = m.log_likelihood_components(pp["s"], pp["u"], pp["v"], pp["w"], {"counts": x})
+    b = hip.log_likelihood_components(pp["s"], pp["u"], pp["v"], pp["w"], {"counts": x})
+    ref = O.log_likelihood_components(cfg, T(x), pp["s"], pp["u"], pp["v"], pp["w"])
+    for key in ("log_likelihood", "rate"):
+        assert tuple(a[key].shape) == (S, B, D)
+        np.testing.assert_allclose(a[key].cpu().numpy(), ref[key].numpy(), rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(a[key].cpu().numpy(), b[key].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    one = m.log_likelihood_components(pp["s"][0], pp["u"][0], pp["v"][0], pp["w"][0], {"counts": x})
+    assert tuple(one["rate"].shape) == (B, D)
