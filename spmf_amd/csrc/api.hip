@@ -187,7 +187,7 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.acc = o;   o += al((size_t)S * acc_len(c->D, c->KP) * sizeof(float));
   k.dacc = o;  o += al((size_t)S * kDaccRep * (kDaccHead + KP) * sizeof(double));
   k.dprep = o; o += al((size_t)S * kPrepSeg * (KP + 1) * sizeof(double));
-  const size_t fnb = (D + 31) / 32;                       // workgroups of the finish kernel
+  const size_t fnb = (D + kFinishCols - 1) / kFinishCols;                     // workgroups of the finish kernel
   k.ppart = o; o += al((size_t)S * fnb * 12 * sizeof(double));
   k.putau = o; o += al((size_t)S * fnb * KP * sizeof(float));
   k.Ap = o;    o += al(nd * D * KP * sizeof(float));

@@ -57,6 +57,11 @@ __device__ __forceinline__ float expm1_dec(float y, float& ey) {
 // partial sums over column segments, dprep[seg][KP+1]: one writer per slot (no atomics,
 // no zero fill), and every reader folds the segments in index order (prep_sum).
 constexpr int kPrepSeg = 8;
+// columns per workgroup of the finish kernel (the per-block slots ppart/putau are sized by it)
+#ifndef FINISH_FTD
+#define FINISH_FTD 32
+#endif
+constexpr int kFinishCols = FINISH_FTD;
 // the block sums land in one of kDaccRep replicas (blockIdx % kDaccRep) so the
 // fp64 atomics of thousands of blocks do not serialise on 4+KP addresses;
 // the pack kernel folds the replicas.

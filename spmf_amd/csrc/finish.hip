@@ -23,7 +23,7 @@
 
 namespace spmf {
 
-constexpr int FTD = 32;
+constexpr int FTD = kFinishCols;
 constexpr int SPMF_NPARTS_LOCAL = 12;
 
 struct Ptrs12 {
@@ -211,11 +211,66 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
 #pragma unroll
   for (int i = 0; i < SPMF_NPARTS_LOCAL; ++i) part[i] = 0.0;
 
+  // Every global operand of the kernel is fetched here, before the first barrier and the
+  // first store: the grid is only a few waves per SIMD, so each later batch of loads
+  // (the output pointers may alias the inputs as far as the compiler knows, and a load
+  // cannot move above a barrier or an earlier store) would cost its own memory round
+  // trip in series -- five of them were most of this kernel's time.
+  constexpr int NIT = (KP * FTD + 255) / 256;
+  float in_u[NIT], in_ue[NIT], in_ua[NIT], in_ga[NIT], in_gv[NIT], in_v[NIT];
+  float old_u[NIT], old_v[NIT];   // PHASE 2 adds to what the prior half left in G
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = t + it * 256;
+    {
+      const int dl = e / KP, k = e % KP;
+      const int d = d0 + dl;
+      const bool on = e < KP * FTD && d < D && k < K;
+      const size_t i = on ? (size_t)d * K + k : 0;
+      in_u[it] = on ? P.p[U_][i] : 0.f;
+      in_ue[it] = (PRIOR && on && !hs) ? P.p[UETA_][i] : 1.f;
+      in_ua[it] = (PRIOR && on && !hs) ? P.p[UETAA_][i] : 1.f;
+      in_ga[it] = (DATA && on) ? gAp[(size_t)d * KP + k] : 0.f;
+      in_gv[it] = (DATA && e < KP * FTD && d < D) ? gVp[(size_t)d * KP + k] : 0.f;
+      old_u[it] = (PHASE == 2 && on) ? G.p[U_][i] : 0.f;
+    }
+    {
+      const int k = e / FTD, dl = e % FTD;
+      const int d = d0 + dl;
+      const bool on = e < KP * FTD && k < K && d < D;
+      in_v[it] = (PRIOR && on) ? P.p[V_][(size_t)k * D + d] : 0.f;
+      old_v[it] = (PHASE == 2 && on) ? G.p[V_][(size_t)k * D + d] : 0.f;
+    }
+  }
+  // [.,D] vectors of this thread's column (threads t < FTD)
+  const bool dcol = t < FTD && d0 + t < D;
+  const bool hier = PRIOR && !hs;
+  const int dme = dcol ? d0 + t : 0;
+  const float c_eta = dcol ? eta[dme] : 1.f;
+  const float c_s0 = dcol ? P.p[S_][dme] : 1.f, c_s1 = dcol ? P.p[S_][D + dme] : 1.f;
+  const float c_w = dcol ? P.p[W_][dme] : 0.f;
+  const float c_se0 = (hier && dcol) ? P.p[SETA_][dme] : 1.f, c_se1 = (hier && dcol) ? P.p[SETA_][D + dme] : 1.f;
+  const float c_stau = (hier && dcol) ? P.p[STAU_][dme] : 1.f, c_sta = (hier && dcol) ? P.p[STAUA_][dme] : 1.f;
+  const float c_sa0 = (hier && dcol) ? P.p[SETAA_][dme] : 1.f, c_sa1 = (hier && dcol) ? P.p[SETAA_][D + dme] : 1.f;
+  const float c_gph = (DATA && dcol) ? gph[dme] : 0.f;
+  const float old_w = (PHASE == 2 && dcol) ? G.p[W_][dme] : 0.f;
+  const float old_s0 = (PHASE == 2 && dcol) ? G.p[S_][dme] : 0.f, old_s1 = (PHASE == 2 && dcol) ? G.p[S_][D + dme] : 0.f;
+  // block 0 also closes the data term: lane k of its first wave holds
+  // (sum_b z_bk) * (sum_d A'_dk), the closed-form rate sum of the linear decoder
+  double rterm = 0.0;
+  if (DATA && blockIdx.x == 0 && t < KP && !lik_bern(logt) && logt != 1)
+    rterm = unpack(tail, kDaccHead + t) * prep_sum(dprep, KP, t);
+  const int c_bern = (lik_bern(logt) || (logt == 3 && dcol && ctype[dme])) ? 1 : 0;
+  // [1,K] vectors (their own prior is block 0's)
+  const bool kown = PRIOR && !hs && t < K;
+  const float c_ut = (!hs && t < K) ? P.p[UTAU_][t] : 1.f;
+  const float c_uta = (kown && blockIdx.x == 0) ? P.p[UTAUA_][t] : 1.f;
+
   if (t < KP) {
     // log_transform: the dense kernel already subtracted sum_b E_bd z_b from gV'
     // (mixed, code 3: still needed for the Poisson columns)
     zsum_s[t] = (!DATA || lik_exp(logt) || lik_bern(logt)) ? 0.f : (float)unpack(tail, kDaccHead + t);
-    utau_s[t] = hs ? u_tau_scale : (t < K ? P.p[UTAU_][t] : 1.f);   // hs: scale = u_tau_scale * decay^k
+    utau_s[t] = hs ? u_tau_scale : c_ut;   // hs: scale = u_tau_scale * decay^k (c_ut is 1 for k >= K)
     dec_s[t] = (float)ipow(decay, t);   // powf is ~1e-6 off at t~60: a systematic part error
     gutau_s[t] = 0.f;
     if (PRIOR) {
@@ -225,18 +280,12 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   }
   if (t < FTD) {
     const int d = d0 + t;
-    float w1 = 0.f, e = 1.f;
-    if (d < D) {
-      e = eta[d];
-      const float s0 = P.p[S_][d], s1 = P.p[S_][D + d];
-      w1 = s0 / (s0 + s1);
-    }
-    w1s[t] = w1;
-    etas_[t] = e;
-    ietas[t] = lik_exp(logt) ? 1.f : 1.f / e;   // A' = w1*u/eta (linear) or w1*u (log_transform)
+    w1s[t] = d < D ? c_s0 / (c_s0 + c_s1) : 0.f;
+    etas_[t] = c_eta;
+    ietas[t] = lik_exp(logt) ? 1.f : 1.f / c_eta;   // A' = w1*u/eta (linear) or w1*u (log_transform)
     GAs[t] = 0.f;
     // column follows the Bernoulli likelihood: all of them (code 2) or by type (mixed, code 3)
-    bern_s[t] = (lik_bern(logt) || (logt == 3 && d < D && ctype[d])) ? 1 : 0;
+    bern_s[t] = c_bern;
   }
   __syncthreads();
 
@@ -245,23 +294,6 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   // 256 % KP == 0, so a thread keeps the same k in every iteration: gut_acc
   // sums its d's in a register (LDS float atomics cost ~200 cycles each here)
   float gut_acc = 0.f;
-  // The output pointers may alias the inputs as far as the compiler knows, so a
-  // load cannot move above an earlier store: fetch the operands of ALL iterations
-  // first, otherwise every iteration pays its own memory round trip in series.
-  constexpr int NIT = (KP * FTD + 255) / 256;
-  float in_u[NIT], in_ue[NIT], in_ua[NIT], in_ga[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int e = t + it * 256;
-    const int dl = e / KP, k = e % KP;
-    const int d = d0 + dl;
-    const bool on = e < KP * FTD && d < D && k < K;
-    const size_t i = on ? (size_t)d * K + k : 0;
-    in_u[it] = on ? P.p[U_][i] : 0.f;
-    in_ue[it] = (PRIOR && on && !hs) ? P.p[UETA_][i] : 1.f;
-    in_ua[it] = (PRIOR && on && !hs) ? P.p[UETAA_][i] : 1.f;
-    in_ga[it] = (DATA && on) ? gAp[(size_t)d * KP + k] : 0.f;
-  }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = t + it * 256;
@@ -305,7 +337,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
         const float ga3 = -1.5f * ia + ia * ia;
         G.p[UETAA_][i] = pw * (ga2 + ga3);
       } else {
-        G.p[U_][i] += du;
+        G.p[U_][i] = old_u[it] + du;
       }
     }
     if (DATA) {
@@ -326,21 +358,16 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
   }
   // ---- v / dv through the transpose tile ---------------------------------
   if (DATA) {
-    for (int e = t; e < KP * FTD; e += 256) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = t + it * 256;
+      if (e >= KP * FTD) break;
       const int dl = e / KP, k = e % KP;
       const int d = d0 + dl;
-      tile[k][dl] = (d < D) ? (gVp[(size_t)d * KP + k] - (bern_s[dl] ? 0.f : zsum_s[k])) * etas_[dl] : 0.f;
+      tile[k][dl] = (d < D) ? (in_gv[it] - (bern_s[dl] ? 0.f : zsum_s[k])) * etas_[dl] : 0.f;
     }
   }
   __syncthreads();
-  float in_v[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int e = t + it * 256;
-    const int k = e / FTD, dl = e % FTD;
-    const int d = d0 + dl;
-    in_v[it] = (PRIOR && e < KP * FTD && k < K && d < D) ? P.p[V_][(size_t)k * D + d] : 0.f;
-  }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = t + it * 256;
@@ -359,21 +386,16 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
         part[V_] += (double)lp;
         G.p[V_][i] = dv + pw * gy;
       } else {
-        G.p[V_][i] += dv;
+        G.p[V_][i] = old_v[it] + dv;
       }
     }
   }
   // ---- [.,D] vectors: w, s, s_eta, s_tau, s_eta_a, s_tau_a ---------------
   if (t < FTD && d0 + t < D) {
     const int d = d0 + t;
-    const float e = etas_[t];
-    const float s0 = P.p[S_][d], s1 = P.p[S_][D + d], w = P.p[W_][d];
-    // all operands before the first store (see the [D,K] loop)
-    const bool hier = PRIOR && !hs;
-    const float se0 = hier ? P.p[SETA_][d] : 1.f, se1 = hier ? P.p[SETA_][D + d] : 1.f;
-    const float stau = hier ? P.p[STAU_][d] : 1.f, sta = hier ? P.p[STAUA_][d] : 1.f;
-    const float sa0 = hier ? P.p[SETAA_][d] : 1.f, sa1 = hier ? P.p[SETAA_][D + d] : 1.f;
-    const float gph_d = DATA ? gph[d] : 0.f;
+    const float e = c_eta, s0 = c_s0, s1 = c_s1, w = c_w;
+    const float se0 = c_se0, se1 = c_se1, stau = c_stau, sta = c_sta, sa0 = c_sa0, sa1 = c_sa1;
+    const float gph_d = c_gph;
     float dw = 0.f, ds0 = 0.f, ds1 = 0.f;
     if (DATA) {
       const float T = s0 + s1, iT2 = 1.f / (T * T);
@@ -429,9 +451,9 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
       G.p[STAUA_][d] = pw * (a_ga + c_ga);
       }
     } else {
-      G.p[W_][d] += dw;
-      G.p[S_][d] += ds0;
-      G.p[S_][D + d] += ds1;
+      G.p[W_][d] = old_w + dw;
+      G.p[S_][d] = old_s0 + ds0;
+      G.p[S_][D + d] = old_s1 + ds1;
     }
   }
   __syncthreads();
@@ -440,7 +462,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     if (t < K && !hs) {
       float g = gutau_s[t];
       if (blockIdx.x == 0) {
-        const float ut = P.p[UTAU_][t], uta = P.p[UTAUA_][t];
+        const float ut = c_ut, uta = c_uta;
         double lp, lp2;
         float gy, ga, ga2;
         sqrt_ig(ut, uta, lp, gy, ga);
@@ -464,7 +486,9 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     __syncthreads();
     if (t < 12) ppart[t] = pred[t][0] + pred[t][1] + pred[t][2] + pred[t][3];
   }
-  if (DATA && blockIdx.x == 0 && t == 0) {
+  if (DATA && blockIdx.x == 0 && t < 64) {
+    const double rsum = wave_sum(rterm);
+    if (t == 0) {
     const double llx = unpack(tail, 0), zsq = unpack(tail, 1);
     // sum of the rate over ALL cells: closed form (linear) or the dense exp sum
     double sum_r = Bglob * prep_sum(dprep, KP, KP);
@@ -473,7 +497,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     else if (logt == 1)
       sum_r += unpack(tail, 3) - Bglob * (double)D;
     else {
-      for (int k = 0; k < KP; ++k) sum_r += unpack(tail, kDaccHead + k) * prep_sum(dprep, KP, k);
+      sum_r += rsum;
       if (logt == 3) sum_r += unpack(tail, 3);   // mixed: + softplus over the Bernoulli columns
     }
     parts[13] = llx - (lik_bern(logt) ? 0.0 : lgamma_sum) - sum_r;      // single writer
@@ -481,6 +505,7 @@ __global__ __launch_bounds__(256) void finish_kernel(int D, int K, double Bglob,
     if (nnf_out) {
       nnf_out[0] = unpack(tail, 2);
       nnf_out[gridDim.y] = unpack(tail, 4);     // [S + s]: saturated cells (log_transform)
+    }
     }
   }
 }

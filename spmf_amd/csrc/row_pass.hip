@@ -36,6 +36,9 @@ namespace spmf {
 #ifndef ROW_MAX_BLOCKS
 #define ROW_MAX_BLOCKS 4096
 #endif
+#ifndef ROW_GRP
+#define ROW_GRP 4
+#endif
 #ifndef ROW_WAVES_PER_SIMD
 #define ROW_WAVES_PER_SIMD 1
 #endif
@@ -57,7 +60,7 @@ template <int KP, int LIK, bool LDSPHI = false>
 struct RowCtx {
   static constexpr int LPN = KP / 4;
   static constexpr int NPI = 64 / LPN;
-  static constexpr int GRP = LPN < 4 ? LPN : 4;  // gathers issued back to back
+  static constexpr int GRP = LPN < ROW_GRP ? LPN : ROW_GRP;  // gathers issued back to back
   const float* Ap;
   const float* Vp;
   const float* phi;
