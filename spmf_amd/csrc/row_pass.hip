@@ -197,7 +197,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
   const bool encode_only = mode == 1;
   constexpr int LPN = KP / 4;
   constexpr bool LDSPHI = BT != 256;
-  if (LDSPHI) {
+  if (LDSPHI && !encode_only) {
     float* pl = lds_dyn();
     for (int i = threadIdx.x; i < Dcols; i += BT) pl[i] = phi[i];
     __syncthreads();
@@ -366,7 +366,8 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
 // the 256-thread form, which reads phi from global memory)
 template <int KP, int LIK, int BT>
 static bool launch_row_lds(const RowArgs& a, hipStream_t st) {
-  const size_t lds = std::max((size_t)a.D * 4, (size_t)(BT / 64) * KP * sizeof(double));
+  // (the encode-only sweep reads no phi: it takes this launch shape, not the LDS)
+  const size_t lds = a.mode == 1 ? 0 : std::max((size_t)a.D * 4, (size_t)(BT / 64) * KP * sizeof(double));
   // opt in to more than 64 KB of dynamic LDS.  The attribute is per DEVICE (and this is one
   // instantiation per process), so the grant is remembered per device ordinal.
   constexpr int kMaxDev = 64;
@@ -413,6 +414,12 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
   // phi from LDS: the sweep-2 forms of the Poisson likelihoods at the K of the named
   // configs, when 4*D bytes fit (and the batch is big enough to fill the wider blocks)
   if constexpr (KP >= 16) {
+    if (ROW_LDS_PHI && a.mode == 1 && a.B >= 4096) {
+      // sweep 1 alone (z from the encoder side) does not depend on the likelihood: the
+      // resident-set launch of the 512-thread form, without the phi copy.  C4: 8.6 -> 6.4 ms
+      // against the 256-thread grid (profiles/r03_sparse_pass_attempts.txt e25)
+      if (launch_row_lds<KP, 0, 512>(a, st)) return;
+    }
     if (ROW_LDS_PHI && a.mode != 1 && (a.logt == 0 || a.logt == 1) && a.B >= 4096) {
       const size_t need = (size_t)a.D * 4;
       if (need <= 80 * 1024) {
