@@ -283,12 +283,17 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       }
     } else {
       // ---- long row: stream the row twice (second read is L2 served) -----
+      // Chunks 0 and 1 came with the row's prefetch; chunk i+2 is fetched while chunk i is
+      // processed, so no chunk waits for its own col/val (14 chunks a row on C4).
       if (mode != 2) {
+        int c = pc0, c1 = pc1;
+        float x = px0, x1 = px1;
         for (int base = start; base < end; base += 64) {
-          const int idx = base + lane;
-          const int c = idx < end ? col[idx] : 0;
-          const float x = idx < end ? val[idx] : 0.f;
+          const int i2 = base + 128 + lane;
+          const int c2 = i2 < end ? col[i2] : 0;
+          const float x2 = i2 < end ? val[i2] : 0.f;
           cx.sweep1(c, x, min(64, end - base), zacc);
+          c = c1; x = x1; c1 = c2; x1 = x2;
         }
         zacc = across_groups_sum4<LPN>(zacc);
         zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
@@ -296,12 +301,16 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       } else {
         zacc = gather4<LPN>(z, (int)b, sub);
       }
-      if (!encode_only)
-      for (int base = start; base < end; base += 64) {
-        const int idx = base + lane;
-        const int c = idx < end ? col[idx] : 0;
-        const float x = idx < end ? val[idx] : 0.f;
-        cx.sweep2(c, x, min(64, end - base), zacc, gz, llrow, nnf_acc);
+      if (!encode_only) {
+        int c = pc0, c1 = pc1;
+        float x = px0, x1 = px1;
+        for (int base = start; base < end; base += 64) {
+          const int i2 = base + 128 + lane;
+          const int c2 = i2 < end ? col[i2] : 0;
+          const float x2 = i2 < end ? val[i2] : 0.f;
+          cx.sweep2(c, x, min(64, end - base), zacc, gz, llrow, nnf_acc);
+          c = c1; x = x1; c1 = c2; x1 = x2;
+        }
       }
     }
     // rotate the pipeline registers
