@@ -82,6 +82,36 @@ def test_energy_parts_and_grads_match_oracle(B, D, K, S, density, scale_rows, pa
     assert_close_grads(grads, grads_ref, O.energy_grad_scales(cfg, x, params))
 
 
+@pytest.mark.parametrize("K,log_transform", [(32, False), (16, False), (64, False), (64, True)])
+def test_row_lengths_around_the_chunk_boundaries(K, log_transform):
+    """Rows of exactly 0, 1, 63 ... 257, 300 stored entries in a batch big enough for the
+    resident-set launches (B >= 4096): the short-row path keeps two 64-entry chunks in
+    registers, longer rows stream their chunks two ahead (row_pass.hip)."""
+    B, D, S = 4200, 300, 1
+    lengths = [0, 1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300]
+    rng = np.random.default_rng(77 + K)
+    x = np.zeros((B, D))
+    for b in range(B):
+        n = lengths[b % len(lengths)]
+        cols = rng.choice(D, size=n, replace=False)
+        x[b, cols] = 1 + rng.poisson(1.5, size=n)
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, scale_rows=True, log_transform=log_transform,
+                         u_tau_scale=1.0 / math.sqrt(B * D))
+    cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = float(rng.uniform(2.0, 6.0))
+    params = O.random_params(cfg, S, 78 + K, fp32_exact=True)
+    if log_transform:   # keep exp(<z, eta v>) in range: the largest exponent is 8
+        T = torch.as_tensor
+        z = O.encode(cfg, T(x), T(params["u"]), T(params["s"]))
+        params["v"] *= 8.0 / float((torch.matmul(z, T(params["v"])) * cfg.eta_i).max())
+    parts_ref, grads_ref, _ = O.energy_and_grads(cfg, x, params)
+    m = build_model(cfg, 1024)
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    assert float(nnf.sum()) == 0
+    assert_close_parts(parts, parts_ref)
+    assert_close_grads(grads, grads_ref, O.energy_grad_scales(cfg, x, params))
+
+
 def test_prior_weight_scales_only_prior_gradient():
     cfg, x, params = make_problem(60, 40, 8, 1, 7, 0.2)
     _, _, groups = O.energy_and_grads(cfg, x, params)
