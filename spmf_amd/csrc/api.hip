@@ -168,9 +168,10 @@ static int64_t est_chunk_rows(const spmf_ctx* c, int64_t rows) {
   return rows < cap ? rows : cap;
 }
 
-// E (exp / sigmoid of the logits) is kept between the two dense contractions by the exp and
-// sigmoid forms; Bernoulli + log_transform (code 4: E would have to carry exp(X) too) recomputes
-// the bf16x3 form of the exp sums (dense3.hip) covers the Poisson exp decoder at KP = 64
+// The bf16x3 form of the exp sums (dense3.hip) covers the Poisson exp decoder at KP = 64 and
+// recomputes E in its second launch.  The exact-f32 exp and sigmoid forms keep E (exp / sigmoid
+// of the logits) in HBM between their two contractions; Bernoulli + log_transform (code 4: E
+// would have to carry exp(X) too) recomputes.
 static bool uses_dense3(const spmf_ctx* c) {
   return c->dense3 && likelihood_code(c) == 1 && c->KP == 64;
 }
