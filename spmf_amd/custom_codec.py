@@ -103,9 +103,13 @@ def log_likelihood_components(model, x_dense, s, u, v, w):
     return {"log_likelihood": ll, "rate": rate}
 
 
-def energy_and_grads(model, x_dense, params, prior_weight=1.0):
+def energy_and_grads(model, x_dense, params, prior_weight=1.0, shard=None):
     """parts (name -> [S] float64) and d(x + z + prior_weight*prior)/d(param)
-    (float32, the shapes of ``params``) for a dense batch [B,D] on the device."""
+    (float32, the shapes of ``params``) for a dense batch [B,D] on the device.
+    ``shard``: a dist.ShardReducer when ``x_dense`` is this rank's row shard -- the data
+    terms ('x', 'z', their gradients, the non-finite count) are summed over the shards
+    in ONE packed fp32 buffer (fp64 scalars as hi/lo pairs, like the kernels'
+    accumulator tail), the prior is evaluated redundantly on every rank."""
     dev = model.device
     dt = torch.float64
     enc, dec = model._custom_codec
@@ -124,6 +128,8 @@ def energy_and_grads(model, x_dense, params, prior_weight=1.0):
     n_bad = (~good).sum((-1, -2)).to(dt)
     # replacement rule (:606-616); the identity when every cell is finite
     fin = torch.where(good, ll, torch.zeros_like(ll))
+    if shard is not None and getattr(shard, "active", False):
+        return _sharded(shard, p, parts, fin, good, ll, theta, n_bad, prior_weight)
     mval = fin.min() - 10.0
     parts["x"] = torch.where(good, torch.clamp(ll, max=0.0), torch.zeros_like(ll)).sum((-1, -2)) + n_bad * mval
     parts["z"] = (HALF_LOG_2_OVER_PI - 0.5 * theta ** 2).sum((-1, -2))
@@ -134,3 +140,49 @@ def energy_and_grads(model, x_dense, params, prior_weight=1.0):
     grads = {n: (gi if gi is not None else torch.zeros_like(p[n])).to(torch.float32)
              for n, gi in zip(names, g)}
     return {k: v.detach() for k, v in parts.items()}, grads, n_bad.detach()
+
+
+def _sharded(shard, p, parts, fin, good, ll, theta, n_bad, prior_weight):
+    """Row-sharded tail of energy_and_grads.  The replacement rule's m (poisson.py:606-616)
+    is the minimum over the shard minima; its gradient comes from the shard that holds the
+    minimum's cell (lowest rank on a tie), weighted with the GLOBAL count of replaced cells."""
+    dt = torch.float64
+    names = list(p)
+    ps = [p[n] for n in names]
+    S = n_bad.shape[0]
+    lmin = fin.min()
+    mins = shard.gather_scalar(float(lmin.detach()), device=lmin.device)
+    gmin = min(mins)
+    holder = mins.index(gmin) == shard.rank
+    nb = n_bad.to(torch.float32).clone()
+    shard._sum(nb)                                    # replaced cells per draw, all shards
+    nbad_glob = nb.to(dt)
+    m_const = gmin - 10.0
+    clipped = torch.where(good, torch.clamp(ll, max=0.0), torch.zeros_like(ll)).sum((-1, -2))
+    zpart = (HALF_LOG_2_OVER_PI - 0.5 * theta ** 2).sum((-1, -2))
+    obj = clipped.sum() + zpart.sum()
+    if holder and float(nbad_glob.sum()) > 0.0:
+        obj = obj + nbad_glob.sum() * (lmin - 10.0)
+    g_data = torch.autograd.grad(obj, ps, allow_unused=True)
+    prior_tot = sum(v.sum() for v in parts.values())
+    g_prior = torch.autograd.grad(prior_tot, ps, allow_unused=True)
+    x_loc = (clipped + n_bad * m_const).detach()
+    z_loc = zpart.detach()
+    # one packed fp32 buffer: gradients | (hi, lo) of x[S] and z[S]
+    flat = [(g if g is not None else torch.zeros_like(q)).to(torch.float32).reshape(-1)
+            for g, q in zip(g_data, ps)]
+    sc = torch.cat([x_loc, z_loc])
+    hi = sc.to(torch.float32)
+    lo = (sc - hi.to(dt)).to(torch.float32)
+    buf = torch.cat(flat + [hi, lo]).contiguous()
+    shard._sum(buf)
+    out, o = {}, 0
+    for n, q, gp in zip(names, ps, g_prior):
+        k = q.numel()
+        gd = buf[o:o + k].reshape(q.shape)
+        o += k
+        out[n] = gd + (prior_weight * gp).to(torch.float32) if gp is not None else gd.clone()
+    tot = buf[o:o + 2 * S].to(dt) + buf[o + 2 * S:o + 4 * S].to(dt)
+    res = {k: v.detach() for k, v in parts.items()}
+    res["x"], res["z"] = tot[:S], tot[S:]
+    return res, out, nbad_glob

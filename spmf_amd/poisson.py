@@ -115,15 +115,16 @@ class PoissonFactorization:
 
     def _custom_energy(self, data, params, all_reduce, prior_weight):
         from . import custom_codec
-        if all_reduce is not None:
-            raise NotImplementedError("custom encoder/decoder callables: single shard only")
+        if all_reduce is not None and not (hasattr(all_reduce, "_sum") and hasattr(all_reduce, "gather_scalar")):
+            raise NotImplementedError("custom encoder/decoder callables: row shards need a dist.ShardReducer "
+                                      "as the all_reduce hook (a bare callable only sees the kernels' accumulators)")
         sc, cs = self._batch(data)
         x = sc.to_dense()
         pr = data.get("panels") if isinstance(data, dict) else None
         if pr is not None:
             r0 = pr[0] * sc.panel_rows
             x = x[r0:r0 + cs.n_rows]
-        parts, grads, nbad = custom_codec.energy_and_grads(self, x, params, prior_weight)
+        parts, grads, nbad = custom_codec.energy_and_grads(self, x, params, prior_weight, shard=all_reduce)
         S = nbad.shape[0]
         zero = torch.zeros(S, dtype=torch.float64, device=self.device)
         # (horshoe_plus=False has four variables: the other parts are 0, like the kernels')

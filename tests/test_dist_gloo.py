@@ -197,3 +197,85 @@ def test_gloo_allreduce_matches_unsharded_oracle(world):
         for k, g in grads[i].items():
             ref = groups["data"][k][i].numpy()
             assert np.abs(g - ref).max() <= 1e-5 * np.abs(ref).max(), (i, k)
+
+
+# ---- custom encoder/decoder callables over row shards (spmf_amd/custom_codec.py) -------
+class _StubModel:
+    """What custom_codec reads of a PoissonFactorization (the class itself needs a GPU)."""
+
+    def __init__(self, cfg, enc, dec):
+        self.device = torch.device("cpu")
+        self.horseshoe_plus = True
+        self.latent_dim = cfg.latent_dim
+        self.symmetry_breaking_decay = cfg.symmetry_breaking_decay
+        self.u_tau_scale, self.s_tau_scale = cfg.u_tau_scale, cfg.s_tau_scale
+        self.scale_rows = cfg.scale_rows
+        self.xi_u_global = cfg.xi_u_global
+        self._eta = cfg.eta_i
+        self._custom_codec = (enc, dec)
+
+    def _eta_device(self):
+        return self._eta
+
+
+def _custom_problem(bad):
+    rng = np.random.default_rng(9)
+    B, D, K, S = 40, 12, 3, 2
+    x = ((rng.random((B, D)) < 0.4) * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, scale_rows=True, u_tau_scale=1.0 / math.sqrt(B * D))
+    cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = 3.0
+    params = O.random_params(cfg, S, 10, fp32_exact=True)
+    if bad:   # a stored cell under rate 0 in draw 0 (row `bad` holds nothing but column 0)
+        params["w"][0, 0, 0] = 0.0
+        params["u"][0, 0, :] = 0.0
+        x[:, 0] = 0
+        x[bad, :] = 0
+        x[bad, 0] = 3.0
+    return cfg, x, params
+
+
+def _custom_worker(rank, world, port, q, bad):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spmf_amd import custom_codec
+    from spmf_amd.dist import ShardReducer, shard_bounds
+    cfg, x, params = _custom_problem(bad)
+    m = _StubModel(cfg, torch.sqrt, lambda y: y * y)
+    r0, r1 = shard_bounds(x.shape[0], world, rank)
+    parts, grads, nbad = custom_codec.energy_and_grads(m, torch.as_tensor(x[r0:r1]), params, 0.7,
+                                                       shard=ShardReducer())
+    if rank == world - 1:
+        q.put({"parts": {k: v.numpy() for k, v in parts.items()},
+               "grads": {k: v.numpy() for k, v in grads.items()}, "nbad": nbad.numpy()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad", [0, 3, 37])
+def test_custom_callables_over_two_row_shards_equal_one_process(bad):
+    """sqrt / square callables: data terms summed over the shards in one packed buffer, prior
+    evaluated on every rank; with a rate-0 stored cell the rule's minimum and its gradient come
+    from whichever shard holds them (row 3: shard 0, row 37: shard 1; 0: no such cell)."""
+    from spmf_amd import custom_codec
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_custom_worker, args=(r, 2, port, q, bad)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg, x, params = _custom_problem(bad)
+    m = _StubModel(cfg, torch.sqrt, lambda y: y * y)
+    parts, grads, nbad = custom_codec.energy_and_grads(m, torch.as_tensor(x), params, 0.7)
+    assert res["nbad"].tolist() == nbad.tolist() == ([1.0, 0.0] if bad else [0.0, 0.0])
+    for k, v in parts.items():
+        np.testing.assert_allclose(res["parts"][k], v.numpy(), rtol=2e-7, err_msg=k)
+    for k, v in grads.items():
+        a, b = res["grads"][k], v.numpy()
+        assert np.isfinite(a).all(), k
+        assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30), (k, np.abs(a - b).max(), np.abs(b).max())

@@ -180,3 +180,58 @@ def test_two_rank_nonfinite_rule_equals_single_process(flip):
         a, b = res["grads"][k], v.cpu().numpy()
         assert np.isfinite(a).all(), k
         assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), (k, np.abs(a - b).max(), np.abs(b).max())
+
+
+def _custom_model(cfg):
+    from spmf_amd import PoissonFactorization
+    m = PoissonFactorization(latent_dim=cfg.latent_dim, feature_dim=cfg.feature_dim, u_tau_scale=cfg.u_tau_scale,
+                             column_norms=cfg.eta_i, initialize_distributions=False, device="cuda", panel_rows=8,
+                             encoder_function=torch.sqrt, decoder_function=lambda y: y * y)
+    m.xi_u_global = cfg.xi_u_global
+    return m
+
+
+def _custom_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from spmf_amd.dist import ShardReducer, shard_bounds
+    from test_gpu_parity import make_problem
+    cfg, x, params = make_problem(48, 20, 3, 2, 41, 0.3)
+    r0, r1 = shard_bounds(x.shape[0], world, rank, granule=8)
+    m = _custom_model(cfg)
+    parts, grads, nnf = m.energy_and_grads({"counts": x[r0:r1]}, params, all_reduce=ShardReducer())
+    if rank == 1:
+        q.put({"parts": {k: v.cpu().numpy() for k, v in parts.items()},
+               "grads": {k: v.cpu().numpy() for k, v in grads.items()}, "nnf": nnf.cpu().numpy()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_custom_callables_equal_single_process():
+    """poisson.py:94-97 callables over row shards (spmf_amd/custom_codec.py _sharded): the class
+    surface with a ShardReducer against the same model on the whole matrix."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_custom_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=500)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import make_problem
+    cfg, x, params = make_problem(48, 20, 3, 2, 41, 0.3)
+    parts, grads, nnf = _custom_model(cfg).energy_and_grads({"counts": x}, params)
+    assert res["nnf"].tolist() == nnf.cpu().tolist() == [0.0, 0.0]
+    for k, v in parts.items():
+        np.testing.assert_allclose(res["parts"][k], v.cpu().numpy(), rtol=2e-7, err_msg=k)
+    for k, v in grads.items():
+        a, b = res["grads"][k], v.cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), (k, np.abs(a - b).max(), np.abs(b).max())
