@@ -171,7 +171,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--samples", type=int, default=1, help="Monte-Carlo draws S per step")
     ap.add_argument("--rows", type=int, default=None, help="override total rows")
-    ap.add_argument("--panel-rows", type=int, default=8192)
+    ap.add_argument("--panel-rows", type=int, default=0,
+                    help="rows per panel of the panel-CSC; 0 = spmf_amd.sparse.balanced_panel_rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the S=20 / minibatch lines")
     ap.add_argument("--split", action="store_true",
@@ -239,6 +240,9 @@ def main():
                          f"{world} ranks")
     logt = args.workload.startswith("c4")
     mixed_mask = None
+    from spmf_amd.sparse import balanced_panel_rows
+    if not args.panel_rows:   # L2-sized panels, a multiple of 8 of them per shard (XCD balance)
+        args.panel_rows = balanced_panel_rows(my_rows, K)
     if args.workload == "c5":
         # BASELINE.json config 5 names 4 GPUs: row shards like C3
         sc, mixed_mask = synth.mixed_c5(my_rows, D, dev, 20241218 + 5, panel_rows=args.panel_rows,
@@ -365,14 +369,22 @@ def main():
         extras["minibatch_ms_per_step"] = timed(lambda: model.energy_and_grads(mb, params), 50, 5)
         # the per-GPU shard of the 8-GPU run (whole panels: 15 x 8192 = 122 880 rows) on this
         # one GPU: its step, the kernel taps, and what does not shrink with N (step - row - col)
-        npan_s = max(1, min(sc.n_panels, 125_000 // sc.panel_rows))
-        sb = {"counts": sc, "panels": (0, npan_s)}
+        # (a rank of the 8-GPU run lays out its OWN rows: panels sized and counted for 125k rows)
+        from spmf_amd.sparse import SparseCounts
+        n_s = min(sc.n_rows, 122_880)
+        e_s = int(sc.row_ptr[n_s])
+        ss = SparseCounts(sc.row_ptr[:n_s + 1].clone(), sc.col_idx[:e_s].clone(), sc.val[:e_s].clone(),
+                          n_s, D, balanced_panel_rows(n_s, K))
+        ss.compute_stats(h)
+        npan_s = ss.n_panels
+        sb = {"counts": ss}
         lib.spmf_ctx_enable_timing(h, 1)
         sh_ms = timed(lambda: model.energy_and_grads(sb, params), 50, 5)
         ms_s = (C.c_float * 6)()
         _lib.check(h, lib.spmf_last_timing(h, ms_s), "spmf_last_timing")
         lib.spmf_ctx_enable_timing(h, 0)
-        extras["shard125k_rows"] = min(sc.n_rows, npan_s * sc.panel_rows)
+        extras["shard125k_rows"] = n_s
+        extras["shard125k_panel_rows"] = ss.panel_rows
         extras["shard125k_ms_per_step"] = sh_ms
         extras["shard125k_kernel_ms"] = {"prep": round(ms_s[0], 4), "row_pass": round(ms_s[1], 4),
                                          "col_pass": round(ms_s[2], 4), "finish": round(ms_s[3], 4)}

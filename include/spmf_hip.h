@@ -80,7 +80,10 @@ typedef struct spmf_ctx spmf_ctx;
 /* One batch (or one row shard) of the count matrix, device resident.
  * Row-major CSR for the row pass and a row-panel CSC ("panel-CSC": for each
  * panel of `panel_rows` consecutive rows, a CSC of that panel) for the
- * column pass.  Replaces the dense [B,D] tensor data[count_key] the
+ * column pass; the column pass walks the panels of residue class blockIdx % 8
+ * on one XCD, so a panel's z and xi*gz rows (panel_rows * 2 * KP floats) should
+ * fit that XCD's L2 and n_panels should be a multiple of 8 for big batches:
+ * spmf_amd/sparse.py balanced_panel_rows).  Replaces the dense [B,D] tensor data[count_key] the
  * reference feeds to encode/log_likelihood_components (poisson.py:170,182).
  */
 typedef struct spmf_counts {

@@ -19,7 +19,6 @@ import torch
 
 from . import _lib
 from .poisson import PoissonFactorization
-from .sparse import DEFAULT_PANEL_ROWS
 
 
 class BernoulliFactorization(PoissonFactorization):
@@ -36,7 +35,7 @@ class BernoulliFactorization(PoissonFactorization):
             strategy=None, encoder_function=None, decoder_function=None,
             log_transform=False, horshoe_plus=True, column_norms=None,
             count_key="counts", dtype=torch.float64, device=None,
-            panel_rows=DEFAULT_PANEL_ROWS, **kwargs):
+            panel_rows=None, **kwargs):
         super().__init__(
             latent_dim=latent_dim, feature_dim=feature_dim,
             u_tau_scale=u_tau_scale, s_tau_scale=s_tau_scale,

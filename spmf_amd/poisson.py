@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from ._lib import PART_ORDER, VAR_ORDER, SpmfError
-from .sparse import DEFAULT_PANEL_ROWS, SparseCounts
+from .sparse import SparseCounts
 
 
 def var_shapes(D: int, K: int) -> Dict[str, tuple]:
@@ -53,7 +53,7 @@ class PoissonFactorization:
             scale_columns=True, scale_rows=True, log_transform=False,
             horshoe_plus=True, column_norms=None, count_key='counts',
             initialize_distributions=True,
-            dtype=torch.float64, device=None, panel_rows=DEFAULT_PANEL_ROWS,
+            dtype=torch.float64, device=None, panel_rows=None,
             **kwargs):
         # poisson.py:94-97 lets callers swap g / f.  The kernels know the two built-in
         # pairs only; with a callable the energy takes the dense torch-on-device route of
@@ -278,7 +278,7 @@ class PoissonFactorization:
                 sc = hit[1]
             else:
                 sc = SparseCounts.from_any(x, self.device, self.panel_rows,
-                                             getattr(self, "column_split", 0))
+                                             getattr(self, "column_split", 0), latent_dim=self.latent_dim)
                 # device layouts of the most recent batches (an epoch loop over a
                 # fixed list of host batches re-uses them; bounded by stored entries)
                 self._batch_cache[ck] = (x, sc)
@@ -677,7 +677,7 @@ class PoissonFactorization:
             h = self._handle()
             for batch in iter(data_factory()):
                 x = batch[self.count_key] if isinstance(batch, dict) else batch
-                sc = SparseCounts.from_any(x, self.device, self.panel_rows)
+                sc = SparseCounts.from_any(x, self.device, self.panel_rows, latent_dim=self.latent_dim)
                 sc.compute_stats(h, colsum, colnnz)
                 N += sc.n_rows
                 if all_reduce is not None:

@@ -22,7 +22,33 @@ import torch
 
 from . import _lib
 
-DEFAULT_PANEL_ROWS = 8192
+DEFAULT_PANEL_ROWS = 8192      # without a latent_dim hint
+PANEL_TABLE_BYTES = 3 << 20    # z and xi*gz rows of one panel: what an XCD's 4 MB L2 should hold
+
+
+def balanced_panel_rows(n_rows, latent_dim, table_bytes=PANEL_TABLE_BYTES):
+    """Rows per panel for a shard of ``n_rows`` at latent dimension ``latent_dim``.
+
+    The column pass gathers z_b and xi*gz_b (2 x KP floats per row) of ONE panel at a time on
+    each XCD (col_pass.hip: workgroup -> panel by blockIdx % 8), so a panel's pair of tables
+    should fit that XCD's L2 with room for the entry stream (3 MB of 4: measured optimum on C3
+    and C4), and the panel count should be a multiple of 8 so that every XCD walks the same
+    number of panels (123 panels on C3 left two XCDs with 16 and six with 15: 4 % of the pass).
+    A shard of up to two such panels stays one panel (fewer than 8 panels are shared by all XCDs)."""
+    n_rows = int(max(1, n_rows))
+    kp = 4
+    while kp < int(latent_dim):
+        kp *= 2
+    target = max(1024, int(table_bytes) // (8 * kp))
+    if n_rows <= 2 * target:
+        return n_rows
+    n_panels = 8 * -(-n_rows // (8 * target))
+    rows = -(-n_rows // n_panels)
+    for g in (64, 8):                       # a round number, if it keeps the panel count
+        r = -(-rows // g) * g
+        if -(-n_rows // r) == n_panels:
+            return r
+    return rows
 SEGMENT_ENTRIES = 256     # longest run of one column a single lane group streams
 #: zero entries appended to pc_row / pc_val / pc_gval: the column pass reads list entries
 #: four per lane (spmf_counts.pc_pad, include/spmf_hip.h) and may run this far past a list
@@ -49,7 +75,11 @@ class SparseCounts:
     """One row shard of the count matrix in the layout the kernels read."""
 
     def __init__(self, row_ptr, col_idx, val, n_rows, n_cols,
-                 panel_rows=DEFAULT_PANEL_ROWS, col_split=0):
+                 panel_rows=None, col_split=0, latent_dim=None):
+        """``panel_rows`` None / 0: chosen by balanced_panel_rows when ``latent_dim`` is given,
+        DEFAULT_PANEL_ROWS otherwise."""
+        if not panel_rows:
+            panel_rows = balanced_panel_rows(n_rows, latent_dim) if latent_dim else DEFAULT_PANEL_ROWS
         dev = val.device
         self.device = dev
         self.n_rows = int(n_rows)
@@ -77,7 +107,7 @@ class SparseCounts:
 
     # ---- construction ----------------------------------------------------
     @classmethod
-    def from_any(cls, x, device=None, panel_rows=DEFAULT_PANEL_ROWS, col_split=0):
+    def from_any(cls, x, device=None, panel_rows=None, col_split=0, latent_dim=None):
         if isinstance(x, SparseCounts):
             return x
         device = torch.device(device if device is not None else
@@ -88,11 +118,11 @@ class SparseCounts:
             return cls(torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(device),
                        torch.as_tensor(np.asarray(indices, dtype=np.int64)).to(device),
                        torch.as_tensor(np.asarray(data, dtype=np.float32)).to(device),
-                       shape[0], shape[1], panel_rows, col_split)
-        return cls.from_dense(x, device, panel_rows, col_split)
+                       shape[0], shape[1], panel_rows, col_split, latent_dim)
+        return cls.from_dense(x, device, panel_rows, col_split, latent_dim)
 
     @classmethod
-    def from_dense(cls, x, device=None, panel_rows=DEFAULT_PANEL_ROWS, col_split=0):
+    def from_dense(cls, x, device=None, panel_rows=None, col_split=0, latent_dim=None):
         device = torch.device(device if device is not None else
                               ("cuda" if torch.cuda.is_available() else "cpu"))
         if hasattr(x, "numpy") and not isinstance(x, torch.Tensor):
@@ -109,7 +139,7 @@ class SparseCounts:
         nz = mask.nonzero(as_tuple=False)      # row-major order
         col = nz[:, 1]
         val = t[mask].to(torch.float32)
-        return cls(row_ptr, col, val, N, D, panel_rows, col_split)
+        return cls(row_ptr, col, val, N, D, panel_rows, col_split, latent_dim)
 
     def _build_panel_csc(self):
         dev, N, D, P = self.device, self.n_rows, self.n_cols, self.panel_rows

@@ -236,3 +236,26 @@ def test_finish_fast_log_series():
     ref = np.log(x)
     assert np.abs(got - ref).max() <= 4e-16 * (np.abs(ref).max() + 1.0)
     assert (np.abs(got - ref) / (np.abs(ref) + 1.0)).max() <= 3e-16
+
+
+def test_balanced_panel_rows_fill_l2_and_count_in_eights():
+    """Panel geometry of the column pass (spmf_amd/sparse.py balanced_panel_rows): the z / xi*gz
+    rows of a panel fit 3 MB, big shards get a multiple of 8 panels (one XCD class each),
+    shards of up to two panels stay whole."""
+    from spmf_amd.sparse import PANEL_TABLE_BYTES, balanced_panel_rows
+    for n_rows, K in [(1_000_000, 32), (500_000, 64), (125_000, 32), (122_880, 32), (200_000, 32),
+                      (100_000, 16), (999_983, 50), (3_000_000, 8)]:
+        pr = balanced_panel_rows(n_rows, K)
+        kp = 4
+        while kp < K:
+            kp *= 2
+        n_panels = -(-n_rows // pr)
+        assert pr * 8 * kp <= PANEL_TABLE_BYTES + 64 * 8 * kp
+        assert n_panels % 8 == 0, (n_rows, K, pr, n_panels)
+        assert (n_panels - 1) * pr < n_rows           # no empty panel
+        assert n_rows - (n_panels - 1) * pr > pr // 2   # and no sliver at the end
+    assert balanced_panel_rows(1_000_000, 32) == 11392      # 88 panels (C3)
+    assert balanced_panel_rows(500_000, 64) == 5696         # 88 panels (C4)
+    assert balanced_panel_rows(125_000, 32) == 7872         # 16 panels (an 8-GPU shard of C3)
+    assert balanced_panel_rows(20_000, 16) == 20_000        # a reference-sized minibatch: one panel
+    assert balanced_panel_rows(5, 2) == 5 and balanced_panel_rows(0, 2) == 1
