@@ -367,7 +367,7 @@ def main():
         mb = {"counts": sc, "panels": (0, npan)}
         extras["minibatch_rows"] = min(sc.n_rows, npan * sc.panel_rows)
         extras["minibatch_ms_per_step"] = timed(lambda: model.energy_and_grads(mb, params), 50, 5)
-        # the per-GPU shard of the 8-GPU run (whole panels: 15 x 8192 = 122 880 rows) on this
+        # the per-GPU shard of the 8-GPU run (122 880 of its 125 000 rows, as in rounds 1-2) on this
         # one GPU: its step, the kernel taps, and what does not shrink with N (step - row - col)
         # (a rank of the 8-GPU run lays out its OWN rows: panels sized and counted for 125k rows)
         from spmf_amd.sparse import SparseCounts
