@@ -128,6 +128,11 @@ typedef struct spmf_counts {
   int32_t col_split;
   int32_t max_items_half[2];
   int32_t reserved2_;
+  /* Optional packed copy of the CSR entries for the row pass: ent[i] = col_idx[i] << 16 | count,
+   * valid when D <= 65536 and every stored value is an integer in [0, 65535] (counts are:
+   * tests/spmf_test.py:19); NULL otherwise.  Halves the entry stream of the sweeps that read the
+   * raw counts (4 instead of 8 bytes per stored entry); col_idx / val stay the canonical arrays. */
+  const uint32_t* ent;
 } spmf_counts;
 
 int spmf_version(void);

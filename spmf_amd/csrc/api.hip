@@ -416,6 +416,8 @@ static int check_counts(spmf_ctx* c, const spmf_counts* ct) {
       "counts: too many rows in one batch for this K (B*KP*4 must be < 4 GiB)");
   if (!ct->row_ptr || (ct->nnz > 0 && (!ct->col_idx || !ct->val))) return fail(c, SPMF_E_ARG,
       "counts: null CSR arrays");
+  if (ct->ent && c->D > 65536) return fail(c, SPMF_E_ARG,
+      "counts.ent packs the column into 16 bits: D must be <= 65536");
   return SPMF_OK;
 }
 
@@ -489,12 +491,14 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
     if (ct->n_rows > 0 && !logt) {
       RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
           dacc, 0, 0, nullptr, nullptr, nbat, D, dacc_stride};
+      ra.ent = ct->ent;
       launch_row_pass(KP, ra, st);
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
       // cores, then the stored-cell terms (sweep 2) with the dense row term.
       RowArgs r1{ct->n_rows, ct->row_ptr, ct->col_idx, lik_exp(logt) ? ct->gval : ct->val, rscale, c->Ap, c->Vp, c->phi,
           dprep, c->z, c->gzs, dacc, 1, logt, nullptr, c->ctype, 1, D, dacc_stride};
+      if (!lik_exp(logt)) r1.ent = ct->ent;   // (the exp encoders read g(x), not the counts)
       launch_row_pass(KP, r1, st);
       if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
       const int act = logt == 4 ? 2 : (logt >= 2 ? 1 : 0);   // dense.hip ACT
@@ -568,6 +572,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
       RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
           dacc, 2, logt, c->gzd, c->ctype, 1, D, dacc_stride};
+      r2.ent = ct->ent;
       launch_row_pass(KP, r2, st);
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
@@ -742,6 +747,7 @@ int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float*
   RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val,
       (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs,
       c->dacc, 1, logt, nullptr, nullptr, 1, c->D, 0};
+  if (!logt) ra.ent = ct->ent;
   launch_row_pass(c->KP, ra, st);
   HIPCHK(c, hipMemcpy2DAsync(z_out, (size_t)c->K * sizeof(float), c->z, (size_t)c->KP * sizeof(float),
       (size_t)c->K * sizeof(float), (size_t)ct->n_rows, hipMemcpyDeviceToDevice, st));
@@ -768,6 +774,7 @@ int spmf_dense_ll(spmf_ctx* c, const spmf_counts* ct, const float* u, const floa
   RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, logt ? ct->gval : ct->val,
       (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr, c->Ap, c->Vp, c->phi, c->dprep, c->z, c->gzs,
       c->dacc, 1, logt, nullptr, nullptr, 1, c->D, 0};
+  if (!logt) ra.ent = ct->ent;
   launch_row_pass(c->KP, ra, st);
   DenseLLArgs da{ct->n_rows, c->D, lik, c->z, c->Vp, c->phi, c->ctype, ct->row_ptr, ct->col_idx, ct->val, rate_out,
       ll_out};

@@ -41,6 +41,7 @@ struct RowArgs {
   // phi, s * kPrepSeg*(KP+1) to dprep, s * B*KP to z / gzs, s * dacc_stride to dacc
   int S, D;
   int64_t dacc_stride;
+  const uint32_t* ent = nullptr;   // packed col << 16 | count copy of (col, val), or null (spmf_counts.ent)
 };
 void launch_row_pass(int KP, const RowArgs& a, hipStream_t st);
 

@@ -54,6 +54,34 @@ __device__ __forceinline__ float* lds_dyn() {
   return spmf_row_lds;
 }
 
+// One stored entry: from the packed stream (col << 16 | count: half the bytes) when the batch
+// carries one, from the canonical col / val arrays otherwise.  PACKED is a template parameter of the
+// kernel (the resident-set launches have both forms).  load_entry only LOADS (into the pipeline registers of the row prefetch);
+// unpack_entry turns them into (column, count) where they are used, one row later -- arithmetic
+// on the loaded word right away would put the wait for the prefetch in front of it.
+template <bool PACKED, bool NT>
+__device__ __forceinline__ void load_entry(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                           const uint32_t* __restrict__ ent, int i, bool ok, int& ra,
+                                           float& rb) {
+  if (PACKED) {
+    ra = ok ? (int)(NT ? __builtin_nontemporal_load(&ent[i]) : ent[i]) : 0;
+    rb = 0.f;
+  } else {
+    ra = ok ? (NT ? __builtin_nontemporal_load(&col[i]) : col[i]) : 0;
+    rb = ok ? (NT ? __builtin_nontemporal_load(&val[i]) : val[i]) : 0.f;
+  }
+}
+template <bool PACKED>
+__device__ __forceinline__ void unpack_entry(int ra, float rb, int& c, float& x) {
+  if (PACKED) {
+    c = (int)((uint32_t)ra >> 16);
+    x = (float)((uint32_t)ra & 0xffffu);
+  } else {
+    c = ra;
+    x = rb;
+  }
+}
+
 // LIK: 0 Poisson / linear decoder, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
 // LDSPHI: phi is read from the workgroup's LDS copy instead of global memory
 template <int KP, int LIK, bool LDSPHI = false>
@@ -176,14 +204,15 @@ struct RowCtx {
 // BT: threads per workgroup.  256: phi from global memory.  512 / 1024: phi staged in LDS
 // (4*D bytes of dynamic LDS: two workgroups per CU up to D = 20 480, one up to 40 960),
 // four waves per SIMD either way.
-template <int KP, int LIK, int BT = 256>
+template <int KP, int LIK, int BT = 256, bool PACKED = false>
 __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pass_kernel(
     int64_t B, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ row_scale,
     const float* __restrict__ Ap, const float* __restrict__ Vp, const float* __restrict__ phi,
     const double* __restrict__ dprep, float* __restrict__ z, float* __restrict__ gzs,
     double* __restrict__ dacc, int mode, const float* __restrict__ gzd,
-    const uint8_t* __restrict__ ctype, int Dcols, int64_t dacc_stride) {
+    const uint8_t* __restrict__ ctype, int Dcols, int64_t dacc_stride,
+    const uint32_t* __restrict__ ent) {
   if (gridDim.y > 1) {   // S draws per launch: tables, outputs and accumulators of draw blockIdx.y
     const size_t sd = blockIdx.y;
     Ap += sd * (size_t)Dcols * KP;
@@ -232,10 +261,8 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     xi = row_scale ? row_scale[wave] : 1.f;
     const int f0 = min(end - start, 64);
     const int i0 = start + lane, i1 = start + f0 + lane;
-    pc0 = lane < f0 ? __builtin_nontemporal_load(&col[i0]) : 0;
-    px0 = lane < f0 ? __builtin_nontemporal_load(&val[i0]) : 0.f;
-    pc1 = i1 < end ? __builtin_nontemporal_load(&col[i1]) : 0;
-    px1 = i1 < end ? __builtin_nontemporal_load(&val[i1]) : 0.f;
+    load_entry<PACKED, true>(col, val, ent, i0, lane < f0, pc0, px0);
+    load_entry<PACKED, true>(col, val, ent, i1, i1 < end, pc1, px1);
   }
   if (wave + nwaves < B) {
     nstart = row_ptr[wave + nwaves];
@@ -250,10 +277,8 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     if (b + nwaves < B) {
       const int f0 = min(nend - nstart, 64);
       const int j0 = nstart + lane, j1 = nstart + f0 + lane;
-      qc0 = lane < f0 ? __builtin_nontemporal_load(&col[j0]) : 0;
-      qx0 = lane < f0 ? __builtin_nontemporal_load(&val[j0]) : 0.f;
-      qc1 = j1 < nend ? __builtin_nontemporal_load(&col[j1]) : 0;
-      qx1 = j1 < nend ? __builtin_nontemporal_load(&val[j1]) : 0.f;
+      load_entry<PACKED, true>(col, val, ent, j0, lane < f0, qc0, qx0);
+      load_entry<PACKED, true>(col, val, ent, j1, j1 < nend, qc1, qx1);
     }
     if (b + 2 * nwaves < B) {
       nnstart = row_ptr[b + 2 * nwaves];
@@ -265,8 +290,10 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     float llrow = 0.f;
     if (n <= 128) {
       // ---- short row: col/val stay in registers for both sweeps ----------
-      const int c0 = pc0, c1 = pc1;
-      const float x0 = px0, x1 = px1;
+      int c0, c1;
+      float x0, x1;
+      unpack_entry<PACKED>(pc0, px0, c0, x0);
+      unpack_entry<PACKED>(pc1, px1, c1, x1);
       const int n0 = min(n, 64), n1 = n - 64;
       if (mode != 2) {
         cx.sweep1(c0, x0, n0, zacc);
@@ -286,14 +313,18 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       // Chunks 0 and 1 came with the row's prefetch; chunk i+2 is fetched while chunk i is
       // processed, so no chunk waits for its own col/val (14 chunks a row on C4).
       if (mode != 2) {
-        int c = pc0, c1 = pc1;
-        float x = px0, x1 = px1;
+        int ra = pc0, ra1 = pc1;
+        float rb = px0, rb1 = px1;
         for (int base = start; base < end; base += 64) {
           const int i2 = base + 128 + lane;
-          const int c2 = i2 < end ? col[i2] : 0;
-          const float x2 = i2 < end ? val[i2] : 0.f;
+          int ra2;
+          float rb2;
+          load_entry<PACKED, false>(col, val, ent, i2, i2 < end, ra2, rb2);
+          int c;
+          float x;
+          unpack_entry<PACKED>(ra, rb, c, x);
           cx.sweep1(c, x, min(64, end - base), zacc);
-          c = c1; x = x1; c1 = c2; x1 = x2;
+          ra = ra1; rb = rb1; ra1 = ra2; rb1 = rb2;
         }
         zacc = across_groups_sum4<LPN>(zacc);
         zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
@@ -302,14 +333,18 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
         zacc = gather4<LPN>(z, (int)b, sub);
       }
       if (!encode_only) {
-        int c = pc0, c1 = pc1;
-        float x = px0, x1 = px1;
+        int ra = pc0, ra1 = pc1;
+        float rb = px0, rb1 = px1;
         for (int base = start; base < end; base += 64) {
           const int i2 = base + 128 + lane;
-          const int c2 = i2 < end ? col[i2] : 0;
-          const float x2 = i2 < end ? val[i2] : 0.f;
+          int ra2;
+          float rb2;
+          load_entry<PACKED, false>(col, val, ent, i2, i2 < end, ra2, rb2);
+          int c;
+          float x;
+          unpack_entry<PACKED>(ra, rb, c, x);
           cx.sweep2(c, x, min(64, end - base), zacc, gz, llrow, nnf_acc);
-          c = c1; x = x1; c1 = c2; x1 = x2;
+          ra = ra1; rb = rb1; ra1 = ra2; rb1 = rb2;
         }
       }
     }
@@ -373,8 +408,8 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
 
 // false: the device does not grant the dynamic LDS this form needs (the caller then launches
 // the 256-thread form, which reads phi from global memory)
-template <int KP, int LIK, int BT>
-static bool launch_row_lds(const RowArgs& a, hipStream_t st) {
+template <int KP, int LIK, int BT, bool PACKED>
+static bool launch_row_lds_t(const RowArgs& a, hipStream_t st) {
   // (the encode-only sweep reads no phi: it takes this launch shape, not the LDS)
   const size_t lds = a.mode == 1 ? 0 : std::max((size_t)a.D * 4, (size_t)(BT / 64) * KP * sizeof(double));
   // opt in to more than 64 KB of dynamic LDS.  The attribute is per DEVICE (and this is one
@@ -388,7 +423,7 @@ static bool launch_row_lds(const RowArgs& a, hipStream_t st) {
       return false;
     }
     if (lds > __atomic_load_n(&granted[dev], __ATOMIC_RELAXED)) {
-      if (hipFuncSetAttribute((const void*)row_pass_kernel<KP, LIK, BT>,
+      if (hipFuncSetAttribute((const void*)row_pass_kernel<KP, LIK, BT, PACKED>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         return false;
@@ -406,10 +441,16 @@ static bool launch_row_lds(const RowArgs& a, hipStream_t st) {
 #endif
   const int64_t cap = (int64_t)ROW_LDS_CAP * 256 / BT;
   const int nb = (int)(want < 1 ? 1 : (want > cap ? cap : want));
-  hipLaunchKernelGGL((row_pass_kernel<KP, LIK, BT>), dim3(nb, a.S > 1 ? a.S : 1), dim3(BT), lds, st,
+  hipLaunchKernelGGL((row_pass_kernel<KP, LIK, BT, PACKED>), dim3(nb, a.S > 1 ? a.S : 1), dim3(BT), lds, st,
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z,
-                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride);
+                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent);
   return true;
+}
+
+// packed entry stream (spmf_counts.ent) when the batch carries one
+template <int KP, int LIK, int BT>
+static bool launch_row_lds(const RowArgs& a, hipStream_t st) {
+  return a.ent ? launch_row_lds_t<KP, LIK, BT, true>(a, st) : launch_row_lds_t<KP, LIK, BT, false>(a, st);
 }
 
 #ifndef ROW_LDS_PHI
@@ -441,7 +482,7 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
 #define SPMF_ROW_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, \
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, \
-                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride)
+                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent)
   if (a.logt == 4) SPMF_ROW_LAUNCH(4);
   else if (a.logt == 3) SPMF_ROW_LAUNCH(3);
   else if (a.logt == 2) SPMF_ROW_LAUNCH(2);

@@ -17,6 +17,8 @@ per-row statistics come from the HIP pre-pass kernel ``spmf_counts_stats``.
 from __future__ import annotations
 
 
+import os
+
 import numpy as np
 import torch
 
@@ -101,6 +103,15 @@ class SparseCounts:
         self.row_scale = None      # xi_b, set by PoissonFactorization
         self._xi_key = None
         self.gval = None           # g(x) = log(x/eta+1) per entry (log_transform only)
+        # packed copy of the CSR entries for the row pass (spmf_counts.ent): col << 16 | count,
+        # when the columns fit 16 bits and every stored value is an integer count below 65536
+        self.ent = None
+        if self.nnz > 0 and self.n_cols <= 65536 and os.environ.get("SPMF_PACKED_ENTRIES", "1") != "0":
+            v = self.val
+            if bool(((v >= 0) & (v <= 65535.0) & (v == torch.floor(v))).all()):
+                w = (self.col_idx.to(torch.int64) << 16) | v.to(torch.int64)
+                # bit pattern of a uint32 in an int32 tensor (torch has no uint32 arithmetic)
+                self.ent = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
         self.pc_gval = None
         self._g_key = None
         self._keep = []
@@ -324,6 +335,7 @@ class SparseCounts:
                 cs.max_items_half[h] = (int(self.items_per_half[h, p0:p1].max())
                                         if self.items.numel() else 0)
         cs.gval = self.gval.data_ptr() if self.gval is not None else None
+        cs.ent = self.ent.data_ptr() if getattr(self, "ent", None) is not None else None
         cs.pc_gval = self.pc_gval.data_ptr() if self.pc_gval is not None else None
         return cs
 

@@ -48,7 +48,7 @@ def test_struct_sizes_agree_between_library_ctypes_and_integration_stub(lib):
     """spmf_sizeof_*: the library's own struct sizes == the ctypes mirrors in
     spmf_amd/_lib.py == the stub INTEGRATION.md tells a maintainer to copy."""
     from spmf_amd import _lib
-    assert lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct) == 160
+    assert lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct) == 168
     assert lib.spmf_sizeof_sur_var() == C.sizeof(_lib.SurVar)
     assert lib.spmf_sizeof_adam_var() == C.sizeof(_lib.AdamVar)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
@@ -84,8 +84,9 @@ def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
 def test_counts_struct_layout_matches_header():
     from spmf_amd._lib import CountsStruct
     # 2*int64 + 4*int32 + 7 pointers + double + 2 pointers + (2 pointers, 2 int32)
-    # + column split: pointer + 4 int32
-    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8 + 16 + 16 + 8 + 8 + 16
+    # + column split: pointer + 4 int32 + the packed entry stream's pointer
+    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8 + 16 + 16 + 8 + 8 + 16 + 8
+    assert CountsStruct.ent.offset == 160
     assert CountsStruct.item_mid.offset == 136 and CountsStruct.col_split.offset == 144
     assert CountsStruct.max_items_half.offset == 148
     assert CountsStruct.gval.offset == 96
@@ -108,6 +109,10 @@ def test_sparse_counts_layout(N, D, P, density):
     np.testing.assert_array_equal(sc.col_idx.numpy(), ref.indices)
     np.testing.assert_array_equal(sc.val.numpy(), ref.data)
     np.testing.assert_array_equal(sc.to_dense().numpy(), x)
+    if sc.nnz:   # integer counts below 65536 in fewer than 65536 columns: col << 16 | count
+        w = sc.ent.numpy().astype(np.int64) & 0xffffffff
+        np.testing.assert_array_equal(w >> 16, ref.indices)
+        np.testing.assert_array_equal((w & 0xffff).astype(np.float32), ref.data)
     # scipy CSR input gives the same layout
     sc2 = SparseCounts.from_any(ref, "cpu", P)
     np.testing.assert_array_equal(sc2.pc_row.numpy(), sc.pc_row.numpy())
@@ -259,3 +264,23 @@ def test_balanced_panel_rows_fill_l2_and_count_in_eights():
     assert balanced_panel_rows(125_000, 32) == 7872         # 16 panels (an 8-GPU shard of C3)
     assert balanced_panel_rows(20_000, 16) == 20_000        # a reference-sized minibatch: one panel
     assert balanced_panel_rows(5, 2) == 5 and balanced_panel_rows(0, 2) == 1
+
+
+def test_packed_entries_only_for_integer_counts_in_16_bits():
+    """spmf_counts.ent (col << 16 | count) exists only when it is exact: real-valued or
+    large entries, or more than 65536 columns, keep the canonical col / val stream."""
+    from spmf_amd.sparse import SparseCounts
+    x = np.zeros((6, 9), dtype=np.float32)
+    x[1, 3], x[2, 8], x[4, 0] = 2.0, 65535.0, 7.0
+    sc = SparseCounts.from_dense(x, "cpu", 4)
+    w = sc.ent.numpy().astype(np.int64) & 0xffffffff
+    assert w.tolist() == [(3 << 16) | 2, (8 << 16) | 65535, 7]
+    for bad in (2.5, 65536.0):
+        y = x.copy()
+        y[1, 3] = bad
+        assert SparseCounts.from_dense(y, "cpu", 4).ent is None
+    wide = sp.csr_matrix((np.ones(2, np.float32), (np.array([0, 1]), np.array([5, 70000]))), shape=(2, 70001))
+    assert SparseCounts.from_any(wide, "cpu", 2).ent is None
+    top = sp.csr_matrix((np.ones(1, np.float32), (np.array([0]), np.array([65535]))), shape=(1, 65536))
+    t = SparseCounts.from_any(top, "cpu", 1)
+    assert (int(t.ent[0]) & 0xffffffff) == (65535 << 16) | 1
