@@ -133,6 +133,10 @@ typedef struct spmf_counts {
    * tests/spmf_test.py:19); NULL otherwise.  Halves the entry stream of the sweeps that read the
    * raw counts (4 instead of 8 bytes per stored entry); col_idx / val stay the canonical arrays. */
   const uint32_t* ent;
+  /* The same for the column pass's lists: pc_ent[i] = (row - first row of its panel) << 16 | count,
+   * in the order (and with the pc_pad) of pc_row / pc_val; needs panel_rows <= 65536 as well.
+   * Used by the four-per-lane fetch only; NULL otherwise. */
+  const uint32_t* pc_ent;
 } spmf_counts;
 
 int spmf_version(void);

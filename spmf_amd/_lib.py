@@ -49,7 +49,7 @@ class CountsStruct(C.Structure):
         ("max_items_per_panel", C.c_int32), ("pc_pad", C.c_int32),
         ("item_mid", C.c_void_p), ("col_split", C.c_int32),
         ("max_items_half", C.c_int32 * 2), ("reserved2_", C.c_int32),
-        ("ent", C.c_void_p),
+        ("ent", C.c_void_p), ("pc_ent", C.c_void_p),
     ]
 
 

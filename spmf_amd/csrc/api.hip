@@ -585,6 +585,8 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
             ct->item_ptr, ct->items, ct->pc_row, ct->pc_val, c->Vp, c->phi, c->z, c->gzs, acc + L.gA_off(hf),
             acc + L.gV_off(hf), acc + L.gphi_off(hf), logt, ct->pc_gval, c->ctype, split ? ct->item_mid : nullptr,
             split ? hf + 1 : 0, nbat, ct->n_rows, (int64_t)al_, ct->pc_pad};
+        ca.pc_ent = ct->pc_ent;
+        ca.panel_rows = ct->panel_rows;
         if (hf == (split ? 1 : 0)) {
           // the fp64 scalars of the row pass are complete before this launch starts: its
           // extra first block folds them into the accumulator tail (the former pack launch)

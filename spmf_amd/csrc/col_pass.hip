@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
 
 // ---- the same pass with 16-B entry fetches (needs padded panel-CSC arrays) ----
 // LIK: 0 Poisson / linear, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
-template <int KP, int LIK>
+template <int KP, int LIK, bool PACKED>
 __global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
     int D, int n_panels, int row_base, int blocks_per_panel,
     const int32_t* __restrict__ item_ptr, const int4* __restrict__ items,
@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
     float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi,
     const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel,
     int64_t Brows, int64_t acc_stride, const double* __restrict__ pack_dacc,
-    float* __restrict__ pack_tail, int64_t dacc_stride) {
+    float* __restrict__ pack_tail, int64_t dacc_stride, const uint32_t* __restrict__ pc_ent,
+    int panel_rows) {
   if (pack_dacc && blockIdx.x == 0) {
     pack_block<KP>(pack_dacc + (size_t)blockIdx.y * dacc_stride, pack_tail + (size_t)blockIdx.y * acc_stride);
     return;
@@ -303,29 +304,57 @@ __global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
   struct __attribute__((packed, aligned(4))) I4 { int x, y, z, w; };
   struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
   constexpr int FE = 4 * LPN;                         // entries per fetch and group
-  auto fetch = [&](int (&rr_)[4], float (&xx_)[4], float (&gx_)[4], int& cnt_) {
+  // fetch_raw only LOADS (the fetch for the next iteration stays untouched until then: decoding
+  // it right away would put the wait for it in front of this iteration's gathers); decode turns
+  // the words of the CURRENT fetch into batch rows / counts where they are used.
+  // PACKED: one word per entry, row inside the panel << 16 | count (spmf_counts.pc_ent).
+  auto fetch_raw = [&](I4& r, F4& x, F4& g, int& cnt_) {
     cnt_ = min(FE, end - cur);                        // 0 once the item is exhausted
     const int e = cur + 4 * sub;
-    I4 r = {0, 0, 0, 0};
-    F4 x = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+    r = {0, 0, 0, 0};
+    x = {0.f, 0.f, 0.f, 0.f};
+    g = {0.f, 0.f, 0.f, 0.f};
     if (4 * sub < cnt_) {
-      r = *reinterpret_cast<const I4*>(pc_row + e);
-      x = *reinterpret_cast<const F4*>(pc_val + e);
+      if (PACKED) {
+        r = *reinterpret_cast<const I4*>(reinterpret_cast<const int32_t*>(pc_ent) + e);
+      } else {
+        r = *reinterpret_cast<const I4*>(pc_row + e);
+        x = *reinterpret_cast<const F4*>(pc_val + e);
+      }
       if (LIK == 1 || LIK == 4) g = *reinterpret_cast<const F4*>(pc_gval + e);
     }
-    const int left = cnt_ - 4 * sub;                  // valid components of this lane
-    rr_[0] = left > 0 ? r.x - row_base : 0; xx_[0] = left > 0 ? x.x : 0.f; gx_[0] = left > 0 ? g.x : 0.f;
-    rr_[1] = left > 1 ? r.y - row_base : 0; xx_[1] = left > 1 ? x.y : 0.f; gx_[1] = left > 1 ? g.y : 0.f;
-    rr_[2] = left > 2 ? r.z - row_base : 0; xx_[2] = left > 2 ? x.z : 0.f; gx_[2] = left > 2 ? g.z : 0.f;
-    rr_[3] = left > 3 ? r.w - row_base : 0; xx_[3] = left > 3 ? x.w : 0.f; gx_[3] = left > 3 ? g.w : 0.f;
     cur += cnt_;
   };
+  const int pbase = PACKED ? p * panel_rows : -row_base;   // batch row of a list word
+  auto decode = [&](const I4& r, const F4& x, const F4& g, int cnt_, int (&rr_)[4], float (&xx_)[4],
+                    float (&gx_)[4]) {
+    const int left = cnt_ - 4 * sub;                  // valid components of this lane
+    const int rw[4] = {r.x, r.y, r.z, r.w};
+    const float xw[4] = {x.x, x.y, x.z, x.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool on = left > t;
+      if (PACKED) {
+        const uint32_t w = (uint32_t)rw[t];
+        rr_[t] = on ? (int)(w >> 16) + pbase : 0;
+        xx_[t] = on ? (float)(w & 0xffffu) : 0.f;
+      } else {
+        rr_[t] = on ? rw[t] + pbase : 0;
+        xx_[t] = on ? xw[t] : 0.f;
+      }
+      gx_[t] = on ? gw[t] : 0.f;
+    }
+  };
 
-  int rr0[4], rr1[4], cnt0, cnt1;
-  float xx0[4], xx1[4], gx0[4], gx1[4];
-  fetch(rr0, xx0, gx0, cnt0);
+  I4 rA, rB;
+  F4 xA, xB, gA_, gB_;
+  int cnt0, cnt1;
+  fetch_raw(rA, xA, gA_, cnt0);
   while (__any(cnt0 > 0)) {
-    fetch(rr1, xx1, gx1, cnt1);                       // one fetch (4*LPN entries) ahead of use
+    fetch_raw(rB, xB, gB_, cnt1);                     // one fetch (4*LPN entries) ahead of use
+    int rr0[4];
+    float xx0[4], gx0[4];
+    decode(rA, xA, gA_, cnt0, rr0, xx0, gx0);
 #pragma unroll
     for (int g0 = 0; g0 < FE; g0 += GRP) {
       if (__any(cnt0 > g0)) {                         // wave-uniform
@@ -362,8 +391,7 @@ __global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
         }
       }
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { rr0[t] = rr1[t]; xx0[t] = xx1[t]; gx0[t] = gx1[t]; }
+    rA = rB; xA = xB; gA_ = gB_;
     cnt0 = cnt1;
   }
   // ---- transpose through LDS so each atomic instruction covers whole rows --
@@ -403,10 +431,18 @@ static bool launch_col_t(const ColArgs& a, hipStream_t st) {
       a.gphi, a.ctype, a.item_mid, a.half_sel, a.B, a.acc_stride, a.pack_dacc, a.pack_tail,     \
       a.dacc_stride
   const bool wide = COL_WIDE && a.pc_pad >= KP - 1;   // 4*LPN - 1 entries of readable padding
-#define SPMF_COL_LAUNCH(L_)                                                              \
-  do {                                                                                   \
-    if (wide) hipLaunchKernelGGL((col_pass_wide_kernel<KP, L_>), SPMF_COL_ARGS);         \
-    else hipLaunchKernelGGL((col_pass_kernel<KP, L_>), SPMF_COL_ARGS);                   \
+  // packed lists (spmf_counts.pc_ent: row in panel << 16 | count) when the batch carries them
+  const bool packed = wide && a.pc_ent && a.panel_rows > 0 && a.panel_rows <= 65536;
+#define SPMF_COL_LAUNCH(L_)                                                                        \
+  do {                                                                                             \
+    if (packed)                                                                                    \
+      hipLaunchKernelGGL((col_pass_wide_kernel<KP, L_, true>), SPMF_COL_ARGS, a.pc_ent,            \
+                         a.panel_rows);                                                            \
+    else if (wide)                                                                                 \
+      hipLaunchKernelGGL((col_pass_wide_kernel<KP, L_, false>), SPMF_COL_ARGS, a.pc_ent,           \
+                         a.panel_rows);                                                            \
+    else                                                                                           \
+      hipLaunchKernelGGL((col_pass_kernel<KP, L_>), SPMF_COL_ARGS);                                \
   } while (0)
   if (a.logt == 4) SPMF_COL_LAUNCH(4);
   else if (a.logt == 3) SPMF_COL_LAUNCH(3);

@@ -64,6 +64,8 @@ struct ColArgs {
   int S;
   int64_t B, acc_stride;
   int pc_pad = 0;           // readable entries behind the last list of pc_row / pc_val / pc_gval
+  const uint32_t* pc_ent = nullptr;   // packed (row in panel << 16 | count) copy of pc_row / pc_val, or null
+  int panel_rows = 0;
   // optional: one extra block folds the row pass's fp64 scalar block (kDaccRep replicas) into
   // the accumulator tail as (hi, lo) float pairs -- what pack_kernel does as its own launch
   const double* pack_dacc = nullptr;

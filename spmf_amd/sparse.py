@@ -165,6 +165,14 @@ class SparseCounts:
         self.pc_val = torch.cat([self.val[order],
                                  torch.zeros(PC_PAD, dtype=torch.float32, device=dev)]).contiguous()
         self.pc_pad = PC_PAD       # what batch_struct reports (0 selects the entry-at-a-time fetch)
+        # packed lists for the column pass (spmf_counts.pc_ent): row inside its panel << 16 | count
+        self.pc_ent = None
+        if self.nnz > 0 and P <= 65536 and os.environ.get("SPMF_PACKED_ENTRIES", "1") != "0":
+            v = self.pc_val[:self.nnz]
+            if bool(((v >= 0) & (v <= 65535.0) & (v == torch.floor(v))).all()):
+                w = ((rows[order] % P) << 16) | v.to(torch.int64)
+                w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+                self.pc_ent = torch.cat([w, torch.zeros(PC_PAD, dtype=torch.int32, device=dev)]).contiguous()
         cnt = torch.bincount(key, minlength=nP * D)
         excl = torch.zeros(nP * D + 1, dtype=torch.int64, device=dev)
         excl[1:] = torch.cumsum(cnt, 0)
@@ -336,6 +344,7 @@ class SparseCounts:
                                         if self.items.numel() else 0)
         cs.gval = self.gval.data_ptr() if self.gval is not None else None
         cs.ent = self.ent.data_ptr() if getattr(self, "ent", None) is not None else None
+        cs.pc_ent = self.pc_ent.data_ptr() if getattr(self, "pc_ent", None) is not None else None
         cs.pc_gval = self.pc_gval.data_ptr() if self.pc_gval is not None else None
         return cs
 
