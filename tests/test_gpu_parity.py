@@ -112,6 +112,31 @@ def test_row_lengths_around_the_chunk_boundaries(K, log_transform):
     assert_close_grads(grads, grads_ref, O.energy_grad_scales(cfg, x, params))
 
 
+@pytest.mark.parametrize("kind", ["fractional", "large"])
+def test_counts_outside_the_packed_format_take_the_canonical_streams(kind):
+    """spmf_counts.ent / pc_ent (col << 16 | count) exist only for integer counts below 65536:
+    real-valued entries (the reference casts whatever it is given, poisson.py:43,182) or one
+    count of 70 000 keep the col / val arrays -- same kernels' canonical instances, B >= 4096 so
+    that the resident-set row launch and the four-per-lane column fetch are the ones that run."""
+    from spmf_amd.sparse import SparseCounts
+    B, D, K, S = 4200, 300, 32, 1
+    cfg, x, params = make_problem(B, D, K, S, 321, 0.2)
+    if kind == "fractional":
+        x = x * 0.5
+    else:
+        x[7, 11] = 70000.0
+    sc = SparseCounts.from_any(x, "cuda", 1024)
+    assert sc.ent is None and sc.pc_ent is None
+    ok = SparseCounts.from_any(np.round(np.minimum(x, 100.0)), "cuda", 1024)
+    assert ok.ent is not None and ok.pc_ent is not None
+    parts_ref, grads_ref, _ = O.energy_and_grads(cfg, x, params)
+    m = build_model(cfg, 1024)
+    parts, grads, nnf = m.energy_and_grads({"counts": sc}, params)
+    assert float(nnf.sum()) == 0
+    assert_close_parts(parts, parts_ref)
+    assert_close_grads(grads, grads_ref, O.energy_grad_scales(cfg, x, params))
+
+
 def test_prior_weight_scales_only_prior_gradient():
     cfg, x, params = make_problem(60, 40, 8, 1, 7, 0.2)
     _, _, groups = O.energy_and_grads(cfg, x, params)
