@@ -532,7 +532,11 @@ def main():
             "config": {"workload": desc + f", S={S}, full batch, row-sharded x{world}",
                        "rows": rows_g, "cols": D, "nnz": nnz_g, "latent_dim": K,
                        "samples": S, "parallelism": f"row-shard dp{world}",
-                       "panel_rows": args.panel_rows},
+                       "panel_rows": args.panel_rows,
+                       # physical entry streams (the algorithmic bytes above stay canonical: 8 B per entry and pass)
+                       "entry_format": ("packed u32: col<<16|count (row pass), row-in-panel<<16|count (column pass)"
+                                        if getattr(sc, "ent", None) is not None and getattr(sc, "pc_ent", None) is not None
+                                        else "canonical int32 index + f32 value")},
             "achieved_hbm_gbps_step": b_tot_g / world / (ms_step * 1e-3) / 1e9,
             "frac_hbm_roofline_step": b_tot_g / world / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_step": b_tot_g,

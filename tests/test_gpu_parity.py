@@ -137,6 +137,34 @@ def test_counts_outside_the_packed_format_take_the_canonical_streams(kind):
     assert_close_grads(grads, grads_ref, O.energy_grad_scales(cfg, x, params))
 
 
+@pytest.mark.parametrize("K,log_transform", [(32, False), (64, True)])
+def test_packed_and_canonical_entry_streams_agree_bit_for_bit(K, log_transform, monkeypatch):
+    """The packed words (spmf_counts.ent / pc_ent) carry exactly what col / val and pc_row /
+    pc_val carry, and the kernels' two instances do the same arithmetic: the results agree up to
+    the order of the atomic sums (fp64 block sums of the row pass, float column sums)."""
+    from spmf_amd.sparse import SparseCounts
+    B, D, S = 4300, 257, 1
+    cfg, x, params = make_problem(B, D, K, S, 99 + K, 0.25)
+    cfg.log_transform = log_transform
+    if log_transform:
+        T = torch.as_tensor
+        z = O.encode(cfg, T(x), T(params["u"]), T(params["s"]))
+        params["v"] *= 8.0 / float((torch.matmul(z, T(params["v"])) * cfg.eta_i).max())
+    packed = SparseCounts.from_any(x, "cuda", 512)
+    monkeypatch.setenv("SPMF_PACKED_ENTRIES", "0")
+    canon = SparseCounts.from_any(x, "cuda", 512)
+    monkeypatch.delenv("SPMF_PACKED_ENTRIES")
+    assert packed.ent is not None and packed.pc_ent is not None and canon.ent is None and canon.pc_ent is None
+    m = build_model(cfg, 512)
+    pa, ga, _ = m.energy_and_grads({"counts": packed}, params)
+    pb, gb, _ = m.energy_and_grads({"counts": canon}, params)
+    for k in ("x", "z"):   # fp64 block sums added with atomics: equal up to their order
+        np.testing.assert_allclose(pa[k].cpu().numpy(), pb[k].cpu().numpy(), rtol=1e-12, err_msg=k)
+    for k in ga:
+        a, b = ga[k].double(), gb[k].double()
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), k
+
+
 def test_prior_weight_scales_only_prior_gradient():
     cfg, x, params = make_problem(60, 40, 8, 1, 7, 0.2)
     _, _, groups = O.energy_and_grads(cfg, x, params)
