@@ -470,13 +470,23 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
       // against the 256-thread grid (profiles/r03_sparse_pass_attempts.txt e25)
       if (launch_row_lds<KP, 0, 512>(a, st)) return;
     }
-    if (ROW_LDS_PHI && a.mode != 1 && (a.logt == 0 || a.logt == 1) && a.B >= 4096) {
+    if (ROW_LDS_PHI && a.mode != 1 && a.logt >= 0 && a.logt <= 3 && a.B >= 4096) {
+      // (likelihood codes 2 and 3, Bernoulli and mixed, since the end of round 3: their
+      //  stored-cell sweep read phi one entry per lane from global memory, C5 0.61 ms)
       const size_t need = (size_t)a.D * 4;
+      bool done = false;
       if (need <= 80 * 1024) {
-        if (a.logt == 0 ? launch_row_lds<KP, 0, 512>(a, st) : launch_row_lds<KP, 1, 512>(a, st)) return;
+        done = a.logt == 0   ? launch_row_lds<KP, 0, 512>(a, st)
+               : a.logt == 1 ? launch_row_lds<KP, 1, 512>(a, st)
+               : a.logt == 2 ? launch_row_lds<KP, 2, 512>(a, st)
+                             : launch_row_lds<KP, 3, 512>(a, st);
       } else if (need <= 160 * 1024 - 1024) {
-        if (a.logt == 0 ? launch_row_lds<KP, 0, 1024>(a, st) : launch_row_lds<KP, 1, 1024>(a, st)) return;
+        done = a.logt == 0   ? launch_row_lds<KP, 0, 1024>(a, st)
+               : a.logt == 1 ? launch_row_lds<KP, 1, 1024>(a, st)
+               : a.logt == 2 ? launch_row_lds<KP, 2, 1024>(a, st)
+                             : launch_row_lds<KP, 3, 1024>(a, st);
       }
+      if (done) return;
     }
   }
 #define SPMF_ROW_LAUNCH(L_)                                                                    \
