@@ -113,12 +113,13 @@ def test_row_lengths_around_the_chunk_boundaries(K, log_transform):
 
 
 @pytest.mark.parametrize("kind", ["fractional", "large"])
-def test_counts_outside_the_packed_format_take_the_canonical_streams(kind):
+def test_counts_outside_the_packed_format_take_the_canonical_streams(kind, monkeypatch):
     """spmf_counts.ent / pc_ent (col << 16 | count) exist only for integer counts below 65536:
     real-valued entries (the reference casts whatever it is given, poisson.py:43,182) or one
     count of 70 000 keep the col / val arrays -- same kernels' canonical instances, B >= 4096 so
     that the resident-set row launch and the four-per-lane column fetch are the ones that run."""
     from spmf_amd.sparse import SparseCounts
+    monkeypatch.delenv("SPMF_PACKED_ENTRIES", raising=False)   # (a run of the suite with packing switched off)
     B, D, K, S = 4200, 300, 32, 1
     cfg, x, params = make_problem(B, D, K, S, 321, 0.2)
     if kind == "fractional":
@@ -150,6 +151,7 @@ def test_packed_and_canonical_entry_streams_agree_bit_for_bit(K, log_transform, 
         T = torch.as_tensor
         z = O.encode(cfg, T(x), T(params["u"]), T(params["s"]))
         params["v"] *= 8.0 / float((torch.matmul(z, T(params["v"])) * cfg.eta_i).max())
+    monkeypatch.delenv("SPMF_PACKED_ENTRIES", raising=False)
     packed = SparseCounts.from_any(x, "cuda", 512)
     monkeypatch.setenv("SPMF_PACKED_ENTRIES", "0")
     canon = SparseCounts.from_any(x, "cuda", 512)
