@@ -588,7 +588,13 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
         if action == "converged":
             break
         if action == "improved":
-            best_state = [p.detach().clone() for p in sur.trainable_variables]
+            # (one multi-tensor copy into buffers kept for the whole fit: two dozen clones per
+            #  improving epoch were a tenth of a full-batch epoch on C3)
+            cur = [p.detach() for p in sur.trainable_variables]
+            if best_state is None:
+                best_state = [p.clone() for p in cur]
+            else:
+                torch._foreach_copy_(best_state, cur)
             continue
         opt.set_lr(ctl.lr)
         if verbose:
