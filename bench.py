@@ -100,20 +100,32 @@ def cpu_baseline(sc, model, params, K, max_rows=125_000):
         out = prep.step(one["u"], one["v"], one["w"], one["s"])
         SE.prior_term(one, model.u_tau_scale, model.s_tau_scale, decay)
         return out
-    ref = step()
-    # the checker's other job: the HIP path on the same rows, same draw (data term only)
+    # the checker's other job: the HIP path on the same rows, same draw (data term only),
+    # entry by entry against the port's own yardstick (per entry the sum of |contributions| of the
+    # stored-cell, minus-rate and z-prior pieces: tests/_gradcheck.py's metric, pinned to
+    # oracle.energy_grad_scales in tests/test_oracle.py) -- and the array-norm figure beside it
+    ref = prep.step(one["u"], one["v"], one["w"], one["s"], scales=True)
+    SE.prior_term(one, model.u_tau_scale, model.s_tau_scale, decay)
     first = {k: v[:1] for k, v in params.items()}
     parts, grads, _ = model.energy_and_grads({"counts": sc, "panels": (0, npan)}, first,
                                              prior_weight=0.0)
     torch.cuda.synchronize()
-    gerr = 0.0
+    gerr, worst, worst_at = 0.0, 0.0, None
     for name in ("u", "v", "w", "s"):
         r = np.asarray(ref["grads"][name], dtype=np.float64)
         g = grads[name][0].double().cpu().numpy().reshape(r.shape)
-        gerr = max(gerr, float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)))
+        err = np.abs(g - r)
+        gerr = max(gerr, float(err.max() / max(np.abs(r).max(), 1e-300)))
+        ys = ref["scales"][name].reshape(r.shape)
+        ratio = np.where(ys > 0, err / np.where(ys > 0, ys, 1.0), np.where(err > 0, np.inf, 0.0))
+        i = int(np.argmax(ratio))
+        if float(ratio.reshape(-1)[i]) >= worst:
+            worst, worst_at = float(ratio.reshape(-1)[i]), f"{name}[{i}]"
     parity = {"rows": int(n),
               "x_rel": abs(float(parts["x"][0]) - ref["x"]) / abs(ref["x"]),
               "z_rel": abs(float(parts["z"][0]) - ref["z"]) / abs(ref["z"]),
+              "grad_worst_entry": worst, "grad_worst_entry_at": worst_at,
+              "grad_worst_entry_unit": "|hip - port| / sum of |contributions| to that entry; contract 1e-5",
               "grad_max_rel": gerr}
     for _ in range(2):
         step()                                   # 3 warm-ups with the one above
@@ -156,6 +168,58 @@ def c1_dense_cpu_baseline():
             ts.append(time.perf_counter() - t0)
     ts.sort()
     return 1.0 / (0.5 * (ts[4] + ts[5])), cores
+
+
+def c5_extra(dev, steps=10, warmup=3):
+    """BASELINE config 5 (mixed likelihood: 200k x 10k, even columns Poisson, odd columns
+    Bernoulli, K = 32) on this one GPU, for the `also` block of the default line: ms per energy +
+    gradient step, the kernel taps, and the dense sigmoid kernels against the f32-MFMA peak on
+    the algorithmic 6*B*D_bern*K.  Generated after the headline's timed region."""
+    import contextlib
+    import ctypes as C
+    import torch
+    from spmf_amd import MixedFactorization, _lib, synth
+    from spmf_amd.sparse import balanced_panel_rows
+    rows, D, _density, K, _desc = WORKLOADS["c5"]
+    pr = balanced_panel_rows(rows, K)
+    sc, mask = synth.mixed_c5(rows, D, dev, 20241218 + 5, panel_rows=pr, first_chunk=0,
+                              chunk_rows=synth.MIXED_CHUNK_ROWS)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = MixedFactorization(mask, latent_dim=K, feature_dim=D, u_tau_scale=1.0 / (rows * D) ** 0.5,
+                                   device=dev, panel_rows=pr)
+    colsum = torch.zeros(D, dtype=torch.float64, device=dev)
+    colnnz = torch.zeros(D, dtype=torch.float64, device=dev)
+    sc.compute_stats(model._handle(), colsum, colnnz)
+    cm = colsum / colnnz
+    model.eta_i = torch.where(cm > 1, cm, torch.ones_like(cm)).reshape(1, D)
+    model.xi_u_global = float(torch.nansum(cm))
+    torch.manual_seed(20241218)
+    params = model.surrogate_distribution.sample(1)
+    batch = {"counts": sc}
+    lib, h = _lib.load(), model._handle()
+    for _ in range(warmup):
+        model.energy_and_grads(batch, params)
+    torch.cuda.synchronize()
+    lib.spmf_ctx_enable_timing(h, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        parts, _, nnf = model.energy_and_grads(batch, params)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    t6 = (C.c_float * 6)()
+    _lib.check(h, lib.spmf_last_timing(h, t6), "spmf_last_timing")
+    lib.spmf_ctx_enable_timing(h, 0)
+    d_bern = int(mask.sum())
+    tf = 6.0 * rows * d_bern * max(32, K) / (t6[5] * 1e-3) / 1e12
+    out = {"c5_ms_per_step": ms, "c5_steps_per_sec": 1e3 / ms, "c5_nnz": int(sc.nnz),
+           "c5_kernel_ms": {"prep": round(t6[0], 4), "row_pass": round(t6[1], 4), "col_pass": round(t6[2], 4),
+                            "finish": round(t6[3], 4), "dense": round(t6[5], 4)},
+           "c5_dense_tflops_algorithmic": tf, "c5_dense_frac": tf / MFMA_F32_PEAK_TFLOPS,
+           "c5_dense_frac_of": "algorithmic 6*B*D_bern*K against the f32-MFMA peak (157.3 TF/s)",
+           "c5_n_nonfinite": float(nnf.sum()), "c5_elbo_x": float(parts["x"][0])}
+    del model, sc, params
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -303,10 +367,12 @@ def main():
     hook = None
     if distributed:
         from spmf_amd.dist import LibraryComm, ShardReducer
-        # SPMF_BENCH_COMM=lib: the library's own RCCL communicator (spmf_allreduce) moves the
-        # accumulators; default: torch.distributed's (the transport rehearsed on CPU with gloo)
+        # transport of the step's one collective: the library's own RCCL communicator
+        # (spmf_allreduce: ncclAllReduce on the step's stream, 3.6 us against 15 us per one-rank
+        # call through torch.distributed, and capturable in the VI step's hipGraph).
+        # SPMF_BENCH_COMM=torch selects torch.distributed's; the gloo rehearsal always uses it.
         comm = None
-        if os.environ.get("SPMF_BENCH_COMM") == "lib" and backend == "nccl":
+        if os.environ.get("SPMF_BENCH_COMM", "lib") != "torch" and backend == "nccl":
             comm = LibraryComm(model)
         hook = ShardReducer(comm=comm)
         hook.set_batch_totals(rows_g, lgam_g)
@@ -401,15 +467,48 @@ def main():
             # the multi-GPU step's critical path on one rank: data pass, prior half of the
             # finish on the side stream, spmf_allreduce, data half of the finish
             from spmf_amd.dist import ShardReducer
-            red1 = ShardReducer(comm=comm1)
+            red1 = ShardReducer(comm=comm1)          # one rank: prior half NOT forked (overlap_prior)
             red1.set_batch_totals(extras["shard125k_rows"],
                                   float(sc.row_lgamma[:extras["shard125k_rows"]].sum()))
             extras["shard125k_1rank_rccl_ms_per_step"] = timed(
                 lambda: model.energy_and_grads(sb, params, all_reduce=red1), 50, 5)
+            # the same with the prior half of the finish forked to the side stream under the
+            # collective, as ranks of a world > 1 run it (what the fork/join costs on one rank)
+            red1f = ShardReducer(comm=comm1, overlap_prior=True)
+            red1f.set_batch_totals(red1.rows_global, red1.lgamma_global)
+            extras["shard125k_1rank_rccl_forked_prior_ms_per_step"] = timed(
+                lambda: model.energy_and_grads(sb, params, all_reduce=red1f), 50, 5)
+            # the whole row-sharded VI step of that shard on the device (vi.vi_step_dev with the
+            # reducer: noise, surrogate, data pass, spmf_allreduce, finish, gate, chain rule +
+            # Adam; no host read-back), eager and replayed from its hipGraph
+            from spmf_amd import vi as _vi
+            sur = model.surrogate_distribution
+            saved = [p_.detach().clone() for p_ in sur.trainable_variables]
+            for tag, use_graph, red in (("eager", False, red1), ("graph", True, red1),
+                                        ("graph_no_comm", True, None)):
+                o_ = _vi.AdamHIP(model, sur.trainable_variables, 1e-3)
+                o_.init_state(3.0)
+                run_ = _vi.StepRunner(model, o_, rows_g, S, use_graph=use_graph, all_reduce=red)
+                key = {"eager": "shard125k_vi_1rank_rccl_eager_ms", "graph": "shard125k_vi_1rank_rccl_ms",
+                       "graph_no_comm": "shard125k_vi_no_comm_ms"}[tag]
+                extras[key] = timed(lambda: run_.step(sb), 50, 5)
+                if use_graph:
+                    extras[key.replace("_ms", "_replays")] = run_.replays
+                del run_, o_
+                with torch.no_grad():
+                    for p_, q_ in zip(sur.trainable_variables, saved):
+                        p_.copy_(q_)
+            del saved
             _lib.check(h, lib.spmf_comm_destroy(h), "spmf_comm_destroy")
         except Exception as e:                      # no librccl on the box: report, do not fail
             extras["allreduce_1rank_us"] = None
             extras["allreduce_error"] = str(e)[:120]
+    if world == 1 and not args.no_extras and args.workload == "c3":
+        # a second BASELINE config in the driver-timed record
+        try:
+            extras.update(c5_extra(dev))
+        except Exception as e:
+            extras["c5_error"] = str(e)[:200]
     if world == 1 and not args.no_extras:
         # "surrogate at its init values and after 50 seeded Adam steps" -- the same
         # energy + gradient step timed again at draws from the trained surrogate
@@ -434,15 +533,15 @@ def main():
     opt = vi.AdamHIP(model, model.surrogate_distribution.trainable_variables, 1e-3)
     opt.init_state(3.0)
     n_vi = max(2, min(5, args.steps))
+    vi_seed = 20241218 + 77          # row shards replicate the surrogate: every rank draws the same noise
     for it in range(n_vi + 1):
         if it == 1:
             torch.cuda.synchronize()
             tv = time.perf_counter()
-        if hook is None:
-            vi.vi_step_dev(model, opt, batch, rows_g, S)      # what fit() runs: no host read-back
-        else:
-            l_, g_, _ = vi.elbo_step(model, batch, rows_g, S, all_reduce=hook)
-            opt.step(g_, 3.0)
+        # what fit() runs, one rank or many: no host read-back (row shards: the reducer's
+        # all-reduce sits inside the device-gated step)
+        vi.vi_step_dev(model, opt, batch, rows_g, S, all_reduce=hook,
+                       seed=vi_seed if hook is not None else None)
     torch.cuda.synchronize()
     vi_ms = 1e3 * (time.perf_counter() - tv) / n_vi
 

@@ -114,10 +114,13 @@ typedef struct spmf_counts {
   const int32_t* item_ptr;
   const int32_t* items;
   int32_t max_items_per_panel;
-  /* Readable int32/float entries behind the END of the last list in pc_row, pc_val (and
-   * pc_gval).  With pc_pad >= 4*ceil(K/4) - 1 (K padded to 4, 8, 16, 32, 64) the column
-   * pass fetches list entries four at a time (16-B loads that may run past a list's end);
-   * 0 selects the entry-at-a-time fetch, which never reads behind a list. */
+  /* Readable int32/float entries behind the END of the last list in pc_row, pc_val, pc_ent
+   * AND pc_gval (every list array the context's decoder reads must carry the same padding:
+   * with log_transform that includes pc_gval).  With pc_pad >= 4*ceil(K/4) - 1 (K padded to 4,
+   * 8, 16, 32, 64) the column pass fetches list entries four at a time (16-B loads that may run
+   * past a list's end); 0 selects the entry-at-a-time fetch, which never reads behind a list.
+   * Negative values are rejected.  (Until version 2 this slot was a reserved field: a caller
+   * that left it uninitialised is caught by struct_size below.) */
   int32_t pc_pad;
   /* Optional column split of the work items (multi-GPU overlap): inside a panel
    * the items are sorted by column half first (columns < col_split, then the
@@ -127,18 +130,26 @@ typedef struct spmf_counts {
   const int32_t* item_mid;
   int32_t col_split;
   int32_t max_items_half[2];
-  int32_t reserved2_;
+  /* ABI guard (spmf_version() >= 3): sizeof(spmf_counts) as the CALLER was compiled.  Every entry
+   * point that takes a spmf_counts rejects a struct whose struct_size differs from the library's
+   * own sizeof (SPMF_E_ARG, "built against another spmf_hip.h"): a caller compiled against an older,
+   * shorter layout can no longer have the fields appended since (ent, pc_ent) read from whatever
+   * follows its struct.  Zero-initialise the struct, then set this first. */
+  int32_t struct_size;
   /* Optional packed copy of the CSR entries for the row pass: ent[i] = col_idx[i] << 16 | count,
    * valid when D <= 65536 and every stored value is an integer in [0, 65535] (counts are:
    * tests/spmf_test.py:19); NULL otherwise.  Halves the entry stream of the sweeps that read the
    * raw counts (4 instead of 8 bytes per stored entry); col_idx / val stay the canonical arrays. */
   const uint32_t* ent;
   /* The same for the column pass's lists: pc_ent[i] = (row - first row of its panel) << 16 | count,
-   * in the order (and with the pc_pad) of pc_row / pc_val; needs panel_rows <= 65536 as well.
-   * Used by the four-per-lane fetch only; NULL otherwise. */
+   * in the order (and with the pc_pad) of pc_row / pc_val; needs panel_rows <= 65536 as well
+   * (rejected otherwise).  Used by the four-per-lane fetch only; NULL otherwise. */
   const uint32_t* pc_ent;
 } spmf_counts;
 
+/* ABI version of this header: 3.  (2 -> 3: spmf_counts.struct_size replaces a reserved slot
+ * and is verified; pc_pad / ent / pc_ent are validated.)  A binding checks it at load time. */
+#define SPMF_ABI_VERSION 3
 int spmf_version(void);
 
 /* sizeof(spmf_counts) / sizeof(spmf_sur_var) / sizeof(spmf_adam_var) as this

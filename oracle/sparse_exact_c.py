@@ -44,6 +44,8 @@ def load():
         lib.spx_set_threads.argtypes = [C.c_int]
         lib.spx_data_term.restype = C.c_int
         lib.spx_data_term.argtypes = [C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 17
+        lib.spx_grad_pieces.restype = C.c_int
+        lib.spx_grad_pieces.argtypes = [C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 10
         _lib = lib
     return _lib
 
@@ -73,8 +75,12 @@ class Prepared:
         rowsum = np.asarray(X.sum(1)).reshape(self.B)
         self.xi = np.ascontiguousarray(rowsum / float(xi_global)) if scale_rows else None
 
-    def step(self, u, v, w, s):
-        """'x', 'z' and d(x+z)/d(u,v,w,s) of one draw: u [D,K], v [K,D], w [1,D], s [2,D]."""
+    def step(self, u, v, w, s, scales=False):
+        """'x', 'z' and d(x+z)/d(u,v,w,s) of one draw: u [D,K], v [K,D], w [1,D], s [2,D].
+        ``scales``: also return the entry-wise yardstick of the gradient comparison under
+        "scales" -- per entry the sum over the three additive pieces of the data term (stored-cell
+        part, minus-rate part, z prior) of |d piece / d entry|, the definition of
+        oracle.spmf_oracle.energy_grad_scales(prior=False) (pinned to it in tests/test_oracle.py)."""
         lib = load()
         B, D = self.B, self.D
         K = u.shape[1]
@@ -113,8 +119,32 @@ class Prepared:
         GA = (u * gA).sum(1)
         Gphi = eta * w * dphi
         gs = np.stack([(GA - Gphi) * s[1] / T ** 2, (Gphi - GA) * s[0] / T ** 2])
-        return {"x": part_x, "z": part_z, "n_nonfinite": int(sc[2]),
-                "grads": {"u": gu, "v": gv, "w": gw, "s": gs}, "z_rows": z, "gz_rows": gz}
+        out = {"x": part_x, "z": part_z, "n_nonfinite": int(sc[2]),
+               "grads": {"u": gu, "v": gv, "w": gw, "s": gs}, "z_rows": z, "gz_rows": gz}
+        if scales:
+            gA_pos = np.empty((D, K))
+            gA_zp = np.empty((D, K))
+            sxx = np.empty(D)
+            rc = lib.spx_grad_pieces(B, D, K, _p(self.csc_ptr), _p(self.csc_row), _p(self.csc_val),
+                                     _p(self.xi), _p(z), _p(gz), _p(veta), _p(gA_pos), _p(gA_zp), _p(sxx))
+            if rc != 0:
+                raise RuntimeError(f"spx_grad_pieces failed: {rc}")
+            zero_dk, zero_d = np.zeros((D, K)), np.zeros(D)
+            pieces = [   # (d piece / dA', d piece / dV', d piece / dphi)
+                (gA_pos, gVp + zsum[None, :], gphi),                              # stored cells: x log r
+                (-sxx[:, None] * veta[None, :], np.broadcast_to(-zsum, (D, K)), np.full(D, -float(B))),  # -sum r
+                (gA_zp, zero_dk, zero_d)]                                         # z prior
+            acc = {"u": np.zeros((D, K)), "v": np.zeros((K, D)), "w": np.zeros((1, D)), "s": np.zeros((2, D))}
+            for pA, pV, pphi in pieces:
+                a = pA / eta[:, None]
+                acc["u"] += np.abs(w1[:, None] * a)
+                acc["v"] += np.abs((pV * eta[:, None]).T)
+                acc["w"] += np.abs(eta * w2 * pphi)[None, :]
+                ga_ = (u * a).sum(1)
+                gp_ = eta * w * pphi
+                acc["s"] += np.abs(np.stack([(ga_ - gp_) * s[1] / T ** 2, (gp_ - ga_) * s[0] / T ** 2]))
+            out["scales"] = acc
+        return out
 
 
 def data_term(X, eta, xi_global, scale_rows, u, v, w, s):

@@ -131,3 +131,40 @@ int spx_data_term(int64_t B, int32_t D, int32_t K, const int32_t* row_ptr, const
   out_scalars[3] = lgs;
   return 0;
 }
+
+/* The yardstick of an entry-wise gradient comparison (oracle/spmf_oracle.py
+ * energy_grad_scales, data pieces): d/dA' of the three additive pieces of the data term
+ * SEPARATELY, from the z / gz rows spx_data_term left:
+ *   stored-cell piece  sum_nnz x log r :  gA'_pos_d = sum_b x xi_b (gz_b + sum_d V'_d + z_b)
+ *   z prior           -sum z^2 / 2     :  gA'_zp_d  = -sum_b x xi_b z_b
+ *   minus-rate piece  -sum_all r       :  gA'_neg_d = -(sum_b x xi_b) sum_d V'_d  -> sxx_d returned
+ * (the pieces of gV' and gphi need no sweep: stored part = spx_data_term's raw gVp / gphi,
+ * rate part = -sum_b z_b and -B.)  veta[K] = sum_d V'_d. */
+int spx_grad_pieces(int64_t B, int32_t D, int32_t K, const int32_t* csc_ptr, const int32_t* csc_row,
+                    const double* csc_val, const double* xi, const double* z, const double* gz,
+                    const double* veta, double* gA_pos, double* gA_zp, double* sxx) {
+  if (B < 0 || D < 1 || K < 1 || K > 256) return -1;
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int32_t d = 0; d < D; ++d) {
+    double gp[256], gq[256];
+    for (int k = 0; k < K; ++k) gp[k] = gq[k] = 0.0;
+    double sx = 0.0;
+    for (int32_t e = csc_ptr[d]; e < csc_ptr[d + 1]; ++e) {
+      const int64_t b = csc_row[e];
+      const double xx = csc_val[e] * (xi ? xi[b] : 1.0);
+      const double* zb = z + (size_t)b * K;
+      const double* gb = gz + (size_t)b * K;
+      for (int k = 0; k < K; ++k) {
+        gp[k] += xx * (gb[k] + veta[k] + zb[k]);
+        gq[k] -= xx * zb[k];
+      }
+      sx += xx;
+    }
+    for (int k = 0; k < K; ++k) {
+      gA_pos[(size_t)d * K + k] = gp[k];
+      gA_zp[(size_t)d * K + k] = gq[k];
+    }
+    sxx[d] = sx;
+  }
+  return 0;
+}

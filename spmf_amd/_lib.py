@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPMF_LIB_PATH") or os.path.join(_HERE, "libspmf_hip.so")
 
 NVARS = 12
+ABI_VERSION = 3          # include/spmf_hip.h SPMF_ABI_VERSION
 VI_STATE_LEN = 16
 NPARTS = 14
 #: variable order of the C-ABI = the reference's var_list (poisson.py:403-539,572)
@@ -48,7 +49,7 @@ class CountsStruct(C.Structure):
         ("item_ptr", C.c_void_p), ("items", C.c_void_p),
         ("max_items_per_panel", C.c_int32), ("pc_pad", C.c_int32),
         ("item_mid", C.c_void_p), ("col_split", C.c_int32),
-        ("max_items_half", C.c_int32 * 2), ("reserved2_", C.c_int32),
+        ("max_items_half", C.c_int32 * 2), ("struct_size", C.c_int32),
         ("ent", C.c_void_p), ("pc_ent", C.c_void_p),
     ]
 
@@ -158,6 +159,9 @@ def load():
         fn = getattr(lib, name)        # AttributeError -> missing export
         fn.restype = res
         fn.argtypes = args
+    if lib.spmf_version() != ABI_VERSION:
+        raise SpmfError(f"{LIB_PATH} has ABI version {lib.spmf_version()}, this binding is written "
+                        f"for {ABI_VERSION} (include/spmf_hip.h SPMF_ABI_VERSION): rebuild the library")
     # the ctypes mirrors must have the library's own struct sizes
     for fn, st in ((lib.spmf_sizeof_counts, CountsStruct), (lib.spmf_sizeof_sur_var, SurVar),
                    (lib.spmf_sizeof_adam_var, AdamVar)):

@@ -209,7 +209,7 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
 
 extern "C" {
 
-int spmf_version(void) { return 2; }
+int spmf_version(void) { return SPMF_ABI_VERSION; }
 size_t spmf_sizeof_counts(void) { return sizeof(spmf_counts); }
 size_t spmf_sizeof_sur_var(void) { return sizeof(spmf_sur_var); }
 size_t spmf_sizeof_adam_var(void) { return sizeof(spmf_adam_var); }
@@ -286,6 +286,10 @@ int spmf_ctx_set_bernoulli_columns(spmf_ctx* c, const int32_t* cols, int n) {
 // spmf_nonfinite_patch, spmf_acc_ptr) fail with SPMF_E_WORKSPACE / return NULL instead of
 // touching memory the caller may have freed.
 static void unbind_ws(spmf_ctx* c) {
+  // a prior half still running on the side stream writes per-workgroup partials into the OLD
+  // workspace and the caller's gradients: let it finish before the caller may free / reuse that
+  // memory (torch's caching allocator does not synchronise on free)
+  if (c->prior_pending && c->ev_join) (void)hipEventSynchronize(c->ev_join);
   c->ws_rows = -1;
   c->ws_S = 0;
   c->acc = nullptr;
@@ -408,6 +412,16 @@ int spmf_last_timing(spmf_ctx* c, float* ms5) {
 
 static int check_counts(spmf_ctx* c, const spmf_counts* ct) {
   if (!ct) return fail(c, SPMF_E_ARG, "counts is null");
+  if (ct->struct_size != (int32_t)sizeof(spmf_counts)) {
+    char b[200];
+    snprintf(b, sizeof b, "counts.struct_size is %d, this library's spmf_counts has %zu bytes: the caller was "
+        "built against another spmf_hip.h (ABI version %d)", (int)ct->struct_size, sizeof(spmf_counts),
+        SPMF_ABI_VERSION);
+    return fail(c, SPMF_E_ARG, b);
+  }
+  if (ct->pc_pad < 0) return fail(c, SPMF_E_ARG, "counts.pc_pad must be >= 0");
+  if (ct->pc_ent && ct->panel_rows > 65536) return fail(c, SPMF_E_ARG,
+      "counts.pc_ent packs the row inside its panel into 16 bits: panel_rows must be <= 65536");
   if (ct->n_cols != c->D) return fail(c, SPMF_E_ARG, "counts.n_cols != ctx D");
   if (ct->n_rows < 0 || ct->nnz < 0 || ct->nnz > 2147483647LL) return fail(c, SPMF_E_ARG,
       "counts: bad n_rows/nnz (nnz must fit int32)");
@@ -438,9 +452,9 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
   if (!c || !params || !eta || S < 1) return fail(c, SPMF_E_ARG, "data_pass: bad arguments");
   // likelihood / decoder code of the kernels: 0 Poisson linear, 1 Poisson log_transform, 2 Bernoulli
   const int logt = likelihood_code(c);
-  if (logt == 3 && !c->ctype) return fail(c, SPMF_E_ARG,
-      "mixed likelihood: spmf_ctx_set_column_types was not called");
   int rc = check_counts(c, ct);
+  if (!rc && logt == 3 && !c->ctype) rc = fail(c, SPMF_E_ARG,
+      "mixed likelihood: spmf_ctx_set_column_types was not called");
   if (!rc && lik_exp(logt) && ct->nnz > 0 && (!ct->gval || !ct->pc_gval)) rc = fail(c, SPMF_E_ARG,
       "counts: log_transform needs gval / pc_gval");
   if (rc) return rc;

@@ -101,7 +101,7 @@ class ShardReducer:
     ``comm``: a LibraryComm moves the packed fp32 accumulators with the library's
     own RCCL communicator; without one (default) torch.distributed does."""
 
-    def __init__(self, group=None, comm=None):
+    def __init__(self, group=None, comm=None, overlap_prior=None):
         self.group = group
         self.comm = comm
         self.active = dist.is_initialized() or comm is not None   # also with one rank (exercises the transport)
@@ -111,6 +111,49 @@ class ShardReducer:
         self.lgamma_global = None
         self.dataset_rows = None       # set by reduce_stats
         self.dataset_lgamma = None
+        # the prior half of the finish on the library's side stream, under the collective
+        # (spmf_prior_async): worth its fork/join only when the collective takes time, i.e.
+        # with more than one rank (one rank, measured: the fork/join costs what the 22 us
+        # prior half saves)
+        self.overlap_prior = (self.world > 1) if overlap_prior is None else bool(overlap_prior)
+        self._totals_cache = {}        # id(batch struct) -> (struct, (rows, lgamma)) for batch_totals
+
+    @property
+    def graph_safe(self):
+        """The step's collective may be captured in a hipGraph: spmf_allreduce is a plain
+        stream-ordered ncclAllReduce on the capturing stream.  torch.distributed's own
+        collectives (and the host-staged gloo rehearsal) stay eager."""
+        return self.comm is not None or not self.active
+
+    def sum_(self, acc):
+        """The step's one collective, nothing else (no totals, no host read)."""
+        if self.active:
+            self._sum(acc)
+
+    def batch_totals(self, cs):
+        """Global (rows, lgamma) of the batch this rank's struct `cs` belongs to, reduced ONCE
+        per batch object and remembered: the device-resident training loop (vi.vi_step_dev)
+        asks every step and must not read anything back.  Valid while rank r's i-th batch
+        always meets the same batches of the other ranks (a fixed data factory)."""
+        if self.rows_global is not None:
+            return self.rows_global, self.lgamma_global
+        hit = self._totals_cache.get(id(cs))
+        if hit is None or hit[0] is not cs:
+            if len(self._totals_cache) > 4096:
+                self._totals_cache.clear()
+            hit = (cs, self.totals(cs.n_rows, cs.lgamma_sum))
+            self._totals_cache[id(cs)] = hit
+        return hit[1]
+
+    def share_int(self, value):
+        """Rank 0's non-negative integer (< 2**63) on every rank, moved in float32-exact
+        21-bit pieces through gather_scalar (any transport that can sum)."""
+        value = int(value)
+        out = 0
+        for i in range(3):
+            piece = (value >> (21 * i)) & ((1 << 21) - 1)
+            out |= int(self.gather_scalar(float(piece))[0]) << (21 * i)
+        return out
 
     def reduce_stats(self, colsum, colnnz, rows, lgamma_sum, full_batch=False):
         """compute_scales' one-time reduction (poisson.py:118-135 across

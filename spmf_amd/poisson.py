@@ -407,9 +407,12 @@ class PoissonFactorization:
         if all_reduce is not None and not split:
             # the prior half of the finish reads no accumulator: it runs on the
             # library's side stream while the collective has the GPU mostly idle
-            # (beside the sparse passes it costs them more than it hides: measured)
-            _lib.check(h, lib.spmf_prior_async(h, S, float(prior_weight), pin, eta.data_ptr(),
-                                               parts.data_ptr(), gout, stream), "spmf_prior_async")
+            # (beside the sparse passes it costs them more than it hides: measured).
+            # The reducer decides (ShardReducer.overlap_prior: on with more than one rank;
+            # with one rank the fork/join costs what the prior half would save)
+            if getattr(all_reduce, "overlap_prior", True):
+                _lib.check(h, lib.spmf_prior_async(h, S, float(prior_weight), pin, eta.data_ptr(),
+                                                   parts.data_ptr(), gout, stream), "spmf_prior_async")
             n = lib.spmf_acc_len(h, S)
             acc = _wrap_f32(lib.spmf_acc_ptr(h), n, self.device, self._ws)
             r = all_reduce(acc, cs.n_rows, cs.lgamma_sum)

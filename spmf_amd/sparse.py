@@ -17,6 +17,7 @@ per-row statistics come from the HIP pre-pass kernel ``spmf_counts_stats``.
 from __future__ import annotations
 
 
+import ctypes as C
 import os
 
 import numpy as np
@@ -313,6 +314,7 @@ class SparseCounts:
         r0 = p0 * self.panel_rows
         r1 = min(p1 * self.panel_rows, self.n_rows)
         cs = _lib.CountsStruct()
+        cs.struct_size = C.sizeof(_lib.CountsStruct)      # ABI guard, verified by the library
         cs.n_rows = r1 - r0
         lo = int(self.row_ptr[r0]) if self.nnz else 0
         hi = int(self.row_ptr[r1]) if self.nnz else 0

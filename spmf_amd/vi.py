@@ -354,12 +354,40 @@ def elbo_step(model, batch, dataset_rows, sample_size, all_reduce=None, nonfinit
     return loss, grads, nnf
 
 
+class _StepReducer:
+    """all_reduce hook of ONE device-resident step over row shards: sums the packed
+    accumulators through the reducer's transport and answers the batch totals from values
+    the host already holds, so the step reads nothing back (and, with the library's RCCL
+    communicator, is a fixed stream-ordered launch sequence a hipGraph can hold)."""
+
+    def __init__(self, red, totals):
+        self.red, self._tot = red, totals
+        self.overlap_prior = getattr(red, "overlap_prior", True)
+
+    def __call__(self, acc, rows, lgamma_sum):
+        self.red.sum_(acc)
+        return self._tot
+
+    def totals(self, rows, lgamma_sum):
+        return self._tot
+
+
 @torch.no_grad()
-def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=None):
+def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=None,
+                all_reduce=None):
     """One whole VI step with no host read-back: noise, surrogate, energy +
     gradient, loss/skip decision (spmf_vi_gate), chain rule, gated Adam
     (spmf_adam_step_dev).  The launch sequence depends only on the batch
-    object, so it can be captured in a hipGraph (StepRunner)."""
+    object, so it can be captured in a hipGraph (StepRunner).
+
+    ``all_reduce``: a dist.ShardReducer when ``batch`` is this rank's row shard of the
+    step's batch (poisson.py:60,72 `strategy` is the reference's only hook).
+    The data pass runs on the shard, the packed accumulators go through the reducer's ONE
+    sum all-reduce, and everything after it -- finish, gate, chain rule, Adam -- runs
+    redundantly on the all-reduced values with the batch's GLOBAL row count, so every rank
+    takes the same decision and applies the same update.  The global totals come from
+    ``ShardReducer.batch_totals`` (reduced once per batch object, on the host); the step
+    itself reads nothing back."""
     lib, h = _lib.load(), model._handle()
     sur = model.surrogate_distribution
     S = int(sample_size)
@@ -368,9 +396,17 @@ def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=No
     noise = sur.draw_noise(S, seed=seed, state=opt.state if seed is not None else None)
     theta, logq = sur.forward_hip(model, S, noise)
     sc, cs = model._batch(batch)
+    hook = None
     B = cs.n_rows
+    if all_reduce is not None:
+        if not hasattr(all_reduce, "batch_totals"):
+            raise ValueError("the device-resident sharded step needs a dist.ShardReducer "
+                             "(batch_totals / sum_); other hooks run through elbo_step")
+        tot = all_reduce.batch_totals(cs)
+        B = int(tot[0])
+        hook = _StepReducer(all_reduce, (B, float(tot[1])))
     c = float(B) / float(dataset_rows)
-    parts, g, nnf = model.energy_and_grads(batch, theta, prior_weight=c)
+    parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=hook, prior_weight=c)
     stream = torch.cuda.current_stream(sur.device).cuda_stream
     _lib.check(h, lib.spmf_vi_gate(h, model._last_parts.data_ptr(), logq.data_ptr(),
                                    nnf.data_ptr(), S, c, float(B), opt.state.data_ptr(), stream),
@@ -393,10 +429,16 @@ class StepRunner:
     batches are launch-bound (about 40 launches per step), which is what the
     graph removes; large ones lose nothing."""
 
-    def __init__(self, model, opt, dataset_rows, sample_size, use_graph=True, max_graphs=64):
+    def __init__(self, model, opt, dataset_rows, sample_size, use_graph=True, max_graphs=64,
+                 all_reduce=None, seed=None):
         self.model, self.opt = model, opt
         self.dataset_rows, self.S = dataset_rows, int(sample_size)
-        self.use_graph = bool(use_graph)
+        self.all_reduce = all_reduce
+        # row shards: the collective is captured only when it is the library's own
+        # stream-ordered ncclAllReduce (dist.LibraryComm); torch.distributed's collectives
+        # and the host-staged gloo rehearsal run the same device-gated step eagerly
+        self.use_graph = bool(use_graph) and (all_reduce is None or
+                                              bool(getattr(all_reduce, "graph_safe", False)))
         self.max_graphs = max_graphs
         self.graphs = {}           # key -> (graph, workspace ptr, pinned refs)
         self.seen = {}
@@ -404,8 +446,12 @@ class StepRunner:
         self.replays = 0
         self.keep_tensors = False  # tests: keep the captured step's tensors
         self.kept = {}
-        # Philox key of this runner's noise; the per-step variation is the device counter
-        self.seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+        # Philox key of this runner's noise; the per-step variation is the device counter.
+        # Row shards replicate the surrogate, so every rank must draw the SAME noise: rank
+        # 0's key goes to the others through the reducer
+        self.seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)) if seed is None else int(seed)
+        if all_reduce is not None and hasattr(all_reduce, "share_int"):
+            self.seed = all_reduce.share_int(self.seed)
 
     def _key(self, batch):
         sc, cs = self.model._batch(batch)
@@ -413,7 +459,8 @@ class StepRunner:
 
     def step(self, batch):
         if not self.use_graph:
-            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, seed=self.seed)
+            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, seed=self.seed,
+                        all_reduce=self.all_reduce)
             return
         key, cs = self._key(batch)
         hit = self.graphs.get(key)
@@ -426,7 +473,8 @@ class StepRunner:
             del self.graphs[key]
         if self.seen.get(key) is not cs or ws == 0:
             # first sight: eager (also the warm-up that sizes the workspace)
-            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, seed=self.seed)
+            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, seed=self.seed,
+                        all_reduce=self.all_reduce)
             if len(self.seen) > 4 * self.max_graphs:
                 self.seen.clear()
             self.seen[key] = cs
@@ -447,7 +495,7 @@ class StepRunner:
         try:
             with torch.cuda.graph(graph, pool=self.pool):
                 vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, keep=keep,
-                            seed=self.seed)
+                            seed=self.seed, all_reduce=self.all_reduce)
         finally:
             if gc_was_on:
                 gc.enable()
@@ -525,13 +573,16 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
     epochs = num_epochs if num_epochs is not None else num_steps
     losses, best_state = [], None
     ctl = PlateauController(learning_rate, rel_tol, abs_tol, max_decay_steps, lr_decay_factor)
-    # (custom encoder/decoder callables run torch autograd inside the step: eager loop)
-    device_loop = all_reduce is None and getattr(model, "_custom_codec", None) is None
+    # (custom encoder/decoder callables run torch autograd inside the step: eager loop; so does
+    #  a foreign all_reduce hook, which only knows how to sum the accumulators)
+    device_loop = getattr(model, "_custom_codec", None) is None and (
+        all_reduce is None or hasattr(all_reduce, "batch_totals"))
     sync_every = int(kwargs.get("sync_every", 200))
+    since_sync = 0
     if device_loop:
         opt.init_state(clip_value)
         runner = StepRunner(model, opt, dataset_size, sample_size,
-                            use_graph=kwargs.get("use_graph", True))
+                            use_graph=kwargs.get("use_graph", True), all_reduce=all_reduce)
     for ep in range(epochs):
         tot, nb, ep_sat = 0.0, 0, 0.0
         if device_loop:
@@ -545,6 +596,12 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
             ep_sat = st[14]
             if verbose and skipped:
                 print(f"Batch loss NaN, skipping ({skipped} batches)")
+            # row shards: the replicas took the same decisions on the same all-reduced
+            # values; the guard re-broadcast of the eager loop, at epoch boundaries
+            since_sync += nb
+            if sync_every and since_sync >= sync_every and hasattr(all_reduce, "sync_replicas"):
+                all_reduce.sync_replicas(list(sur.trainable_variables) + opt.m + opt.v)
+                since_sync = 0
             if skipped:
                 # the device-gated loop cannot apply the replacement rule (it needs a
                 # host decision); from here on run the eager loop, which trains THROUGH

@@ -15,7 +15,7 @@ for name, (res, args) in _lib.SIGNATURES.items():
     fn = getattr(lib, name)
     fn.restype, fn.argtypes = res, args
 
-assert lib.spmf_version() == 2 and lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct)
+assert lib.spmf_version() == 3 and lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct)
 h = C.c_void_p()
 assert lib.spmf_ctx_create(0, 100, 10, 0, C.byref(h)) == -1
 assert lib.spmf_ctx_create(0, 0, 10, 0, C.byref(h)) == -1
@@ -44,6 +44,10 @@ for flags in (0, 1, 2 | 1, 4, 4 | 2, 8, 16 | 1):
         cs = _lib.CountsStruct()
         cs.n_cols = 999
         P = _lib.PtrArray()
+        # ABI guard: a struct from a caller built against another header is refused first
+        assert lib.spmf_data_pass(h, C.byref(cs), 1, P, 4096, None) == -1
+        assert b"struct_size" in lib.spmf_last_error(h)
+        cs.struct_size = C.sizeof(_lib.CountsStruct)
         assert lib.spmf_data_pass(h, C.byref(cs), 1, P, None, None) == -1
         assert lib.spmf_data_pass(h, None, 1, P, 4096, None) != 0
         assert lib.spmf_finish(h, 1, 10, 0.0, 1.0, P, 4096, 4096, P, None, None) == -1

@@ -93,6 +93,66 @@ def test_c2_batch_20000x5000_K16_vs_sparse_exact():
         np.testing.assert_allclose(ref["grads"][k], dref["grads"][k][0], rtol=1e-9,
                                    atol=1e-12 * np.abs(dref["grads"][k]).max())
     _close_grads({k: v[0] for k, v in grads.items()}, tot, scales, tag="c2")
+    # the OpenMP C port (the checker of the full-shard C3 test and of bench.py's
+    # parity_vs_port) on the same batch: its gradient and ITS yardstick are the dense
+    # oracle's, and the HIP gradients hold 1e-5 entry by entry against it too
+    from oracle import sparse_exact_c as SC
+    cref = SC.Prepared(X, eta, float(m.xi_u_global), True).step(one["u"], one["v"], one["w"], one["s"],
+                                                                 scales=True)
+    for k in ("u", "v", "w", "s"):
+        np.testing.assert_allclose(cref["scales"][k], dref["scales"][k][0], rtol=1e-9, err_msg=k)
+        np.testing.assert_allclose(cref["grads"][k], dref["grads"][k][0], rtol=1e-9,
+                                   atol=1e-12 * np.abs(dref["grads"][k]).max())
+    _close_grads({k: v[0] for k, v in grads.items()},
+                 {k: pg[k] + cref["grads"].get(k, 0.0) for k in pg},
+                 {k: psc[k][0] + (cref["scales"][k] if k in cref["scales"] else 0.0) for k in pg},
+                 tag="c2 vs omp port")
+
+
+@pytest.mark.timeout(900)
+def test_c3_shard_entrywise_vs_openmp_port():
+    """The headline config at the size of one of its row shards: 125 000 rows x 20 000 of the C3
+    generator (the per-GPU shard of the 8-GPU configuration, 1.25e7 stored entries, K = 32)
+    through the HIP path against the fp64 OpenMP port -- 'x', 'z' to 1e-5 and ALL gradients entry
+    by entry to 1e-5 of the port's yardstick (sum of |contributions| per entry, pinned to
+    oracle.energy_grad_scales in tests/test_oracle.py and on C2 above), the norm-wise bound too."""
+    from oracle import sparse_exact_c as SC
+    from spmf_amd import PoissonFactorization, synth
+    from _chunked_oracle import prior_scales
+    dev = torch.device("cuda")
+    N, n, D, K = 1_000_000, 125_000, 20_000, 32
+    sc = synth.linear_structure(n, D, 0.005, dev)
+    assert 1.1e7 < sc.nnz < 1.4e7
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(N * D), device=dev)
+    m.compute_scales(lambda: [{"counts": sc}])
+    eta = m._eta_device().double().cpu().numpy()
+    X = _csr_of(sc)
+    prep = SC.Prepared(X, eta, float(m.xi_u_global), True)
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, u_tau_scale=m.u_tau_scale)
+    cfg.eta_i = torch.as_tensor(eta).reshape(1, D)
+    cfg.xi_u_global = float(m.xi_u_global)
+    torch.manual_seed(11)
+    for scale in (1.0, 20.0):      # the surrogate's initial point (what bench.py times), and away from it
+        params = m.surrogate_distribution.sample(1)
+        params["u"] = params["u"] * scale
+        params["v"] = params["v"] * scale
+        parts, grads, nnf = m.energy_and_grads({"counts": sc}, params)
+        assert float(nnf.sum()) == 0
+        one = {k: v[0].double().cpu().numpy() for k, v in params.items()}
+        ref = prep.step(one["u"], one["v"], one["w"], one["s"], scales=True)
+        assert ref["n_nonfinite"] == 0
+        np.testing.assert_allclose(parts["x"][0].item(), ref["x"], rtol=1e-5)
+        np.testing.assert_allclose(parts["z"][0].item(), ref["z"], rtol=1e-5)
+        pparts, pg = SE.prior_term(one, m.u_tau_scale, m.s_tau_scale, m.symmetry_breaking_decay ** np.arange(K))
+        for k, r in pparts.items():
+            np.testing.assert_allclose(parts[k][0].item(), r, rtol=1e-5, err_msg=k)
+        psc = prior_scales(cfg, {k: v.double().cpu().numpy() for k, v in params.items()})
+        tot = {k: pg[k] + ref["grads"].get(k, 0.0) for k in pg}
+        scales = {k: psc[k][0] + (ref["scales"][k] if k in ref["scales"] else 0.0) for k in pg}
+        _close_grads({k: v[0] for k, v in grads.items()}, tot, scales, tag=f"c3 shard x{scale}")
+        for k in ("u", "v", "w", "s"):     # the array-norm bound of rounds 1-2 holds as well
+            a, b = grads[k][0].double().cpu().numpy().reshape(tot[k].shape), tot[k]
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), k
 
 
 @pytest.mark.timeout(600)

@@ -407,6 +407,71 @@ def test_fit_with_and_without_graph_agree():
     assert np.mean(b[-3:]) < b[0] - 0.5
 
 
+def test_sharded_device_loop_one_rank_rccl_graph_replay_equals_unsharded():
+    """The row-sharded VI step ON THE DEVICE (vi.vi_step_dev with a ShardReducer): data pass on
+    the shard, spmf_allreduce through the library's RCCL communicator, finish / gate / chain rule /
+    Adam on the all-reduced values -- captured in a hipGraph and replayed (the collective is a
+    plain stream-ordered ncclAllReduce).  With one rank the sum is the identity, so the run must
+    reproduce the unsharded device loop on the same Philox key, step for step, and must never go
+    through the host-driven elbo_step."""
+    from spmf_amd import SparseCounts, vi
+    from spmf_amd.dist import LibraryComm, ShardReducer
+    X = _data()
+    N, D = X.shape
+    sc = SparseCounts.from_any(X, "cuda", 100)
+    batches = [{"counts": sc, "panels": (p, p + 2)} for p in range(0, sc.n_panels, 2)]
+
+    def run(reducer_of, use_graph, forked=None):
+        m = _fresh_model(X)
+        red = reducer_of(m)
+        if red is not None and forked is not None:
+            red.overlap_prior = forked
+        opt = vi.AdamHIP(m, m.surrogate_distribution.trainable_variables, 0.05)
+        opt.init_state(10.0)
+        r = vi.StepRunner(m, opt, N, 2, use_graph=use_graph, all_reduce=red, seed=4242)
+        losses = []
+        for ep in range(4):
+            for b in batches:
+                r.step(b)
+                losses.append(opt.read_state()[8])
+        st = opt.read_state()
+        assert st[7] == 4 * len(batches) and st[12] == 0
+        return losses, [p.detach().clone() for p in m.surrogate_distribution.trainable_variables], r
+
+    base, pb, _ = run(lambda m: None, True)
+    for forked in (False, True):       # prior half inline / forked to the side stream under the collective
+        got, pg, r = run(lambda m: ShardReducer(comm=LibraryComm(m, rank=0, world=1)), True, forked)
+        assert r.use_graph and len(r.graphs) == len(batches) and r.replays == 3 * len(batches)
+        np.testing.assert_allclose(got, base, rtol=2e-6)
+        for a, b in zip(pg, pb):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1e-30, float(b.abs().max()))
+    # a reducer without the library communicator (torch.distributed / gloo transport): the same
+    # device-gated step, eagerly
+    got, pg, r = run(lambda m: ShardReducer(), False)
+    np.testing.assert_allclose(got, base, rtol=2e-6)
+
+
+def test_sharded_fit_stays_on_the_device_loop(monkeypatch):
+    """fit(all_reduce=ShardReducer) takes the device-resident loop (no per-step host read-back):
+    the host-driven elbo_step is never called; a foreign hook still takes the eager loop."""
+    from spmf_amd import vi
+    from spmf_amd.dist import LibraryComm, ShardReducer
+    X = _data(300, 18)
+    N = X.shape[0]
+    m = _fresh_model(X)
+    calls = []
+    real = vi.elbo_step
+    monkeypatch.setattr(vi, "elbo_step", lambda *a, **k: calls.append(1) or real(*a, **k))
+    red = ShardReducer(comm=LibraryComm(m, rank=0, world=1))
+    losses = m.fit(lambda: [{"counts": X}], dataset_size=N, sample_size=2, num_steps=6,
+                   learning_rate=0.05, rel_tol=1e-12, verbose=False, all_reduce=red)
+    assert len(losses) == 6 and not calls and all(np.isfinite(losses))
+    m2 = _fresh_model(X)
+    m2.fit(lambda: [{"counts": X}], dataset_size=N, sample_size=2, num_steps=2, learning_rate=0.05,
+           rel_tol=1e-12, verbose=False, all_reduce=lambda acc, rows, lg: None)
+    assert len(calls) == 2
+
+
 def test_checkpoint_roundtrip(tmp_path):
     """factor.save -> pickle -> reconstitute BY POSITION (poisson.py:711-717):
     the restored model encodes identically."""

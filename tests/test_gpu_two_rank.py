@@ -67,6 +67,13 @@ def _worker(rank, world, port, q):
     sync_seed(78)
     loss, g, _ = elbo_step(m, {"counts": sc}, rows_g, 2, all_reduce=red)
     sync_seed(79)
+    # the sharded fit is the device-resident loop (vi.vi_step_dev with the reducer; gloo: eager,
+    # no hipGraph); the host-driven step must not be what runs
+    from spmf_amd import vi as _vi
+
+    def _no_host_step(*a, **k):
+        raise AssertionError("fit(all_reduce=ShardReducer) fell back to the host-driven elbo_step")
+    _vi.elbo_step = _no_host_step
     losses = m.fit(lambda: [{"counts": sc}], dataset_size=rows_g, sample_size=2, num_steps=4,
                    learning_rate=0.02, rel_tol=1e-12, verbose=False, all_reduce=red, sync_every=2)
     drift = red.replicas_max_abs_diff(m.surrogate_distribution.trainable_variables)
@@ -115,7 +122,8 @@ def test_two_rank_sharded_energy_step_and_fit_equal_single_process():
         assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-30)
     torch.manual_seed(79)
     from spmf_amd.dist import ShardReducer
-    # an inactive reducer (no process group): the same eager loop the shards ran
+    # an inactive reducer (no process group): the same device-resident loop the shards ran, on
+    # the whole matrix (here replayed from a hipGraph; the Philox key is drawn the same way)
     losses = m.fit(lambda: [{"counts": X}], dataset_size=N, sample_size=2, num_steps=4,
                    learning_rate=0.02, rel_tol=1e-12, verbose=False, all_reduce=ShardReducer())
     assert len(res["losses"]) == len(losses) == 4

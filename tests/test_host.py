@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.spmf_version() == 2
+    assert lib.spmf_version() == 3 and 'define SPMF_ABI_VERSION 3' in hdr
 
 
 def test_library_exports_only_the_c_abi(lib):
@@ -79,6 +79,35 @@ def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
     assert lib.spmf_ctx_create(0, 3, 10, 0, C.byref(h3)) == 0
     assert lib.spmf_padded_k(h3) == 4
     lib.spmf_ctx_destroy(h3)
+
+
+def test_counts_struct_abi_guard_rejects_foreign_layouts(lib):
+    """spmf_counts grew fields without a version signal.  Since ABI version 3
+    every entry point that takes the struct refuses one whose struct_size is not the library's own
+    sizeof (a caller compiled against the shorter layout, or one that never initialised the former
+    reserved slot), a negative pc_pad, and a packed list stream with panels too tall for 16 bits
+    -- all on the host, before anything touches the device."""
+    from spmf_amd import _lib
+    h = C.c_void_p()
+    assert lib.spmf_ctx_create(0, 8, 100, 1, C.byref(h)) == 0
+    P = _lib.PtrArray()
+    cs = _lib.CountsStruct()
+    cs.n_cols, cs.n_rows = 100, 4
+    for bad in (0, 160, 184):                      # zero-initialised, the round-2 layout, a longer one
+        cs.struct_size = bad
+        assert lib.spmf_data_pass(h, C.byref(cs), 1, P, 4096, None) == -1
+        assert b"struct_size" in lib.spmf_last_error(h) and b"another spmf_hip.h" in lib.spmf_last_error(h)
+        assert lib.spmf_encode(h, C.byref(cs), 4096, 4096, 4096, 4096, None) == -1
+        assert b"struct_size" in lib.spmf_last_error(h)
+    cs.struct_size = C.sizeof(_lib.CountsStruct)
+    cs.pc_pad = -1
+    assert lib.spmf_data_pass(h, C.byref(cs), 1, P, 4096, None) == -1
+    assert b"pc_pad" in lib.spmf_last_error(h)
+    cs.pc_pad = 64
+    cs.pc_ent, cs.panel_rows = 4096, 70000
+    assert lib.spmf_data_pass(h, C.byref(cs), 1, P, 4096, None) == -1
+    assert b"panel_rows must be <= 65536" in lib.spmf_last_error(h)
+    lib.spmf_ctx_destroy(h)
 
 
 def test_counts_struct_layout_matches_header():

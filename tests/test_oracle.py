@@ -328,6 +328,34 @@ def test_c_port_equals_numpy_port():
     assert SC.max_threads() >= 1
 
 
+@pytest.mark.parametrize("scale_rows", [True, False])
+def test_c_port_yardstick_equals_oracle_energy_grad_scales(scale_rows):
+    """The OpenMP port's entry-wise yardstick (Prepared.step(scales=True): per entry the sum over
+    the stored-cell, minus-rate and z-prior pieces of |d piece / d entry|) is the data part of
+    oracle.energy_grad_scales -- the metric the full-shard C2 / C3 parity tests and bench.py's
+    parity_vs_port hold the HIP gradients to.  Includes empty rows and an empty column."""
+    from oracle import sparse_exact_c as SC
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    B, D, K = 57, 23, 4
+    x = ((rng.random((B, D)) < 0.2) * (1 + rng.poisson(2.0, size=(B, D)))).astype(np.float64)
+    x[4] = 0
+    x[:, 7] = 0
+    cfg = O.OracleConfig(latent_dim=K, feature_dim=D, u_tau_scale=1 / math.sqrt(B * D),
+                         scale_rows=scale_rows)
+    cfg.eta_i = torch.as_tensor(rng.uniform(0.5, 3.0, size=(1, D)))
+    cfg.xi_u_global = 3.3
+    params = O.random_params(cfg, 1, 22)
+    ref = O.energy_grad_scales(cfg, x, params, prior=False)
+    one = {k: np.asarray(v)[0] for k, v in params.items()}
+    out = SC.Prepared(sp.csr_matrix(x), cfg.eta_i.numpy().reshape(-1), cfg.xi_u_global,
+                      scale_rows).step(one["u"], one["v"], one["w"], one["s"], scales=True)
+    for k in ("u", "v", "w", "s"):
+        np.testing.assert_allclose(out["scales"][k], ref[k][0].numpy(), rtol=1e-11, atol=1e-300, err_msg=k)
+        # and it dominates the gradient it measures
+        assert (np.abs(out["grads"][k]) <= out["scales"][k] * (1 + 1e-12) + 1e-300).all(), k
+
+
 def test_horseshoe_log_prob_restates_tfp_approximation_close_to_the_exact_density():
     """tfd.Horseshoe.log_prob is a closed-form approximation; the restatement in the
     oracle must sit within its known accuracy (< 1e-3 nats) of the exact
