@@ -175,9 +175,36 @@ static int64_t est_chunk_rows(const spmf_ctx* c, int64_t rows) {
 static bool uses_dense3(const spmf_ctx* c) {
   return c->dense3 && likelihood_code(c) == 1 && c->KP == 64;
 }
+// The bf16x3 form of the sigmoid / softplus sums (dense3.hip sigdot3: Bernoulli and mixed contexts with the
+// linear decoder) at KP = 32; it recomputes the sigmoid in its second launch too.
+static bool uses_sig3(const spmf_ctx* c) {
+  const int lik = likelihood_code(c);
+  return c->dense3 && (lik == 2 || lik == 3) && c->KP == 32;
+}
 static bool uses_e_buffer(const spmf_ctx* c) {
   return (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once &&
-         likelihood_code(c) != 4 && !uses_dense3(c);
+         likelihood_code(c) != 4 && !uses_dense3(c) && !uses_sig3(c);
+}
+
+// Q chunks (gridDim.y) of a P-stationary dense launch of nbx workgroup columns over ntiles Q tiles on
+// `slots` resident workgroups: the count that fills whole rounds of the chip best, charging every
+// workgroup a fixed prologue (P fragments, first tile) of about 0.7 tile-times.
+static int pick_chunks(int nbx, int ntiles, int slots, int max_chunks) {
+  int best = 1;
+  double best_eff = -1.0;
+  for (int c = 1; c <= ntiles && c <= max_chunks; ++c) {
+    const int tpc = (ntiles + c - 1) / c;
+    if ((ntiles + tpc - 1) / tpc != c) continue;          // some chunk would get no tile
+    const long n = (long)nbx * c;
+    const long rounds = (n + slots - 1) / slots;
+    const double eff = ((double)n / (double)(rounds * slots)) * ((double)ntiles / ((double)c * tpc)) *
+                       ((double)tpc / (tpc + 0.7));
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = c;
+    }
+  }
+  return best;
 }
 
 static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
@@ -548,6 +575,21 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr,
             nullptr};
         launch_expdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+      } else if (uses_sig3(c)) {
+        // bf16x3 sigmoid form: (Z, W) with the column bias on the Q rows, then (W, Z) with it on the P
+        // rows; the sigmoid is recomputed (8 GB of E traffic per step on C5 cost more than that).
+        // Two waves per SIMD by registers: chunk counts that fill whole rounds of the resident workgroups.
+        const int zt = (Dd + 127) / 128, wt = (int)((ct->n_rows + 127) / 128);
+        const int rpw = sigdot3_rows_per_wg(), slots = 256 * sigdot3_wgs_per_cu();
+        const int znb = (int)((ct->n_rows + rpw - 1) / rpw), wnb = (Dd + rpw - 1) / rpw;
+        const int zc = pick_chunks(znb, zt, slots, 16), wc = pick_chunks(wnb, wt, slots, 256);
+        if (zc > 1) launch_zero(c->gzd, (size_t)ct->n_rows * KP * sizeof(float), st);
+        ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, zc, zc > 1 ? 1 : 0, 1, nullptr, lbias,
+            nullptr, nullptr};
+        ez.e_planes = 3;              // V' rows have mixed signs under the Normal priors: third plane of E
+        launch_sigdot3(KP, ez, st);   // gzd_b = sum_d sigmoid(l_bd) V'_d ; dacc[3] = sum softplus
+        ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 1, lbias, nullptr, gphi_acc, orows};
+        launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b sigmoid z_b ; gphi_d -= sum_b sigmoid
       } else if (c->est && act != 2) {   // (act 2: E carries exp(X) too, its row sums are not the d/dphi sums)
         // E once: per row chunk, the Z-stationary kernel keeps E (exp, or the sigmoid of the
         // Bernoulli logits) and the second contraction (gV'_d -= sum_b E_bd z_b; Bernoulli:

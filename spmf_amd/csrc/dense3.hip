@@ -340,6 +340,387 @@ __global__ __launch_bounds__(512, 2) void expdot3_kernel(int NP, int NQ, const f
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// sigdot3: the Bernoulli / mixed dense sums (dense.hip ACT 1; mederrata_spmf/bernoulli.py:127-155:
+// ll = x l - softplus(l), l = <z_b, V'_d> + phi_d) on the same bf16x3 operands:
+//     out_p[k] = sum_q sigmoid(l_pq) Q_q[k],   esum = sum softplus(l_pq),   out2[p] = sum_q sigmoid(l_pq)
+// launched as (Z, W) with the column bias on the Q rows and as (W, Z) with it on the P rows; the
+// sigmoid is recomputed in the second launch (keeping it costs a B*D*4-byte write and read: 8 GB per
+// step on C5, more than the second launch's whole time).  KD = 32 or 64.
+// Differences from expdot3: (i) the bias rides in the accumulator's initial value, and ONE fp32
+// accumulator takes all six partial products of a step (the logits are O(10): no large-exponent
+// regime whose absolute error a second accumulator would have to protect -- d sigmoid = s(1-s) dX
+// <= dX/4, and the 2*KD/16*6 MFMA adds of the chain are the fmaf chain of the exact-f32 kernel, just
+// shorter); (ii) the epilogue is the one of dense.hip ACT 1 -- sigmoid from one v_exp and one v_rcp,
+// the softplus sum as max(l, 0) plus ONE log2 of the product of a sub-tile's sixteen (1 + e^-|l|)
+// factors -- followed by the two-plane split of E = sigmoid in [0, 1] (|E - e1 - e2| <= 2^-18 E term by
+// term, every term of the sums positive: <= 3.8e-6 of the result in the worst case, unbiased rounding
+// in practice); (iii) the kernel is VALU-bound (about 15 vector issue slots per cell against 22 MFMAs
+// per 1024 cells at KD = 32), so the body is left to the compiler's scheduler: other waves' MFMAs fill
+// the matrix pipe under a wave's epilogue.
+#ifndef SPMF_SIG3_VALU
+#define SPMF_SIG3_VALU 230
+#endif
+constexpr int kSigValu = SPMF_SIG3_VALU;
+// ESUM: this launch owns the softplus sum (part 'x'); CSUM: it owns the sigmoid sums per P row (out2);
+// EPL: bf16 planes of E = sigmoid in the second product.  Two planes leave |dE| <= 2^-18 E per term: fine
+// where every term of the sum has one sign (Q = z rows, z >= 0); where the Q rows have mixed signs (Q =
+// V' under the Normal priors of bernoulli.py:187-216) a sum can cancel to a small fraction of its terms
+// and the entry-wise 1e-5 needs the third plane (2^-26).
+template <int KD, bool EDGE, bool BQ, bool ESUM, bool CSUM, int EPL>
+__device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ img, uint32_t lds_tr_base,
+                                              const float* __restrict__ bq, float bp,
+                                              const bf16x8 (&pb)[KD / 16][3], f32x16 (&acc)[KD / 32],
+                                              float& es_tile, float& colsum, int r, int h, int q0, int NQ,
+                                              bool p_in) {
+  constexpr int KS = KD / 16, MT = KD / 32, NSUB = kQT3 / 32;
+  constexpr int PITCH = KD * 2 + 16;
+  constexpr int IMG = kQT3 * PITCH;
+  f32x16 x[NSUB];
+  u32x4 eb[NSUB][2][EPL];          // [sub][s2][plane]
+  auto productA = [&](int sub) {
+    f32x16 xi;
+    if (BQ) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bq + 32 * sub + 8 * g + 4 * h);
+        xi[4 * g + 0] = b4.x; xi[4 * g + 1] = b4.y; xi[4 * g + 2] = b4.z; xi[4 * g + 3] = b4.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xi[i] = bp;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[pl] = *reinterpret_cast<const bf16x8*>(img + pl * IMG + (32 * sub + r) * PITCH + (16 * s + 8 * h) * 2);
+      xi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], pb[s][0], xi, 0, 0, 0);
+      xi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], pb[s][1], xi, 0, 0, 0);
+      xi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], pb[s][2], xi, 0, 0, 0);
+      xi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], pb[s][0], xi, 0, 0, 0);
+      xi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], pb[s][1], xi, 0, 0, 0);
+      xi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], pb[s][0], xi, 0, 0, 0);
+    }
+    x[sub] = xi;
+  };
+  auto sigsplit = [&](int sub) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    float pm0 = 0.f, pm1 = 0.f, dp0 = 1.f, dp1 = 1.f, cs0 = 0.f, cs1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      float l0 = x[sub][i], l1 = x[sub][i + 1];
+      if (EDGE) {
+        const int qa = q0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
+        l0 = (p_in && qa < NQ) ? l0 : -INFINITY;          // sigmoid -> 0, softplus -> 0
+        l1 = (p_in && qa + 1 < NQ) ? l1 : -INFINITY;
+      }
+      float s0, s1;
+      if (ESUM) {
+        // softplus(l) = max(l, 0) + log(1 + e^-|l|); sigmoid from the same e^-|l|
+        const float en0 = __builtin_amdgcn_exp2f(-fabsf(l0) * kLog2e);      // in (0, 1]
+        const float en1 = __builtin_amdgcn_exp2f(-fabsf(l1) * kLog2e);
+        const float d0 = 1.f + en0, d1 = 1.f + en1;
+        const float i0 = __builtin_amdgcn_rcpf(d0), i1 = __builtin_amdgcn_rcpf(d1);
+        const bool g0 = l0 >= 0.f, g1 = l1 >= 0.f;
+        s0 = (g0 ? 1.f : en0) * i0;
+        s1 = (g1 ? 1.f : en1) * i1;
+        pm0 += g0 ? l0 : 0.f;            // (a select, not fmaxf: no canonicalising v_max in front of it)
+        pm1 += g1 ? l1 : 0.f;
+        dp0 *= d0;
+        dp1 *= d1;
+      } else {
+        // sigmoid(l) = 1 / (1 + e^-l): e^-l overflows to +inf for l < -88 and the reciprocal gives the 0
+        // that sigmoid rounds to there; relative accuracy 2 ulp everywhere else
+        s0 = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-l0 * kLog2e));
+        s1 = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-l1 * kLog2e));
+      }
+      if (CSUM) {
+        cs0 += s0;
+        cs1 += s1;
+      }
+      const uint32_t p1 = pack_bf16(s0, s1);
+      const float r0 = s0 - bf16_lo(p1), r1 = s1 - bf16_hi(p1);
+      const uint32_t p2 = pack_bf16(r0, r1);
+      eb[sub][i >> 3][0][(i & 7) >> 1] = p1;
+      eb[sub][i >> 3][1][(i & 7) >> 1] = p2;
+      if (EPL == 3) eb[sub][i >> 3][EPL - 1][(i & 7) >> 1] = pack_bf16(r0 - bf16_lo(p2), r1 - bf16_hi(p2));
+    }
+    // sum_i log(1 + e^-|l_i|) = ln2 * log2 of the product (eight factors in (1, 2] per partial product)
+    if (ESUM)
+      es_tile += (pm0 + pm1) + 0.69314718056f * (__builtin_amdgcn_logf(dp0) + __builtin_amdgcn_logf(dp1));
+    if (CSUM) colsum += cs0 + cs1;
+  };
+  auto productC = [&](int sub) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const uint32_t ad = lds_tr_base + pl * IMG + (32 * sub + 16 * s2) * PITCH + 32 * m * 2;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(uintptr_t)ad);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(uintptr_t)(ad + 8 * PITCH));
+          const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          a[pl] = __builtin_bit_cast(bf16x8, both);
+        }
+        const bf16x8 e1v = __builtin_bit_cast(bf16x8, eb[sub][s2][0]);
+        const bf16x8 e2v = __builtin_bit_cast(bf16x8, eb[sub][s2][1]);
+        if (EPL == 3)
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], __builtin_bit_cast(bf16x8, eb[sub][s2][EPL - 1]),
+                                                            acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], e2v, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], e1v, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], e2v, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], e1v, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], e1v, acc[m], 0, 0, 0);
+      }
+  };
+  // issue order (one scheduling region, as expdot3_tile): A0 | A1 + E0 | C0 + A2 + E1 | C1 + A3 + E2 |
+  // C2 + E3 | C3 -- the vector work of a sub-tile's epilogue is spread under the MFMAs of the next
+  // sub-tile's first product and the previous one's second (kSigValu ~ vector instructions of one
+  // epilogue; a group that asks for more than there are is simply shorter)
+  constexpr int NA = 6 * KS, NC = (2 * EPL + 1) * 2 * MT;
+  constexpr int NV = ESUM ? kSigValu : (kSigValu * 2) / 3;
+  productA(0);
+  productA(1);
+  sigsplit(0);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, (NV + NA - 1) / NA, 0);
+  }
+  productC(0);
+  productA(2);
+  sigsplit(1);
+#pragma unroll
+  for (int i = 0; i < NA + NC; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, (NV + NA + NC - 1) / (NA + NC), 0);
+  }
+  productC(1);
+  productA(3);
+  sigsplit(2);
+#pragma unroll
+  for (int i = 0; i < NA + NC; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, (NV + NA + NC - 1) / (NA + NC), 0);
+  }
+  productC(2);
+  sigsplit(3);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, (NV + NC - 1) / NC, 0);
+  }
+  productC(3);
+}
+
+#ifndef SPMF_SIG3_WPS
+#define SPMF_SIG3_WPS 2      // waves per SIMD the kernel is compiled for (register budget 512 / WPS)
+#endif
+#ifndef SPMF_SIG3_NW
+#define SPMF_SIG3_NW 4       // waves per workgroup (32 P rows each): two 256-thread workgroups per CU, so a
+                             // workgroup at its per-tile barrier leaves the CU to the other (C5 dense: 1.85 -> 1.52 ms)
+#endif
+constexpr int kSigNW = SPMF_SIG3_NW;
+template <int KD, bool BQ, bool ESUM, bool CSUM, int EPL>
+__global__ __launch_bounds__(kSigNW * 64, SPMF_SIG3_WPS) void sigdot3_kernel(
+    int NP, int NQ, const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ out, float sign,
+    double* __restrict__ esum, int atomic_out, const float* __restrict__ bias, float* __restrict__ out2,
+    const int32_t* __restrict__ out_rows) {
+  static_assert(KD == 32 || KD == 64, "sigdot3: K padded to 32 or 64");
+  constexpr int KS = KD / 16, MT = KD / 32, NW = kSigNW, NT = NW * 64;
+  constexpr int PITCH = KD * 2 + 16;            // bytes per LDS row; 144 (KD 64) / 80 (KD 32): the 16 rows of a
+                                                // ds_read_b128 service group cover all 64 banks
+  constexpr int IMG = kQT3 * PITCH;
+  constexpr int PCS = kQT3 * (KD / 8);          // (row, 8 k) pieces of a tile
+  constexpr int NPC = (PCS + NT - 1) / NT;      // pieces per loader thread
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][IMG];
+  __shared__ __attribute__((aligned(16))) float bqs[2][kQT3];
+  __shared__ double red[16];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int p = (blockIdx.x * NW + wid) * 32 + r;
+  const int ntiles = (NQ + kQT3 - 1) / kQT3;
+  const int tpc = (ntiles + gridDim.y - 1) / gridDim.y;
+  const int tile0 = blockIdx.y * tpc, tile1 = min(ntiles, tile0 + tpc);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&lds[0][0][0];
+  const uint32_t tr_lane = (uint32_t)((((lane & 15) >> 2) + 4 * h) * PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+
+  bf16x8 pb[KS][3];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    float v[8];
+#pragma unroll
+    for (int q4 = 0; q4 < 2; ++q4) {
+      const float4 f = p < NP ? *reinterpret_cast<const float4*>(P + (size_t)p * KD + 16 * s + 8 * h + 4 * q4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[4 * q4 + 0] = f.x; v[4 * q4 + 1] = f.y; v[4 * q4 + 2] = f.z; v[4 * q4 + 3] = f.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const Split3 sp = split3(v[j]);
+      pb[s][0][j] = sp.a; pb[s][1][j] = sp.b; pb[s][2][j] = sp.c;
+    }
+  }
+  const float bp = (!BQ && bias && p < NP) ? bias[p] : 0.f;
+  // two-level accumulation (runs of 4 tiles x 128 = 512 terms per fp32 chain) at KD = 64 only: at KD = 32
+  // the second accumulator set does not fit the 256-register budget of two waves per SIMD, the terms are
+  // sigmoids in [0, 1] and a chain is one Q chunk long (a few thousand terms), like dense.hip's KD = 32 form
+  constexpr int FOLD = 4;
+  constexpr bool TWO = KD == 64;
+  f32x16 acc[MT], tot[TWO ? MT : 1];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc[m][i] = 0.f;
+      if (TWO) tot[m][i] = 0.f;
+    }
+  double es = 0.0;
+  float colsum = 0.f, coltot = 0.f;
+
+  float4 st0[NPC], st1[NPC];
+  float bst = 0.f;
+  auto gload = [&](int tile) {
+    const int q0 = tile * kQT3;
+    if (BQ && t < kQT3) bst = (bias && q0 + t < NQ) ? bias[q0 + t] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int pc = t + NT * j, row = (pc / (KD / 8)) % kQT3, k8 = (pc % (KD / 8)) * 8;
+      const int qr = min(q0 + row, NQ - 1);           // rows past NQ: read the last row, zeroed below
+      const float* src = Q + (size_t)qr * KD + k8;
+      const float keep = q0 + row < NQ ? 1.f : 0.f;
+      const float4 a = *reinterpret_cast<const float4*>(src);
+      const float4 b = *reinterpret_cast<const float4*>(src + 4);
+      st0[j] = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
+      st1[j] = make_float4(b.x * keep, b.y * keep, b.z * keep, b.w * keep);
+    }
+  };
+  auto swrite = [&](int buf) {
+    if (BQ && t < kQT3) bqs[buf][t] = bst;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int pc = t + NT * j, row = (pc / (KD / 8)) % kQT3, k8 = (pc % (KD / 8)) * 8;
+      if (PCS % NT != 0 && pc >= PCS) continue;
+      const float v[8] = {st0[j].x, st0[j].y, st0[j].z, st0[j].w, st1[j].x, st1[j].y, st1[j].z, st1[j].w};
+      u32x4 c3[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x0 = v[2 * e], x1 = v[2 * e + 1];
+        const uint32_t p1 = pack_bf16(x0, x1);
+        x0 -= bf16_lo(p1);
+        x1 -= bf16_hi(p1);
+        const uint32_t p2 = pack_bf16(x0, x1);
+        x0 -= bf16_lo(p2);
+        x1 -= bf16_hi(p2);
+        c3[0][e] = p1; c3[1][e] = p2; c3[2][e] = pack_bf16(x0, x1);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<u32x4*>(&lds[buf][pl][row * PITCH + k8 * 2]) = c3[pl];
+    }
+  };
+
+  if (tile0 < tile1) {
+    gload(tile0);
+    swrite(0);
+  }
+  __syncthreads();
+  const bool p_edge = (int)(blockIdx.x * NW * 32 + NW * 32) > NP;      // block-uniform
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int buf = (tile - tile0) & 1;
+    const bool more = tile + 1 < tile1;                    // block-uniform
+    if (more) gload(tile + 1);                             // lands under this tile's MFMAs
+    const int q0 = tile * kQT3;
+    float es_tile = 0.f;
+    const uint32_t trb = lds0 + buf * 3 * IMG + tr_lane;
+    if (p_edge || q0 + kQT3 > NQ)
+      sigdot3_tile<KD, true, BQ, ESUM, CSUM, EPL>(&lds[buf][0][0], trb, bqs[buf], bp, pb, acc, es_tile, colsum, r, h,
+                                                  q0, NQ, p < NP);
+    else
+      sigdot3_tile<KD, false, BQ, ESUM, CSUM, EPL>(&lds[buf][0][0], trb, bqs[buf], bp, pb, acc, es_tile, colsum, r, h,
+                                                   q0, NQ, true);
+    if (ESUM) es += (double)es_tile;
+    if (((tile - tile0) % FOLD) == FOLD - 1) {             // block-uniform: close the run
+      coltot += colsum;
+      colsum = 0.f;
+      if (TWO) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            tot[m][i] += acc[m][i];
+            acc[m][i] = 0.f;
+          }
+      }
+    }
+    if (more) swrite(buf ^ 1);
+    __syncthreads();
+  }
+  const int prow = (out_rows && p < NP) ? out_rows[p] : p;
+  if (p < NP) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float* dst = out + (size_t)prow * KD + m * 32 + 8 * g4 + 4 * h;
+        float4 v = make_float4(acc[m][4 * g4 + 0], acc[m][4 * g4 + 1], acc[m][4 * g4 + 2], acc[m][4 * g4 + 3]);
+        if (TWO) {
+          v.x += tot[m][4 * g4 + 0]; v.y += tot[m][4 * g4 + 1]; v.z += tot[m][4 * g4 + 2]; v.w += tot[m][4 * g4 + 3];
+        }
+        v.x *= sign; v.y *= sign; v.z *= sign; v.w *= sign;
+        if (atomic_out) {
+          atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        } else {
+          *reinterpret_cast<float4*>(dst) = v;
+        }
+      }
+  }
+  if (CSUM && out2) {
+    float cs = colsum + coltot;
+    cs += __shfl_xor(cs, 32);                         // the two lane halves hold disjoint q rows
+    if (h == 0 && p < NP && cs != 0.f) atomicAdd(&out2[prow], sign * cs);
+  }
+  if (ESUM && esum) {
+    const double tsum = block_sum(es, red);
+    if (t == 0) atomicAdd(esum, tsum);
+  }
+}
+
+// launch geometry for the caller's chunk choice: P rows per workgroup, resident workgroups per CU
+// (two waves per SIMD by registers: 8 waves per CU)
+int sigdot3_rows_per_wg() { return kSigNW * 32; }
+int sigdot3_wgs_per_cu() { return 8 / kSigNW; }
+
+// (Z, W)-type launch: bias on the Q rows (bias_q); (W, Z)-type: bias on the P rows (bias_p).
+bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
+  // (KD = 64 compiles but spills at two waves per SIMD: not routed until it fits; dense.hip covers it)
+  if (KD != 32 || a.act != 1 || a.est || (a.bias_p && a.bias_q)) return false;
+  const int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
+  if (chunks > 1 && !a.atomic_out) return false;
+  const int nbx = (a.NP + kSigNW * 32 - 1) / (kSigNW * 32);
+  const bool bq = a.bias_q != nullptr;
+  const float* bias = bq ? a.bias_q : a.bias_p;
+  const bool es = a.esum != nullptr, cs = a.out2 != nullptr;
+  const int epl = a.e_planes == 3 ? 3 : 2;
+#define SPMF_SIG3(BQ_, ES_, CS_, EPL_)                                                                     \
+  hipLaunchKernelGGL((sigdot3_kernel<32, BQ_, ES_, CS_, EPL_>), dim3(nbx, chunks), dim3(kSigNW * 64), 0, st, a.NP, a.NQ, \
+                     a.P, a.Q, a.out, a.sign, a.esum, a.atomic_out, bias, a.out2, a.out_rows)
+  // the two shapes the step uses, and one general form for any other caller
+  if (bq && es && !cs && epl == 3) SPMF_SIG3(true, true, false, 3);
+  else if (!bq && !es && cs && epl == 2) SPMF_SIG3(false, false, true, 2);
+  else if (bq) SPMF_SIG3(true, true, true, 3);
+  else SPMF_SIG3(false, true, true, 3);
+#undef SPMF_SIG3
+  return true;
+}
+
 bool launch_expdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
   if (KD != 64 || a.act != 0 || a.bias_p || a.bias_q || a.out2 || a.out_rows || a.est) return false;
   const int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;

@@ -440,6 +440,10 @@ class StepRunner:
         self.use_graph = bool(use_graph) and (all_reduce is None or
                                               bool(getattr(all_reduce, "graph_safe", False)))
         self.max_graphs = max_graphs
+        # batches with more stored entries than this run the SAME device-gated step eagerly: the
+        # step is then GPU-bound (launches queue ahead of it) and a replayed hipGraph is slower than
+        # the plain launches (122 880-row shard of C3, 1.25e7 entries: 0.542 ms replayed, 0.516 eager)
+        self.graph_max_nnz = 8_000_000
         self.graphs = {}           # key -> (graph, workspace ptr, pinned refs)
         self.seen = {}
         self.pool = None
@@ -463,6 +467,10 @@ class StepRunner:
                         all_reduce=self.all_reduce)
             return
         key, cs = self._key(batch)
+        if cs.nnz > self.graph_max_nnz:
+            vi_step_dev(self.model, self.opt, batch, self.dataset_rows, self.S, seed=self.seed,
+                        all_reduce=self.all_reduce)
+            return
         hit = self.graphs.get(key)
         ws = self.model._ws.data_ptr() if self.model._ws is not None else 0
         if hit is not None and hit[1] == ws and hit[2] is cs:

@@ -467,8 +467,15 @@ def test_sharded_fit_stays_on_the_device_loop(monkeypatch):
                    learning_rate=0.05, rel_tol=1e-12, verbose=False, all_reduce=red)
     assert len(losses) == 6 and not calls and all(np.isfinite(losses))
     m2 = _fresh_model(X)
+
+    class Foreign:                 # a caller's own hook: sums nothing (one shard), knows the totals
+        def __call__(self, acc, rows, lg):
+            return rows, lg
+
+        def totals(self, rows, lg):
+            return rows, lg
     m2.fit(lambda: [{"counts": X}], dataset_size=N, sample_size=2, num_steps=2, learning_rate=0.05,
-           rel_tol=1e-12, verbose=False, all_reduce=lambda acc, rows, lg: None)
+           rel_tol=1e-12, verbose=False, all_reduce=Foreign())
     assert len(calls) == 2
 
 
