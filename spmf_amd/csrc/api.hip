@@ -534,6 +534,44 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
           dacc, 0, 0, nullptr, nullptr, nbat, D, dacc_stride};
       ra.ent = ct->ent;
       launch_row_pass(KP, ra, st);
+    } else if (ct->n_rows > 0 && uses_sig3(c)) {
+      // Bernoulli / mixed columns with the linear decoder on the bf16x3 sigmoid kernels: ONE fused row
+      // pass (both sweeps read the same counts; mode 3 leaves xi_b (gz_b - [veta] - z_b) in gzs), then
+      // the (Z, W) launch subtracts the dense row term in its epilogue, gzs_b -= xi_b sum_d sigmoid(l_bd) V'_d,
+      // instead of encode-only sweep -> dense -> stored-cell sweep (two row launches re-stream the
+      // entries and pass z through HBM: DESIGN section 4)
+      RowArgs rf{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
+          dacc, 3, logt, nullptr, c->ctype, 1, D, dacc_stride};
+      rf.ent = ct->ent;
+      launch_row_pass(KP, rf, st);
+      if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
+      const float* lbias = logt == 3 ? c->dbias : c->phi;   // mixed: -1e30 masks the Poisson columns
+      float* gphi_acc = acc + L.gphi_off(0);
+      const bool compact = logt == 3 && c->bcols && c->n_bcols > 0;
+      const float* Wd = c->Vp;
+      int Dd = D;
+      const int32_t* orows = nullptr;
+      if (compact) {
+        launch_compact_rows(c->n_bcols, KP, c->bcols, c->Vp, c->phi, c->Vb, c->bb, st);
+        Wd = c->Vb;
+        Dd = c->n_bcols;
+        lbias = c->bb;
+        orows = c->bcols;
+      }
+      // Two waves per SIMD by registers: chunk counts that fill whole rounds of the resident workgroups.
+      const int zt = (Dd + 127) / 128, wt = (int)((ct->n_rows + 127) / 128);
+      const int rpw = sigdot3_rows_per_wg(), slots = 256 * sigdot3_wgs_per_cu();
+      const int znb = (int)((ct->n_rows + rpw - 1) / rpw), wnb = (Dd + rpw - 1) / rpw;
+      const int zc = pick_chunks(znb, zt, slots, 16), wc = pick_chunks(wnb, wt, slots, 256);
+      ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzs, -1.f, dacc + 3, zc, zc > 1 ? 1 : 0, 1, nullptr, lbias,
+          nullptr, nullptr};
+      ez.e_planes = 3;              // V' rows have mixed signs under the Normal priors: third plane of E
+      ez.accumulate = 1;
+      ez.p_scale = rscale;
+      launch_sigdot3(KP, ez, st);   // gzs_b -= xi_b sum_d sigmoid(l_bd) V'_d ; dacc[3] = sum softplus
+      ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 1, lbias, nullptr, gphi_acc, orows};
+      launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b sigmoid z_b ; gphi_d -= sum_b sigmoid
+      if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
       // cores, then the stored-cell terms (sweep 2) with the dense row term.
@@ -575,21 +613,6 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr,
             nullptr};
         launch_expdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
-      } else if (uses_sig3(c)) {
-        // bf16x3 sigmoid form: (Z, W) with the column bias on the Q rows, then (W, Z) with it on the P
-        // rows; the sigmoid is recomputed (8 GB of E traffic per step on C5 cost more than that).
-        // Two waves per SIMD by registers: chunk counts that fill whole rounds of the resident workgroups.
-        const int zt = (Dd + 127) / 128, wt = (int)((ct->n_rows + 127) / 128);
-        const int rpw = sigdot3_rows_per_wg(), slots = 256 * sigdot3_wgs_per_cu();
-        const int znb = (int)((ct->n_rows + rpw - 1) / rpw), wnb = (Dd + rpw - 1) / rpw;
-        const int zc = pick_chunks(znb, zt, slots, 16), wc = pick_chunks(wnb, wt, slots, 256);
-        if (zc > 1) launch_zero(c->gzd, (size_t)ct->n_rows * KP * sizeof(float), st);
-        ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, zc, zc > 1 ? 1 : 0, 1, nullptr, lbias,
-            nullptr, nullptr};
-        ez.e_planes = 3;              // V' rows have mixed signs under the Normal priors: third plane of E
-        launch_sigdot3(KP, ez, st);   // gzd_b = sum_d sigmoid(l_bd) V'_d ; dacc[3] = sum softplus
-        ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 1, lbias, nullptr, gphi_acc, orows};
-        launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b sigmoid z_b ; gphi_d -= sum_b sigmoid
       } else if (c->est && act != 2) {   // (act 2: E carries exp(X) too, its row sums are not the d/dphi sums)
         // E once: per row chunk, the Z-stationary kernel keeps E (exp, or the sigmoid of the
         // Bernoulli logits) and the second contraction (gV'_d -= sum_b E_bd z_b; Bernoulli:

@@ -532,7 +532,7 @@ template <int KD, bool BQ, bool ESUM, bool CSUM, int EPL>
 __global__ __launch_bounds__(kSigNW * 64, SPMF_SIG3_WPS) void sigdot3_kernel(
     int NP, int NQ, const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ out, float sign,
     double* __restrict__ esum, int atomic_out, const float* __restrict__ bias, float* __restrict__ out2,
-    const int32_t* __restrict__ out_rows) {
+    const int32_t* __restrict__ out_rows, int accumulate, const float* __restrict__ p_scale) {
   static_assert(KD == 32 || KD == 64, "sigdot3: K padded to 32 or 64");
   constexpr int KS = KD / 16, MT = KD / 32, NW = kSigNW, NT = NW * 64;
   constexpr int PITCH = KD * 2 + 16;            // bytes per LDS row; 144 (KD 64) / 80 (KD 32): the 16 rows of a
@@ -665,6 +665,7 @@ __global__ __launch_bounds__(kSigNW * 64, SPMF_SIG3_WPS) void sigdot3_kernel(
   }
   const int prow = (out_rows && p < NP) ? out_rows[p] : p;
   if (p < NP) {
+    const float sc = sign * (p_scale ? p_scale[p] : 1.f);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -674,9 +675,12 @@ __global__ __launch_bounds__(kSigNW * 64, SPMF_SIG3_WPS) void sigdot3_kernel(
         if (TWO) {
           v.x += tot[m][4 * g4 + 0]; v.y += tot[m][4 * g4 + 1]; v.z += tot[m][4 * g4 + 2]; v.w += tot[m][4 * g4 + 3];
         }
-        v.x *= sign; v.y *= sign; v.z *= sign; v.w *= sign;
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         if (atomic_out) {
           atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        } else if (accumulate) {
+          const float4 o = *reinterpret_cast<const float4*>(dst);      // this lane is the only writer of dst
+          *reinterpret_cast<float4*>(dst) = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
         } else {
           *reinterpret_cast<float4*>(dst) = v;
         }
@@ -704,6 +708,7 @@ bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
   if (KD != 32 || a.act != 1 || a.est || (a.bias_p && a.bias_q)) return false;
   const int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
   if (chunks > 1 && !a.atomic_out) return false;
+  if (a.p_scale && a.out_rows) return false;      // (p_scale is indexed by the P row, not the output row)
   const int nbx = (a.NP + kSigNW * 32 - 1) / (kSigNW * 32);
   const bool bq = a.bias_q != nullptr;
   const float* bias = bq ? a.bias_q : a.bias_p;
@@ -711,7 +716,8 @@ bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
   const int epl = a.e_planes == 3 ? 3 : 2;
 #define SPMF_SIG3(BQ_, ES_, CS_, EPL_)                                                                     \
   hipLaunchKernelGGL((sigdot3_kernel<32, BQ_, ES_, CS_, EPL_>), dim3(nbx, chunks), dim3(kSigNW * 64), 0, st, a.NP, a.NQ, \
-                     a.P, a.Q, a.out, a.sign, a.esum, a.atomic_out, bias, a.out2, a.out_rows)
+                     a.P, a.Q, a.out, a.sign, a.esum, a.atomic_out, bias, a.out2, a.out_rows, a.accumulate,  \
+                     a.p_scale)
   // the two shapes the step uses, and one general form for any other caller
   if (bq && es && !cs && epl == 3) SPMF_SIG3(true, true, false, 3);
   else if (!bq && !es && cs && epl == 2) SPMF_SIG3(false, false, true, 2);

@@ -33,7 +33,8 @@ struct RowArgs {
   const double* dprep;
   float *z, *gzs;
   double* dacc;  // [kDaccHead+KP] (zeroed by the caller)
-  int mode;            // 0 full (linear decoder), 1 sweep 1 only (encode), 2 sweep 2 only
+  int mode;            // 0 full (linear decoder), 1 sweep 1 only (encode), 2 sweep 2 only, 3 full with the dense
+                       // row term left to the dense kernel's epilogue (launch_sigdot3 p_scale / accumulate)
   int logt;            // log_transform rate r = exp(<z,V'>) - 1 + phi
   const float* gzd;    // mode 2: per-row dense term sum_d E_bd V'_d  [B,KP]
   const uint8_t* ctype;  // likelihood code 3 (mixed): column types
@@ -88,6 +89,11 @@ struct ExpdotArgs {
   float* est = nullptr;      // keep E (exp or sigmoid) for launch_estdot (layout: dense.hip), ldE = its P extent
   int64_t ldE = 0;
   int e_planes = 2;          // launch_sigdot3: bf16 planes of E in the second product (3 where the Q rows have mixed signs)
+  // launch_sigdot3: out[p] += sign * p_scale[p] * result instead of out[p] = sign * result (p_scale may be
+  // null = 1; plain read-modify-write unless atomic_out): the fused row pass leaves xi_b (gz_b - z_b) in
+  // gzs and this launch subtracts xi_b * sum_d E_bd V'_d from it
+  int accumulate = 0;
+  const float* p_scale = nullptr;
 };
 void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st);
 // dense3.hip: the same operator (act 0, KD = 64, no biases / E store) on the bf16 matrix cores with

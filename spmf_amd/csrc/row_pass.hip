@@ -363,6 +363,9 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       // (mixed: closed-form Poisson-column part veta PLUS the dense Bernoulli-column term)
       float4 dn = (mode == 2 && gzd) ? gather4<LPN>(gzd, (int)b, sub) : veta4;
       if (LIK == 3 && mode == 2 && gzd) dn = add4(dn, veta4);
+      // mode 3 (both sweeps, dense row term subtracted LATER by the dense kernel's epilogue,
+      // gzs_b -= xi_b * sum_d E_bd V'_d): only the closed-form Poisson-column part is known here
+      if (mode == 3 && LIK != 3) dn = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 o;
       o.x = xi_cur * (gz.x - dn.x - zacc.x);
       o.y = xi_cur * (gz.y - dn.y - zacc.y);
