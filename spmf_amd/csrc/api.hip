@@ -58,6 +58,12 @@ struct spmf_ctx {
   float* est = nullptr;
   int64_t est_rows = 0;           // rows per chunk of the bound workspace
   int e_once = 1;                 // SPMF_DENSE_E_ONCE=0: recompute E in a second launch instead
+  int fuse_rows = -1;             // dense-term contexts: one fused row pass + dense-kernel epilogue instead of
+                                  // encode sweep -> dense -> stored-cell sweep.  -1 = where it measured faster:
+                                  // the sigmoid forms at KP = 32 (C5 row launches 0.97 -> 0.84 ms); NOT the exp
+                                  // decoder at KP = 64, where the two-stream fused kernel (20 spilled registers
+                                  // at four waves per SIMD) ran 13.9 ms against 12.8 for the two launches on C4
+                                  // (profiles/r04_fused_rows_c4.txt).  SPMF_FUSE_ROWS=1 / 0 forces it on / off.
   int dense3 = 1;                 // exp sums on the bf16 matrix cores with three-way split operands
                                   // (dense3.hip; Poisson log_transform at KP = 64 only);
                                   // SPMF_DENSE_BF16X3=0 selects the exact-f32 MFMA kernels (dense.hip)
@@ -260,6 +266,7 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   c->flags = flags;
   if (const char* e = getenv("SPMF_DENSE_E_ONCE")) c->e_once = e[0] != '0';
   if (const char* e = getenv("SPMF_DENSE_BF16X3")) c->dense3 = e[0] != '0';
+  if (const char* e = getenv("SPMF_FUSE_ROWS")) c->fuse_rows = e[0] != '0' ? 1 : 0;
   *out = c;
   return SPMF_OK;
 }
@@ -571,6 +578,32 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       launch_sigdot3(KP, ez, st);   // gzs_b -= xi_b sum_d sigmoid(l_bd) V'_d ; dacc[3] = sum softplus
       ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 1, lbias, nullptr, gphi_acc, orows};
       launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b sigmoid z_b ; gphi_d -= sum_b sigmoid
+      if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
+    } else if (ct->n_rows > 0 && [&]() {
+      // Poisson log_transform on the bf16x3 exp kernels with a packed entry stream: ONE fused row pass
+      // too -- sweep 1 reads g(x) (counts.gval), sweep 2 takes the count out of the packed word
+      // (RowArgs.dual: the register cost of the canonical (col, val) pair) -- and the (Z, W) launch
+      // subtracts xi_b sum_d E_bd V'_d from gzs in its epilogue.  Only the LDS-phi launch shapes
+      // have the two-stream form: false = nothing was launched, take the three-launch flow below.
+      if (!uses_dense3(c) || !ct->ent || !ct->gval || c->fuse_rows != 1) return false;
+      RowArgs rf{ct->n_rows, ct->row_ptr, ct->col_idx, ct->gval, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
+          dacc, 3, logt, nullptr, c->ctype, 1, D, dacc_stride};
+      rf.ent = ct->ent;
+      rf.dual = 1;
+      return launch_row_pass(KP, rf, st);
+    }()) {
+      if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
+      ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzs, -1.f, dacc + 3, 1, 0, 0, nullptr, nullptr, nullptr, nullptr};
+      ez.accumulate = 1;
+      ez.p_scale = rscale;
+      launch_expdot3(KP, ez, st);   // gzs_b -= xi_b sum_d E_bd V'_d ; dacc[3] = sum E
+      const int nbx3 = (D + 255) / 256;
+      const int qt3 = (int)((ct->n_rows + 63) / 64);
+      int ch3 = (6 * 256 + nbx3 / 2) / nbx3;      // whole rounds of 256 workgroups (see below)
+      if (ch3 > qt3) ch3 = qt3;
+      if (ch3 < 1) ch3 = 1;
+      ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr, nullptr};
+      launch_expdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix

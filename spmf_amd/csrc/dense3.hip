@@ -10,6 +10,13 @@
 // measured parity: DESIGN.md section 4 (dense path), tools/b3_err.py.
 // Six bf16 MFMAs of 32 cycles replace eight f32 MFMAs of 64 (32x32x2 covers k = 2, 32x32x16
 // covers k = 16): 2.67 x less matrix-pipe time per product.
+// NOT every operand is split three ways: in the SECOND product E = exp(X) is carried in TWO bf16
+// planes (e1 = bf16(E), e2 = bf16(E - e1): 16 significant bits, |E - e1 - e2| <= 2^-18 E per term)
+// against Q in three, five MFMAs: e1 (q1 + q2 + q3) + e2 (q1 + q2).  Every term of those sums is
+// positive (E > 0 times one sign of z or eta v per entry), so the bound on a sum is 2^-18 = 3.8e-6 of
+// the result in the worst case and the rounding is unbiased in practice; sum E for part 'x' comes from
+// the unsplit fp32 E.  Pinned by tests/test_gpu_logtransform.py (oracle at 1e-5 / 1.5e-5 up to
+// exponents of 60, and against the exact-f32 kernels entry by entry).
 //
 //   expdot3(P, Q):  out_p[k] = sum_q exp(min(<P_p, Q_q>, kYSat)) Q_q[k],  esum = sum_{p,q} exp(.)
 // the same operator as dense.hip's expdot_kernel<KD, 0> (Poisson likelihood, exp decoder:
@@ -201,7 +208,8 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
 template <int KD>
 __global__ __launch_bounds__(512, 2) void expdot3_kernel(int NP, int NQ, const float* __restrict__ P,
                                                           const float* __restrict__ Q, float* __restrict__ out,
-                                                          float sign, double* __restrict__ esum, int atomic_out) {
+                                                          float sign, double* __restrict__ esum, int atomic_out,
+                                                          int accumulate, const float* __restrict__ p_scale) {
   static_assert(KD == 64, "expdot3b: K padded to 64");
   constexpr int KS = KD / 16, MT = KD / 32, NW = 8, NT = NW * 64;
   constexpr int IMG = kQT3 * kPitch3;
@@ -316,17 +324,21 @@ __global__ __launch_bounds__(512, 2) void expdot3_kernel(int NP, int NQ, const f
     __syncthreads();
   }
   if (p < NP) {
+    const float sc = sign * (p_scale ? p_scale[p] : 1.f);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         float* dst = out + (size_t)p * KD + m * 32 + 8 * g4 + 4 * h;
-        const float4 v = make_float4(sign * (acc[m][4 * g4 + 0] + tot[m][4 * g4 + 0]),
-                                     sign * (acc[m][4 * g4 + 1] + tot[m][4 * g4 + 1]),
-                                     sign * (acc[m][4 * g4 + 2] + tot[m][4 * g4 + 2]),
-                                     sign * (acc[m][4 * g4 + 3] + tot[m][4 * g4 + 3]));
+        const float4 v = make_float4(sc * (acc[m][4 * g4 + 0] + tot[m][4 * g4 + 0]),
+                                     sc * (acc[m][4 * g4 + 1] + tot[m][4 * g4 + 1]),
+                                     sc * (acc[m][4 * g4 + 2] + tot[m][4 * g4 + 2]),
+                                     sc * (acc[m][4 * g4 + 3] + tot[m][4 * g4 + 3]));
         if (atomic_out) {
           atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        } else if (accumulate) {
+          const float4 o = *reinterpret_cast<const float4*>(dst);      // this lane is the only writer of dst
+          *reinterpret_cast<float4*>(dst) = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
         } else {
           *reinterpret_cast<float4*>(dst) = v;
         }
@@ -732,7 +744,7 @@ bool launch_expdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
   const int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
   const int nbx = (a.NP + 255) / 256;
   hipLaunchKernelGGL((expdot3_kernel<64>), dim3(nbx, chunks), dim3(512), 0, st, a.NP, a.NQ, a.P, a.Q, a.out,
-                     a.sign, a.esum, a.atomic_out);
+                     a.sign, a.esum, a.atomic_out, a.accumulate, a.p_scale);
   return true;
 }
 

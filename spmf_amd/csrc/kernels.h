@@ -43,8 +43,11 @@ struct RowArgs {
   int S, D;
   int64_t dacc_stride;
   const uint32_t* ent = nullptr;   // packed col << 16 | count copy of (col, val), or null (spmf_counts.ent)
+  // mode 3 with the exp decoder (LIK 1): `val` is g(x) (sweep 1) and the counts of sweep 2 come out of `ent`
+  // (must be non-null); only the LDS-phi launch shapes have this form: launch_row_pass returns false otherwise
+  int dual = 0;
 };
-void launch_row_pass(int KP, const RowArgs& a, hipStream_t st);
+bool launch_row_pass(int KP, const RowArgs& a, hipStream_t st);   // false: a.dual asked for a form this shape lacks (nothing launched)
 
 struct ColArgs {
   int D, n_panels, row_base;

@@ -59,23 +59,33 @@ __device__ __forceinline__ float* lds_dyn() {
 // kernel (the resident-set launches have both forms).  load_entry only LOADS (into the pipeline registers of the row prefetch);
 // unpack_entry turns them into (column, count) where they are used, one row later -- arithmetic
 // on the loaded word right away would put the wait for the prefetch in front of it.
-template <bool PACKED, bool NT>
+// FMT 0: canonical (col, val).  FMT 1: packed word.  FMT 2: packed word + a second value stream
+// (`val` = g(x) of the log_transform encoder, poisson.py:41-42): the fused pass of the exp decoders
+// reads g(x) in sweep 1 and the count out of the word in sweep 2 -- the register cost of the canonical pair.
+template <int FMT, bool NT>
 __device__ __forceinline__ void load_entry(const int32_t* __restrict__ col, const float* __restrict__ val,
                                            const uint32_t* __restrict__ ent, int i, bool ok, int& ra,
                                            float& rb) {
-  if (PACKED) {
+  if (FMT == 1) {
     ra = ok ? (int)(NT ? __builtin_nontemporal_load(&ent[i]) : ent[i]) : 0;
     rb = 0.f;
+  } else if (FMT == 2) {
+    ra = ok ? (int)(NT ? __builtin_nontemporal_load(&ent[i]) : ent[i]) : 0;
+    rb = ok ? (NT ? __builtin_nontemporal_load(&val[i]) : val[i]) : 0.f;
   } else {
     ra = ok ? (NT ? __builtin_nontemporal_load(&col[i]) : col[i]) : 0;
     rb = ok ? (NT ? __builtin_nontemporal_load(&val[i]) : val[i]) : 0.f;
   }
 }
-template <bool PACKED>
+// SWEEP 1: the encoder's value (g(x) under FMT 2); SWEEP 2: the count
+template <int FMT, int SWEEP = 2>
 __device__ __forceinline__ void unpack_entry(int ra, float rb, int& c, float& x) {
-  if (PACKED) {
+  if (FMT == 1 || (FMT == 2 && SWEEP == 2)) {
     c = (int)((uint32_t)ra >> 16);
     x = (float)((uint32_t)ra & 0xffffu);
+  } else if (FMT == 2) {
+    c = (int)((uint32_t)ra >> 16);
+    x = rb;
   } else {
     c = ra;
     x = rb;
@@ -204,7 +214,7 @@ struct RowCtx {
 // BT: threads per workgroup.  256: phi from global memory.  512 / 1024: phi staged in LDS
 // (4*D bytes of dynamic LDS: two workgroups per CU up to D = 20 480, one up to 40 960),
 // four waves per SIMD either way.
-template <int KP, int LIK, int BT = 256, bool PACKED = false>
+template <int KP, int LIK, int BT = 256, int PACKED = 0>
 __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pass_kernel(
     int64_t B, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ row_scale,
@@ -296,8 +306,13 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       unpack_entry<PACKED>(pc1, px1, c1, x1);
       const int n0 = min(n, 64), n1 = n - 64;
       if (mode != 2) {
-        cx.sweep1(c0, x0, n0, zacc);
-        if (n1 > 0) cx.sweep1(c1, x1, n1, zacc);
+        if (PACKED == 2) {              // sweep 1 reads the encoder's values, not the counts
+          cx.sweep1(c0, px0, n0, zacc);
+          if (n1 > 0) cx.sweep1(c1, px1, n1, zacc);
+        } else {
+          cx.sweep1(c0, x0, n0, zacc);
+          if (n1 > 0) cx.sweep1(c1, x1, n1, zacc);
+        }
         zacc = across_groups_sum4<LPN>(zacc);
         zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
         if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
           load_entry<PACKED, false>(col, val, ent, i2, i2 < end, ra2, rb2);
           int c;
           float x;
-          unpack_entry<PACKED>(ra, rb, c, x);
+          unpack_entry<PACKED, 1>(ra, rb, c, x);
           cx.sweep1(c, x, min(64, end - base), zacc);
           ra = ra1; rb = rb1; ra1 = ra2; rb1 = rb2;
         }
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
 
 // false: the device does not grant the dynamic LDS this form needs (the caller then launches
 // the 256-thread form, which reads phi from global memory)
-template <int KP, int LIK, int BT, bool PACKED>
+template <int KP, int LIK, int BT, int PACKED>
 static bool launch_row_lds_t(const RowArgs& a, hipStream_t st) {
   // (the encode-only sweep reads no phi: it takes this launch shape, not the LDS)
   const size_t lds = a.mode == 1 ? 0 : std::max((size_t)a.D * 4, (size_t)(BT / 64) * KP * sizeof(double));
@@ -453,7 +468,11 @@ static bool launch_row_lds_t(const RowArgs& a, hipStream_t st) {
 // packed entry stream (spmf_counts.ent) when the batch carries one
 template <int KP, int LIK, int BT>
 static bool launch_row_lds(const RowArgs& a, hipStream_t st) {
-  return a.ent ? launch_row_lds_t<KP, LIK, BT, true>(a, st) : launch_row_lds_t<KP, LIK, BT, false>(a, st);
+  if constexpr (LIK == 1) {
+    // fused pass of the exp decoder: packed word + the g(x) stream (RowArgs.dual)
+    if (a.dual) return a.ent ? launch_row_lds_t<KP, LIK, BT, 2>(a, st) : false;
+  }
+  return a.ent ? launch_row_lds_t<KP, LIK, BT, 1>(a, st) : launch_row_lds_t<KP, LIK, BT, 0>(a, st);
 }
 
 #ifndef ROW_LDS_PHI
@@ -461,7 +480,7 @@ static bool launch_row_lds(const RowArgs& a, hipStream_t st) {
 #endif
 
 template <int KP>
-static void launch_row_t(const RowArgs& a, hipStream_t st) {
+static bool launch_row_t(const RowArgs& a, hipStream_t st) {
   int64_t want = (a.B + 3) / 4;  // 4 waves (rows in flight) per 256-thread block
   int nb = (int)(want < 1 ? 1 : (want > ROW_MAX_BLOCKS ? ROW_MAX_BLOCKS : want));
   // phi from LDS: the sweep-2 forms of the Poisson likelihoods at the K of the named
@@ -471,7 +490,7 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
       // sweep 1 alone (z from the encoder side) does not depend on the likelihood: the
       // resident-set launch of the 512-thread form, without the phi copy.  C4: 8.6 -> 6.4 ms
       // against the 256-thread grid (profiles/r03_sparse_pass_attempts.txt e25)
-      if (launch_row_lds<KP, 0, 512>(a, st)) return;
+      if (launch_row_lds<KP, 0, 512>(a, st)) return true;
     }
     if (ROW_LDS_PHI && a.mode != 1 && a.logt >= 0 && a.logt <= 3 && a.B >= 4096) {
       // (likelihood codes 2 and 3, Bernoulli and mixed, since the end of round 3: their
@@ -489,9 +508,10 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
                : a.logt == 2 ? launch_row_lds<KP, 2, 1024>(a, st)
                              : launch_row_lds<KP, 3, 1024>(a, st);
       }
-      if (done) return;
+      if (done) return true;
     }
   }
+  if (a.dual) return false;      // only the LDS-phi shapes have the two-stream form
 #define SPMF_ROW_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, \
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, \
@@ -502,16 +522,17 @@ static void launch_row_t(const RowArgs& a, hipStream_t st) {
   else if (a.logt == 1) SPMF_ROW_LAUNCH(1);
   else SPMF_ROW_LAUNCH(0);
 #undef SPMF_ROW_LAUNCH
+  return true;
 }
 
-void launch_row_pass(int KP, const RowArgs& a, hipStream_t st) {
+bool launch_row_pass(int KP, const RowArgs& a, hipStream_t st) {
   switch (KP) {
-    case 4: launch_row_t<4>(a, st); break;
-    case 8: launch_row_t<8>(a, st); break;
-    case 16: launch_row_t<16>(a, st); break;
-    case 32: launch_row_t<32>(a, st); break;
-    case 64: launch_row_t<64>(a, st); break;
-    default: break;
+    case 4: return launch_row_t<4>(a, st);
+    case 8: return launch_row_t<8>(a, st);
+    case 16: return launch_row_t<16>(a, st);
+    case 32: return launch_row_t<32>(a, st);
+    case 64: return launch_row_t<64>(a, st);
+    default: return false;
   }
 }
 

@@ -26,9 +26,15 @@ def worst_entry(g, r, sc):
     return float(ratio.reshape(-1)[i]), i
 
 
-def assert_grads_entrywise(got, ref, scales, tol=1e-5, tag=""):
+def assert_grads_entrywise(got, ref, scales, tol=1e-5, tag="", norm_tol=None):
     """got: name -> tensor / array (any float dtype, device); ref, scales: name -> array-like
-    of the reference's shape."""
+    of the reference's shape.
+
+    BOTH bounds must hold: the entry-wise one above, and the array-norm bound of rounds
+    1-2, max|hip - oracle| <= norm_tol * max|oracle| (norm_tol defaults to tol).  The yardstick of a
+    strongly cancelling entry can be orders of magnitude above |oracle| there, so on the DOMINANT
+    entries the entry-wise bound alone is the looser of the two; the norm bound keeps those tight."""
+    norm_tol = tol if norm_tol is None else norm_tol
     for k in ref:
         g = got[k]
         if hasattr(g, "detach"):
@@ -38,3 +44,8 @@ def assert_grads_entrywise(got, ref, scales, tol=1e-5, tag=""):
         w, i = worst_entry(g, r, sc)
         assert w <= tol, (tag, k, f"entry {i}: |hip-oracle| = {w:.3e} x its yardstick "
                           f"(ref {r.reshape(-1)[i]:.6e}, yardstick {np.broadcast_to(sc, r.shape).reshape(-1)[i]:.6e})")
+        g64 = np.asarray(g, dtype=np.float64).reshape(r.shape)
+        top = float(np.abs(r).max()) if r.size else 0.0
+        err = float(np.abs(g64 - r).max()) if r.size else 0.0
+        assert err <= norm_tol * top + 1e-300, (tag, k, f"array norm: max|hip-oracle| = {err:.3e} = "
+                                                f"{err / max(top, 1e-300):.3e} x max|oracle| ({top:.3e})")

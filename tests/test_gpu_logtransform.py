@@ -210,3 +210,9 @@ def test_bf16x3_dense_path_matches_oracle(monkeypatch, B, D, S, ymax):
     # (the two kernels are each within the contract of the oracle; at exponents of 45 - 60 both
     #  are a few 1e-6 from it, on either side)
     assert abs(float(parts["x"].sum()) - float(parts2["x"].sum())) <= 1e-5 * abs(float(parts2["x"].sum()))
+    # ... and so do the gradients, entry by entry (pins the split -- P and Q in three bf16
+    # planes, E = exp(X) in TWO in the second product, |dE| <= 2^-18 E per term -- against a regression):
+    # the two kernels together may use the two bounds above, no more
+    tol2 = 2e-5 if ymax <= 45.0 else 3e-5
+    assert_grads_entrywise(grads, {k: v.double().cpu().numpy() for k, v in grads2.items()},
+                           O.energy_grad_scales(cfg, x, params), tol2, f"bf16x3 vs f32 MFMA {B}x{D} ymax={ymax}")
