@@ -39,7 +39,7 @@
 //
 // A wave leaves through an LDS transpose and 8 float-atomic wave instructions,
 // each covering two whole 128-B gradient rows (the shape MI355X runs atomics
-// at full rate).  Atomic traffic is n_items * (2KP+1)*4 B (0.63 GB on C3).
+// at full rate).  Atomic traffic is n_items * (2KP+1)*4 B (0.49 GB on C3 with 88 panels).
 // Float atomics make the low-order bits of the gradient run-to-run dependent;
 // parity tolerance is 1e-5 relative (north_star).
 #include "common.h"
@@ -73,9 +73,19 @@ __device__ __forceinline__ void pack_block(const double* __restrict__ dacc, floa
   }
 }
 
-// LIK: 0 Poisson / linear, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
-template <int KP, int LIK>
-__global__ __launch_bounds__(256) void col_pass_kernel(
+// ONE kernel body for both fetch shapes (the round-3 file carried it twice):
+//   EPL = 4 ("wide", the default): every lane reads FOUR consecutive entries of its group's list (one
+//     16-B load per array; list starts are only 4-B aligned), so a fetch covers 4*LPN entries = one 128-B
+//     line per group and array at K = 32, against one 32-B piece of a line per 8 entries with EPL = 1
+//     (four times the vector-cache line slots for the same bytes).  Reads up to 4*LPN - 1 entries past the
+//     end of a list: the caller guarantees that much readable padding behind the panel-CSC arrays
+//     (spmf_counts.pc_pad).  PACKED: one word per entry, row inside the panel << 16 | count
+//     (spmf_counts.pc_ent).
+//   EPL = 1 ("narrow"): one entry per lane and fetch, never reads behind a list (pc_pad = 0: a C-ABI
+//     caller whose arrays carry no padding).
+// LIK: 0 Poisson / linear, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear, 3 mixed, 4 Bernoulli / exp
+template <int KP, int LIK, int EPL, bool PACKED>
+__global__ __launch_bounds__(256, EPL == 4 ? COL_WIDE_WAVES : 1) void col_pass_kernel(
     int D, int n_panels, int row_base, int blocks_per_panel,
     const int32_t* __restrict__ item_ptr, const int4* __restrict__ items,
     const int32_t* __restrict__ pc_row, const float* __restrict__ pc_val,
@@ -84,7 +94,10 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
     float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi,
     const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel,
     int64_t Brows, int64_t acc_stride, const double* __restrict__ pack_dacc,
-    float* __restrict__ pack_tail, int64_t dacc_stride) {
+    float* __restrict__ pack_tail, int64_t dacc_stride, const uint32_t* __restrict__ pc_ent,
+    int panel_rows) {
+  static_assert(EPL == 1 || EPL == 4, "entries per lane and fetch: 1 or 4");
+  static_assert(!PACKED || EPL == 4, "the packed lists are read by the wide fetch only");
   if (pack_dacc && blockIdx.x == 0) {
     pack_block<KP>(pack_dacc + (size_t)blockIdx.y * dacc_stride, pack_tail + (size_t)blockIdx.y * acc_stride);
     return;
@@ -142,34 +155,91 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
   float4 gV = make_float4(0.f, 0.f, 0.f, 0.f), gA = gV;
   float gph = 0.f;
 
-  auto fetch = [&](int& rr_, float& xx_, float& gx_, int& cnt_) {
-    cnt_ = min(LPN, end - cur);                       // 0 once the item is exhausted
-    const int e = cur + sub;
-    rr_ = sub < cnt_ ? pc_row[e] - row_base : 0;
-    xx_ = sub < cnt_ ? pc_val[e] : 0.f;
-    gx_ = ((LIK == 1 || LIK == 4) && sub < cnt_) ? pc_gval[e] : 0.f;  // g(x) = log(x/eta+1), data side
-    cur += cnt_;
+  struct __attribute__((packed, aligned(4))) I4 { int x, y, z, w; };
+  struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+  constexpr int FE = EPL * LPN;                       // entries per fetch and group
+  // One fetch of a lane: EPL list words per array.  fetch_raw only LOADS (the fetch for a later
+  // iteration stays untouched until then: decoding it right away would put the wait for it in front of
+  // this iteration's gathers); decode turns the words of the CURRENT fetch into batch rows / counts /
+  // g(x) where they are used.
+  struct Raw {
+    int r[EPL];
+    float x[EPL], g[EPL];
+    int cnt;
+  };
+  auto fetch_raw = [&](Raw& f) {
+    f.cnt = min(FE, end - cur);                       // 0 once the item is exhausted
+    const int e = cur + EPL * sub;
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+      f.r[t] = 0;
+      f.x[t] = 0.f;
+      f.g[t] = 0.f;
+    }
+    if (EPL * sub < f.cnt) {
+      if constexpr (EPL == 4) {
+        if (PACKED) {
+          const I4 w = *reinterpret_cast<const I4*>(reinterpret_cast<const int32_t*>(pc_ent) + e);
+          f.r[0] = w.x; f.r[1] = w.y; f.r[2] = w.z; f.r[3] = w.w;
+        } else {
+          const I4 w = *reinterpret_cast<const I4*>(pc_row + e);
+          const F4 v = *reinterpret_cast<const F4*>(pc_val + e);
+          f.r[0] = w.x; f.r[1] = w.y; f.r[2] = w.z; f.r[3] = w.w;
+          f.x[0] = v.x; f.x[1] = v.y; f.x[2] = v.z; f.x[3] = v.w;
+        }
+        if (LIK == 1 || LIK == 4) {                   // g(x) = log(x/eta+1), data side
+          const F4 v = *reinterpret_cast<const F4*>(pc_gval + e);
+          f.g[0] = v.x; f.g[1] = v.y; f.g[2] = v.z; f.g[3] = v.w;
+        }
+      } else {
+        f.r[0] = pc_row[e];
+        f.x[0] = pc_val[e];
+        if (LIK == 1 || LIK == 4) f.g[0] = pc_gval[e];
+      }
+    }
+    cur += f.cnt;
+  };
+  const int pbase = PACKED ? p * panel_rows : -row_base;   // batch row of a list word
+  auto decode = [&](const Raw& f, int (&rr_)[EPL], float (&xx_)[EPL], float (&gx_)[EPL]) {
+    const int left = f.cnt - EPL * sub;               // valid components of this lane
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+      const bool on = left > t;
+      if (PACKED) {
+        const uint32_t w = (uint32_t)f.r[t];
+        rr_[t] = on ? (int)(w >> 16) + pbase : 0;
+        xx_[t] = on ? (float)(w & 0xffffu) : 0.f;
+      } else {
+        rr_[t] = on ? f.r[t] + pbase : 0;
+        xx_[t] = on ? f.x[t] : 0.f;
+      }
+      gx_[t] = on ? f.g[t] : 0.f;
+    }
   };
 
-  int rr0, cnt0, rr1, cnt1;
-  float xx0, xx1, gx0, gx1;
-  fetch(rr0, xx0, gx0, cnt0);
-  fetch(rr1, xx1, gx1, cnt1);
-  while (__any(cnt0 > 0)) {
-    int rr2, cnt2;
-    float xx2, gx2;
-    fetch(rr2, xx2, gx2, cnt2);                       // two fetches ahead of use
+  // the wide fetch runs one fetch (4*LPN entries) ahead of use, the narrow one two (2*LPN entries)
+  Raw fa, fb, fc;
+  fetch_raw(fa);
+  if (EPL == 1) fetch_raw(fb);
+  while (__any(fa.cnt > 0)) {
+    if (EPL == 1) fetch_raw(fc);
+    else fetch_raw(fb);
+    int rr0[EPL];
+    float xx0[EPL], gx0[EPL];
+    decode(fa, rr0, xx0, gx0);
+    const int cnt0 = fa.cnt;
 #pragma unroll
-    for (int g0 = 0; g0 < LPN; g0 += GRP) {
+    for (int g0 = 0; g0 < FE; g0 += GRP) {
       if (__any(cnt0 > g0)) {                         // wave-uniform
         float4 zz[GRP], gg[GRP];
         float xv[GRP], gv[GRP];
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
-          const int src = grp * LPN + g0 + j;
-          const int b = __shfl(rr0, src);
-          xv[j] = __shfl(xx0, src);
-          gv[j] = (LIK == 1 || LIK == 4) ? __shfl(gx0, src) : xv[j];
+          const int q = g0 + j;                       // entry q of the fetch: lane q / EPL, component q % EPL
+          const int src = grp * LPN + q / EPL;
+          const int b = __shfl(rr0[q % EPL], src);
+          xv[j] = __shfl(xx0[q % EPL], src);
+          gv[j] = (LIK == 1 || LIK == 4) ? __shfl(gx0[q % EPL], src) : xv[j];
           zz[j] = gather4<LPN>(z, b, sub);
           gg[j] = gather4<LPN>(gzs, b, sub);
         }
@@ -200,201 +270,17 @@ __global__ __launch_bounds__(256) void col_pass_kernel(
         }
       }
     }
-    rr0 = rr1; xx0 = xx1; gx0 = gx1; cnt0 = cnt1;
-    rr1 = rr2; xx1 = xx2; gx1 = gx2; cnt1 = cnt2;
+    if (EPL == 1) {
+      fa = fb;
+      fb = fc;
+    } else {
+      fa = fb;
+    }
   }
   // ---- transpose through LDS so each atomic instruction covers whole rows --
-  float4* st4 = reinterpret_cast<float4*>(&stage[wid][grp][0]);
-  st4[sub] = gV;
-  st4[LPN + sub] = gA;
-  __builtin_amdgcn_wave_barrier();
-  const float* flat = &stage[wid][0][0];
-#pragma unroll
-  for (int i = 0; i < (NG * 2 * KP) / 64; ++i) {
-    const int e = i * 64 + lane;
-    const int c = e / (2 * KP), rem = e % (2 * KP);
-    const int dd = __shfl(d, c * LPN);                // column of group c's item
-    const int okc = __shfl((int)ok, c * LPN);
-    const float v = flat[e];
-    if (okc && v != 0.f) {
-      float* dst = (rem >= KP ? gAp + (size_t)dd * KP + (rem - KP) : gVp + (size_t)dd * KP + rem);
-      atomicAdd(dst, v);
-    }
-  }
-  if (ok && sub == 0 && gph != 0.f) atomicAdd(&gphi[d], gph);
-}
-
-// ---- the same pass with 16-B entry fetches (needs padded panel-CSC arrays) ----
-// LIK: 0 Poisson / linear, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
-template <int KP, int LIK, bool PACKED>
-__global__ __launch_bounds__(256, COL_WIDE_WAVES) void col_pass_wide_kernel(
-    int D, int n_panels, int row_base, int blocks_per_panel,
-    const int32_t* __restrict__ item_ptr, const int4* __restrict__ items,
-    const int32_t* __restrict__ pc_row, const float* __restrict__ pc_val,
-    const float* __restrict__ pc_gval, const float* __restrict__ Vp,
-    const float* __restrict__ phi, const float* __restrict__ z, const float* __restrict__ gzs,
-    float* __restrict__ gAp, float* __restrict__ gVp, float* __restrict__ gphi,
-    const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel,
-    int64_t Brows, int64_t acc_stride, const double* __restrict__ pack_dacc,
-    float* __restrict__ pack_tail, int64_t dacc_stride, const uint32_t* __restrict__ pc_ent,
-    int panel_rows) {
-  if (pack_dacc && blockIdx.x == 0) {
-    pack_block<KP>(pack_dacc + (size_t)blockIdx.y * dacc_stride, pack_tail + (size_t)blockIdx.y * acc_stride);
-    return;
-  }
-  if (gridDim.y > 1) {   // S draws per launch
-    const size_t sd = blockIdx.y;
-    Vp += sd * (size_t)D * KP;
-    phi += sd * (size_t)D;
-    z += sd * (size_t)Brows * KP;
-    gzs += sd * (size_t)Brows * KP;
-    gAp += sd * (size_t)acc_stride;
-    gVp += sd * (size_t)acc_stride;
-    gphi += sd * (size_t)acc_stride;
-  }
-  constexpr int LPN = KP / 4;
-  constexpr int NG = 64 / LPN;                        // items per wave
-  constexpr int GRP = LPN < COL_GRP ? LPN : COL_GRP;  // entries gathered back to back
-  __shared__ __attribute__((aligned(16))) float stage[4][NG][2 * KP];
-  const int lane = threadIdx.x & 63;
-  const int sub = lane % LPN, grp = lane / LPN;
-  const int wid = threadIdx.x >> 6;
-  // block id -> (panel, block of 4*NG items); blockIdx % 8 = panel residue
-  // (batches of fewer than 8 panels use a flat mapping: the residue mapping
-  // would leave the XCDs of the missing residues with empty workgroups only)
-  const int64_t L = (int64_t)blockIdx.x - (pack_dacc ? 1 : 0);   // block 0 is the pack block when asked
-  int p, ib;
-  if (n_panels < 8) {
-    p = (int)(L / blocks_per_panel);
-    ib = (int)(L % blocks_per_panel);
-  } else {
-    const int x = (int)(L & 7);
-    const int64_t q = L >> 3;
-    p = 8 * (int)(q / blocks_per_panel) + x;
-    ib = (int)(q % blocks_per_panel);
-  }
-  if (p >= n_panels) return;                          // block-uniform
-  // item range of this launch: the whole panel, or one column half of it (the host
-  // sorts a panel's items by half first: multi-GPU overlap of the all-reduce)
-  const int ilo = half_sel == 2 ? item_mid[p] : item_ptr[p];
-  const int ihi = half_sel == 1 ? item_mid[p] : item_ptr[p + 1];
-  const int i0 = ilo + ib * 4 * NG;
-  if (i0 >= ihi) return;                              // block-uniform
-  const int it = i0 + wid * NG + grp;
-  const bool ok = it < ihi;
-  int cur = 0, end = 0, d = 0;
-  if (ok) {
-    const int4 im = items[it];
-    cur = im.x;
-    end = im.x + im.y;
-    d = im.z;
-  }
-  const float4 vp = ok ? gather4<LPN>(Vp, d, sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float ph = ok ? phi[d] : 1.f;
-  const bool bern = LIK == 2 || LIK == 4 || (LIK == 3 && ok && ctype[d]);   // item's column is Bernoulli
-  float4 gV = make_float4(0.f, 0.f, 0.f, 0.f), gA = gV;
-  float gph = 0.f;
-
-  // Wide fetch: every lane reads FOUR consecutive entries of its group's list (one 16-B
-  // load per array; list starts are only 4-B aligned), so a fetch covers 4*LPN entries =
-  // one 128-B line per group and array at K = 32, against one 32-B piece of a line per
-  // 8 entries in col_pass_kernel (four times the vector-cache line slots for the same
-  // bytes).  Reads up to 4*LPN - 1 entries past the end of a list: the caller guarantees
-  // that much readable padding behind the panel-CSC arrays (spmf_counts.pc_pad).
-  struct __attribute__((packed, aligned(4))) I4 { int x, y, z, w; };
-  struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
-  constexpr int FE = 4 * LPN;                         // entries per fetch and group
-  // fetch_raw only LOADS (the fetch for the next iteration stays untouched until then: decoding
-  // it right away would put the wait for it in front of this iteration's gathers); decode turns
-  // the words of the CURRENT fetch into batch rows / counts where they are used.
-  // PACKED: one word per entry, row inside the panel << 16 | count (spmf_counts.pc_ent).
-  auto fetch_raw = [&](I4& r, F4& x, F4& g, int& cnt_) {
-    cnt_ = min(FE, end - cur);                        // 0 once the item is exhausted
-    const int e = cur + 4 * sub;
-    r = {0, 0, 0, 0};
-    x = {0.f, 0.f, 0.f, 0.f};
-    g = {0.f, 0.f, 0.f, 0.f};
-    if (4 * sub < cnt_) {
-      if (PACKED) {
-        r = *reinterpret_cast<const I4*>(reinterpret_cast<const int32_t*>(pc_ent) + e);
-      } else {
-        r = *reinterpret_cast<const I4*>(pc_row + e);
-        x = *reinterpret_cast<const F4*>(pc_val + e);
-      }
-      if (LIK == 1 || LIK == 4) g = *reinterpret_cast<const F4*>(pc_gval + e);
-    }
-    cur += cnt_;
-  };
-  const int pbase = PACKED ? p * panel_rows : -row_base;   // batch row of a list word
-  auto decode = [&](const I4& r, const F4& x, const F4& g, int cnt_, int (&rr_)[4], float (&xx_)[4],
-                    float (&gx_)[4]) {
-    const int left = cnt_ - 4 * sub;                  // valid components of this lane
-    const int rw[4] = {r.x, r.y, r.z, r.w};
-    const float xw[4] = {x.x, x.y, x.z, x.w}, gw[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool on = left > t;
-      if (PACKED) {
-        const uint32_t w = (uint32_t)rw[t];
-        rr_[t] = on ? (int)(w >> 16) + pbase : 0;
-        xx_[t] = on ? (float)(w & 0xffffu) : 0.f;
-      } else {
-        rr_[t] = on ? rw[t] + pbase : 0;
-        xx_[t] = on ? xw[t] : 0.f;
-      }
-      gx_[t] = on ? gw[t] : 0.f;
-    }
-  };
-
-  I4 rA, rB;
-  F4 xA, xB, gA_, gB_;
-  int cnt0, cnt1;
-  fetch_raw(rA, xA, gA_, cnt0);
-  while (__any(cnt0 > 0)) {
-    fetch_raw(rB, xB, gB_, cnt1);                     // one fetch (4*LPN entries) ahead of use
-    int rr0[4];
-    float xx0[4], gx0[4];
-    decode(rA, xA, gA_, cnt0, rr0, xx0, gx0);
-#pragma unroll
-    for (int g0 = 0; g0 < FE; g0 += GRP) {
-      if (__any(cnt0 > g0)) {                         // wave-uniform
-        float4 zz[GRP], gg[GRP];
-        float xv[GRP], gv[GRP];
-#pragma unroll
-        for (int j = 0; j < GRP; ++j) {
-          const int q = g0 + j;                       // entry q of the fetch: lane q/4, component q%4
-          const int src = grp * LPN + q / 4;
-          const int b = __shfl(rr0[q % 4], src);
-          xv[j] = __shfl(xx0[q % 4], src);
-          gv[j] = (LIK == 1 || LIK == 4) ? __shfl(gx0[q % 4], src) : xv[j];
-          zz[j] = gather4<LPN>(z, b, sub);
-          gg[j] = gather4<LPN>(gzs, b, sub);
-        }
-#pragma unroll
-        for (int j = 0; j < GRP; ++j) {
-          if (bern) {
-            float wv = xv[j];
-            if (LIK == 4) wv *= expf(fminf(group_sum<LPN>(dot4(zz[j], vp)), kYSat));
-            gV = fma4(wv, zz[j], gV);
-            gA = fma4(gv[j], gg[j], gA);
-            gph += xv[j];
-          } else {
-            const float y = group_sum<LPN>(dot4(zz[j], vp));
-            float ey = 1.f;
-            const float r = (LIK == 1 ? expm1_dec(fminf(y, kYSat), ey) : y) + ph;
-            const float xr = (r > 0.f && r < INFINITY) ? xv[j] * __builtin_amdgcn_rcpf(r)
-                                                       : (xv[j] > 0.f ? 1.f : 0.f);
-            gV = fma4(LIK == 1 ? xr * ey : xr, zz[j], gV);
-            gA = fma4(gv[j], gg[j], gA);
-            gph += xr;
-          }
-        }
-      }
-    }
-    rA = rB; xA = xB; gA_ = gB_;
-    cnt0 = cnt1;
-  }
-  // ---- transpose through LDS so each atomic instruction covers whole rows --
+  // (a wave leaves through 8 float-atomic wave instructions, each covering two whole 128-B gradient
+  //  rows: the shape MI355X runs atomics at full rate; n_items * (2KP+1)*4 B, 0.49 GB on C3.  The
+  //  owner form that needs no atomics was measured and rejected: profiles/r04_col_owner_probe.txt)
   float4* st4 = reinterpret_cast<float4*>(&stage[wid][grp][0]);
   st4[sub] = gV;
   st4[LPN + sub] = gA;
@@ -429,20 +315,18 @@ static bool launch_col_t(const ColArgs& a, hipStream_t st) {
   dim3((unsigned)nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, a.D, a.n_panels, a.row_base, bpp,   \
       a.item_ptr, items, a.pc_row, a.pc_val, a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, \
       a.gphi, a.ctype, a.item_mid, a.half_sel, a.B, a.acc_stride, a.pack_dacc, a.pack_tail,     \
-      a.dacc_stride
+      a.dacc_stride, a.pc_ent, a.panel_rows
   const bool wide = COL_WIDE && a.pc_pad >= KP - 1;   // 4*LPN - 1 entries of readable padding
   // packed lists (spmf_counts.pc_ent: row in panel << 16 | count) when the batch carries them
   const bool packed = wide && a.pc_ent && a.panel_rows > 0 && a.panel_rows <= 65536;
 #define SPMF_COL_LAUNCH(L_)                                                                        \
   do {                                                                                             \
     if (packed)                                                                                    \
-      hipLaunchKernelGGL((col_pass_wide_kernel<KP, L_, true>), SPMF_COL_ARGS, a.pc_ent,            \
-                         a.panel_rows);                                                            \
+      hipLaunchKernelGGL((col_pass_kernel<KP, L_, 4, true>), SPMF_COL_ARGS);                       \
     else if (wide)                                                                                 \
-      hipLaunchKernelGGL((col_pass_wide_kernel<KP, L_, false>), SPMF_COL_ARGS, a.pc_ent,           \
-                         a.panel_rows);                                                            \
+      hipLaunchKernelGGL((col_pass_kernel<KP, L_, 4, false>), SPMF_COL_ARGS);                      \
     else                                                                                           \
-      hipLaunchKernelGGL((col_pass_kernel<KP, L_>), SPMF_COL_ARGS);                                \
+      hipLaunchKernelGGL((col_pass_kernel<KP, L_, 1, false>), SPMF_COL_ARGS);                      \
   } while (0)
   if (a.logt == 4) SPMF_COL_LAUNCH(4);
   else if (a.logt == 3) SPMF_COL_LAUNCH(3);

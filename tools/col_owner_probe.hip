@@ -11,7 +11,7 @@
 //   kernel adds the 8 class partials.
 //
 // Reference in the same program: THE PRODUCT'S kernel (spmf_amd/csrc/col_pass.hip is compiled into this
-// file: col_pass_wide_kernel<32, 0, packed>, items sorted by length per panel, float-atomic flush) on the
+// file: col_pass_kernel<32, 0, 4, packed>, items sorted by length per panel, float-atomic flush) on the
 // same matrix, same z / xi*gz / V' / phi.
 //
 //   hipcc -O3 --offload-arch=gfx950 -Ispmf_amd/csrc -Iinclude tools/col_owner_probe.hip -o tools/bin/col_owner_probe
@@ -275,7 +275,7 @@ int main(int argc, char** argv) {
   ca.pc_val = reinterpret_cast<const float*>(d_ent);
   ca.pc_ent = d_ent;
   ca.panel_rows = panel_rows;
-  const float t_ref = timeit("product: col_pass_wide_kernel<32,0,packed>, float-atomic flush (+ zero fill)", [&] {
+  const float t_ref = timeit("product: col_pass_kernel<32,0,4,packed>, float-atomic flush (+ zero fill)", [&] {
     (void)hipMemsetAsync(d_acc0, 0, accn * 4, 0);
     launch_col_pass(KP, ca, 0);
   });

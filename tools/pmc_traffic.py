@@ -35,7 +35,7 @@ def kernels_sha():
     return h.hexdigest()[:16]
 
 
-SHORT = {"row_pass_kernel": "row_pass", "col_pass_kernel": "col_pass", "col_pass_wide_kernel": "col_pass",
+SHORT = {"row_pass_kernel": "row_pass", "col_pass_kernel": "col_pass", "col_pass_wide_kernel": "col_pass", "sigdot3_kernel": "dense_expdot",
          "expdot_kernel": "dense_expdot", "expdot3_kernel": "dense_expdot", "finish_kernel": "finish",
          "prep_kernel": "prep"}
 
