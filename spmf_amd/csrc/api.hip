@@ -597,11 +597,8 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       ez.accumulate = 1;
       ez.p_scale = rscale;
       launch_expdot3(KP, ez, st);   // gzs_b -= xi_b sum_d E_bd V'_d ; dacc[3] = sum E
-      const int nbx3 = (D + 255) / 256;
-      const int qt3 = (int)((ct->n_rows + 63) / 64);
-      int ch3 = (6 * 256 + nbx3 / 2) / nbx3;      // whole rounds of 256 workgroups (see below)
-      if (ch3 > qt3) ch3 = qt3;
-      if (ch3 < 1) ch3 = 1;
+      const int ch3 = pick_chunks((D + expdot3_rows_per_wg() - 1) / expdot3_rows_per_wg(),
+                                  (int)((ct->n_rows + 127) / 128), 256 * expdot3_wgs_per_cu(), 64);
       ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr, nullptr};
       launch_expdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
@@ -635,14 +632,11 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, 1, 0, 0, nullptr, nullptr, nullptr,
             nullptr};
         launch_expdot3(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E
-        const int nbx3 = (Dd + 255) / 256;
-        const int qt3 = (int)((ct->n_rows + 63) / 64);
-        // one 110 KB workgroup per CU: size the Q chunks so that the launch is a whole number of
-        // rounds of 256 workgroups (6 of them; 5 chunks = 590 workgroups ran 2.3 rounds, the last
-        // one a third full)
-        int ch3 = (6 * 256 + nbx3 / 2) / nbx3;
-        if (ch3 > qt3) ch3 = qt3;
-        if (ch3 < 1) ch3 = 1;
+        // Q chunks of the W-stationary launch: whole rounds of the resident workgroups (one 110 KB
+        // workgroup per CU: 118 column blocks x 13 chunks = 6 rounds of 256 on C4; 5 chunks = 590
+        // workgroups ran 2.3 rounds, the last one a third full)
+        const int ch3 = pick_chunks((Dd + expdot3_rows_per_wg() - 1) / expdot3_rows_per_wg(),
+                                    (int)((ct->n_rows + 127) / 128), 256 * expdot3_wgs_per_cu(), 64);
         ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr,
             nullptr};
         launch_expdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b

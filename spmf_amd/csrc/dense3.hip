@@ -205,16 +205,23 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
   productC(3);
 }
 
+#ifndef SPMF_EXP3_NW
+#define SPMF_EXP3_NW 8       // waves per workgroup (32 P rows each)
+#endif
+#ifndef SPMF_EXP3_NBUF
+#define SPMF_EXP3_NBUF 2     // LDS buffers of the staged Q tile (1: the next tile waits in registers for a barrier)
+#endif
+constexpr int kExpNW = SPMF_EXP3_NW, kExpNBUF = SPMF_EXP3_NBUF;
 template <int KD>
-__global__ __launch_bounds__(512, 2) void expdot3_kernel(int NP, int NQ, const float* __restrict__ P,
+__global__ __launch_bounds__(kExpNW * 64, 2) void expdot3_kernel(int NP, int NQ, const float* __restrict__ P,
                                                           const float* __restrict__ Q, float* __restrict__ out,
                                                           float sign, double* __restrict__ esum, int atomic_out,
                                                           int accumulate, const float* __restrict__ p_scale) {
   static_assert(KD == 64, "expdot3b: K padded to 64");
-  constexpr int KS = KD / 16, MT = KD / 32, NW = 8, NT = NW * 64;
+  constexpr int KS = KD / 16, MT = KD / 32, NW = kExpNW, NT = NW * 64;
   constexpr int IMG = kQT3 * kPitch3;
   constexpr int NPC = kQT3 * (KD / 8) / NT;    // (row, 8 k) pieces per loader thread
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kExpNBUF][3][IMG];
   __shared__ double red[16];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -253,11 +260,14 @@ __global__ __launch_bounds__(512, 2) void expdot3_kernel(int NP, int NQ, const f
   float xmax = 0.f;
 
   // ---- stage loader: piece pc = t + NT j: row pc / 8 of the tile, k = 8 (pc % 8) .. + 7 -------
-  float4 st0[NPC], st1[NPC];
-  auto gload = [&](int tile) {
+  // (single-buffer form: the pieces of a thread go through the staging registers two at a time)
+  constexpr int NST = kExpNBUF == 2 ? NPC : (NPC < 2 ? NPC : 2);
+  float4 st0[NST], st1[NST];
+  auto gload = [&](int tile, int j0 = 0) {
     const int q0 = tile * kQT3;
 #pragma unroll
-    for (int j = 0; j < NPC; ++j) {
+    for (int jj = 0; jj < NST; ++jj) {
+      const int j = j0 + jj;
       const int pc = t + NT * j, row = pc >> 3, k8 = (pc & 7) * 8;
       // rows past NQ read the last row (always in bounds) and are zeroed: no branch, no
       // exec masking around the loads
@@ -266,15 +276,16 @@ __global__ __launch_bounds__(512, 2) void expdot3_kernel(int NP, int NQ, const f
       const float keep = q0 + row < NQ ? 1.f : 0.f;
       const float4 a = *reinterpret_cast<const float4*>(src);
       const float4 b = *reinterpret_cast<const float4*>(src + 4);
-      st0[j] = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
-      st1[j] = make_float4(b.x * keep, b.y * keep, b.z * keep, b.w * keep);
+      st0[jj] = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
+      st1[jj] = make_float4(b.x * keep, b.y * keep, b.z * keep, b.w * keep);
     }
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](int buf, int j0 = 0) {
 #pragma unroll
-    for (int j = 0; j < NPC; ++j) {
+    for (int jj = 0; jj < NST; ++jj) {
+      const int j = j0 + jj;
       const int pc = t + NT * j, row = pc >> 3, k8 = (pc & 7) * 8;
-      const float v[8] = {st0[j].x, st0[j].y, st0[j].z, st0[j].w, st1[j].x, st1[j].y, st1[j].z, st1[j].w};
+      const float v[8] = {st0[jj].x, st0[jj].y, st0[jj].z, st0[jj].w, st1[jj].x, st1[jj].y, st1[jj].z, st1[jj].w};
       u32x4 c3[3];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -294,15 +305,18 @@ __global__ __launch_bounds__(512, 2) void expdot3_kernel(int NP, int NQ, const f
   };
 
   if (tile0 < tile1) {
-    gload(tile0);
-    swrite(0);
+#pragma unroll
+    for (int j0 = 0; j0 < NPC; j0 += NST) {
+      gload(tile0, j0);
+      swrite(0, j0);
+    }
   }
   __syncthreads();
   const bool p_edge = (int)(blockIdx.x * NW * 32 + NW * 32) > NP;      // block-uniform
   for (int tile = tile0; tile < tile1; ++tile) {
-    const int buf = (tile - tile0) & 1;
+    const int buf = kExpNBUF == 2 ? ((tile - tile0) & 1) : 0;
     const bool more = tile + 1 < tile1;                    // block-uniform
-    if (more) gload(tile + 1);                             // lands under this tile's MFMAs
+    if (kExpNBUF == 2 && more) gload(tile + 1);            // lands under this tile's MFMAs
     const int q0 = tile * kQT3;
     float es_tile = 0.f;
     const uint32_t trb = lds0 + buf * 3 * IMG + tr_lane;
@@ -320,8 +334,20 @@ __global__ __launch_bounds__(512, 2) void expdot3_kernel(int NP, int NQ, const f
           acc[m][i] = 0.f;
         }
     }
-    if (more) swrite(buf ^ 1);
-    __syncthreads();
+    if (kExpNBUF == 2) {
+      if (more) swrite(buf ^ 1);
+      __syncthreads();
+    } else {
+      __syncthreads();                                     // every wave has read this tile
+      if (more) {                                          // (the CU's other workgroup computes meanwhile)
+#pragma unroll
+        for (int j0 = 0; j0 < NPC; j0 += NST) {
+          gload(tile + 1, j0);
+          swrite(0, j0);
+        }
+      }
+      __syncthreads();
+    }
   }
   if (p < NP) {
     const float sc = sign * (p_scale ? p_scale[p] : 1.f);
@@ -711,6 +737,8 @@ __global__ __launch_bounds__(kSigNW * 64, SPMF_SIG3_WPS) void sigdot3_kernel(
 
 // launch geometry for the caller's chunk choice: P rows per workgroup, resident workgroups per CU
 // (two waves per SIMD by registers: 8 waves per CU)
+int expdot3_rows_per_wg() { return kExpNW * 32; }
+int expdot3_wgs_per_cu() { return (8 / kExpNW) < (kExpNBUF == 2 ? 1 : 2) ? (8 / kExpNW) : (kExpNBUF == 2 ? 1 : 2); }
 int sigdot3_rows_per_wg() { return kSigNW * 32; }
 int sigdot3_wgs_per_cu() { return 8 / kSigNW; }
 
@@ -742,8 +770,8 @@ bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
 bool launch_expdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
   if (KD != 64 || a.act != 0 || a.bias_p || a.bias_q || a.out2 || a.out_rows || a.est) return false;
   const int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
-  const int nbx = (a.NP + 255) / 256;
-  hipLaunchKernelGGL((expdot3_kernel<64>), dim3(nbx, chunks), dim3(512), 0, st, a.NP, a.NQ, a.P, a.Q, a.out,
+  const int nbx = (a.NP + kExpNW * 32 - 1) / (kExpNW * 32);
+  hipLaunchKernelGGL((expdot3_kernel<64>), dim3(nbx, chunks), dim3(kExpNW * 64), 0, st, a.NP, a.NQ, a.P, a.Q, a.out,
                      a.sign, a.esum, a.atomic_out, a.accumulate, a.p_scale);
   return true;
 }

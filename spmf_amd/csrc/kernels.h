@@ -105,6 +105,8 @@ bool launch_expdot3(int KD, const ExpdotArgs& a, hipStream_t st);
 // dense3.hip: the sigmoid / softplus operator (act 1: Bernoulli and mixed columns, KD = 32 or 64, one of
 // bias_p / bias_q, out2, out_rows; no E store) on the same bf16x3 operands; false = not covered
 bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st);
+int expdot3_rows_per_wg();
+int expdot3_wgs_per_cu();
 int sigdot3_rows_per_wg();
 int sigdot3_wgs_per_cu();
 void launch_estdot(int KD, int NQ, int NP, int64_t ldE, const float* est, const float* P, float* out, float sign,

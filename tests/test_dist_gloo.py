@@ -86,6 +86,30 @@ def _worker(rank, world, port, q):
         n_rows, lgamma_sum = r1 - r0, lg
     assert batch_rows_global(_CS, red) == rows_g == x.shape[0]
     assert batch_rows_global(_CS, None) == r1 - r0
+    # ---- what the device-resident sharded loop (vi.vi_step_dev with the reducer) leans on -------------
+    # rank 0's Philox key on every rank (three float32-exact 21-bit pieces through the sum all-reduce)
+    key = (1 << 61) + 123456789012345
+    assert red.share_int(key + 17 * rank) == key
+    # per-batch global totals: reduced ONCE per batch object, then answered from the cache with no
+    # communication (the step must not read anything back)
+    red_mb = ShardReducer()                       # minibatched shards: no fixed per-step totals
+
+    class _Batch:
+        n_rows, lgamma_sum = r1 - r0, lg
+    b0 = _Batch()
+    assert red_mb.batch_totals(b0) == (rows_g, lg_g)
+    real_sum = red_mb._sum
+
+    def _no_comm(t):
+        raise AssertionError("batch_totals communicated again for a batch it has seen")
+    red_mb._sum = _no_comm
+    assert red_mb.batch_totals(b0) == (rows_g, lg_g)
+    red_mb._sum = real_sum
+    assert red.batch_totals(b0) == (rows_g, lg_g)          # full-batch reducer: the fixed totals
+    # torch.distributed as the transport: the step's collective is not graph-capturable, and the prior
+    # half of the finish is forked under it only when there is more than one rank
+    assert red.graph_safe is False and red.overlap_prior is (world > 1)
+    assert ShardReducer(overlap_prior=False).overlap_prior is False
     # replicas: equal after a sync, and the diagnostic sees a planted difference
     rep = [torch.full((5,), float(rank)), torch.arange(3.0) + rank]
     assert red.replicas_max_abs_diff(rep) == float(world - 1)
