@@ -365,6 +365,7 @@ def main():
     batch = {"counts": sc}
 
     hook = None
+    transport = None
     if distributed:
         from spmf_amd.dist import LibraryComm, ShardReducer
         # transport of the step's one collective: the library's own RCCL communicator
@@ -372,8 +373,14 @@ def main():
         # call through torch.distributed, and capturable in the VI step's hipGraph).
         # SPMF_BENCH_COMM=torch selects torch.distributed's; the gloo rehearsal always uses it.
         comm = None
+        transport = f"torch.distributed ({backend})"
         if os.environ.get("SPMF_BENCH_COMM", "lib") != "torch" and backend == "nccl":
-            comm = LibraryComm(model)
+            try:
+                comm = LibraryComm(model)
+                transport = "library RCCL communicator (spmf_allreduce on the step's stream)"
+            except Exception as e:        # librccl not loadable from the library: every rank lands here alike
+                print(f"LibraryComm unavailable ({e}); torch.distributed moves the accumulators", file=sys.stderr)
+                comm = None
         hook = ShardReducer(comm=comm)
         hook.set_batch_totals(rows_g, lgam_g)
 
@@ -632,7 +639,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + f", S={S}, full batch, row-sharded x{world}",
                        "rows": rows_g, "cols": D, "nnz": nnz_g, "latent_dim": K,
-                       "samples": S, "parallelism": f"row-shard dp{world}",
+                       "samples": S, "parallelism": f"row-shard dp{world}", "allreduce_transport": transport,
                        "panel_rows": args.panel_rows,
                        # physical entry streams (the algorithmic bytes above stay canonical: 8 B per entry and pass)
                        "entry_format": ("packed u32: col<<16|count (row pass), row-in-panel<<16|count (column pass)"
