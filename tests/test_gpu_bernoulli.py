@@ -27,10 +27,15 @@ def problem(B, D, K, S, seed, density):
     return cfg, x, params
 
 
+@pytest.mark.parametrize("bf16x3", ["1", "0"])
 @pytest.mark.parametrize("B,D,K,S,density", [(37, 23, 3, 2, 0.3), (150, 90, 8, 1, 0.1),
-                                             (260, 200, 32, 1, 0.05), (300, 129, 64, 2, 0.05)])
-def test_bernoulli_energy_and_grads(B, D, K, S, density):
+                                             (260, 200, 32, 1, 0.05), (300, 129, 64, 2, 0.05),
+                                             (1500, 700, 20, 1, 0.02)])
+def test_bernoulli_energy_and_grads(monkeypatch, B, D, K, S, density, bf16x3):
+    """Both dense paths (read at spmf_ctx_create): the bf16x3 sigmoid kernels with the fused row pass
+    (default at K <= 32) and the exact-f32 MFMA kernels; the last case spans several Q tiles and chunks."""
     from spmf_amd import BernoulliFactorization
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", bf16x3)
     cfg, x, params = problem(B, D, K, S, 700 + B + K, density)
     pref, gref, _ = O.energy_and_grads(cfg, x, params)
     m = BernoulliFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,

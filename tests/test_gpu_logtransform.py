@@ -216,3 +216,33 @@ def test_bf16x3_dense_path_matches_oracle(monkeypatch, B, D, S, ymax):
     tol2 = 2e-5 if ymax <= 45.0 else 3e-5
     assert_grads_entrywise(grads, {k: v.double().cpu().numpy() for k, v in grads2.items()},
                            O.energy_grad_scales(cfg, x, params), tol2, f"bf16x3 vs f32 MFMA {B}x{D} ymax={ymax}")
+
+
+@pytest.mark.parametrize("B,D,S", [(4500, 300, 1), (4700, 1500, 2)])
+def test_fused_row_pass_of_the_exp_decoder_matches_the_two_launch_flow(monkeypatch, B, D, S):
+    """SPMF_FUSE_ROWS=1 (off by default: slower on C4, profiles/r04_fused_rows_c4.txt): ONE row pass for the
+    Poisson log_transform context at K = 64 -- sweep 1 reads g(x), sweep 2 takes the count out of the packed
+    word (row_pass.hip FMT 2), mode 3 leaves xi (gz - z) in gzs -- and the (Z, W) expdot3 launch subtracts
+    xi_b sum_d E_bd V'_d in its epilogue.  Needs >= 4096 rows (the LDS-phi launch shapes carry the two-stream
+    form).  Against the oracle at the contract, and against the default flow of the same library."""
+    from spmf_amd import PoissonFactorization
+    K = 64
+    cfg, x, params = problem(B, D, K, S, 4100 + D, 0.03)
+    pref, gref, _ = O.energy_and_grads(cfg, x, params)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SPMF_FUSE_ROWS", fuse)
+        m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale, log_transform=True,
+                                 column_norms=cfg.eta_i, initialize_distributions=False, device="cuda")
+        m.xi_u_global = cfg.xi_u_global
+        parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+        assert float(nnf.sum()) == 0
+        out[fuse] = (parts, grads)
+    scales = O.energy_grad_scales(cfg, x, params)
+    for k, r in pref.items():
+        np.testing.assert_allclose(out["1"][0][k].cpu().numpy(), r.numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
+    assert_grads_entrywise(out["1"][1], gref, scales, 1e-5, "fused exp row pass")
+    for k in out["1"][0]:
+        np.testing.assert_allclose(out["1"][0][k].cpu().numpy(), out["0"][0][k].cpu().numpy(), rtol=2e-6, err_msg=k)
+    assert_grads_entrywise(out["1"][1], {k: v.double().cpu().numpy() for k, v in out["0"][1].items()}, scales,
+                           4e-6, "fused vs two launches")

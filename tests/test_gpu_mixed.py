@@ -29,10 +29,14 @@ def problem(B, D, K, S, seed, density, scale_rows=True):
     return cfg, x, params, mask
 
 
+@pytest.mark.parametrize("bf16x3", ["1", "0"])
 @pytest.mark.parametrize("B,D,K,S,density,sr", [(37, 24, 3, 2, 0.3, True), (150, 90, 8, 1, 0.1, False),
                                                 (260, 200, 32, 1, 0.05, True), (300, 129, 64, 2, 0.05, True)])
-def test_mixed_energy_and_grads(B, D, K, S, density, sr):
+def test_mixed_energy_and_grads(monkeypatch, B, D, K, S, density, sr, bf16x3):
+    """Both dense paths of the sigmoid sums (read at spmf_ctx_create): the bf16x3 kernels with the fused
+    row pass (csrc/dense3.hip sigdot3, default at K <= 32) and the exact-f32 MFMA kernels."""
     from spmf_amd import MixedFactorization
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", bf16x3)
     cfg, x, params, mask = problem(B, D, K, S, 800 + B + K, density, sr)
     pref, gref, _ = O.energy_and_grads(cfg, x, params)
     m = MixedFactorization(mask, latent_dim=K, u_tau_scale=cfg.u_tau_scale, scale_rows=sr,
@@ -46,12 +50,16 @@ def test_mixed_energy_and_grads(B, D, K, S, density, sr):
     assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "")
 
 
+@pytest.mark.parametrize("bf16x3", ["0", "1"])
 @pytest.mark.parametrize("kind", ["mixed", "bernoulli"])
-def test_sigmoid_e_buffer_in_several_row_chunks(kind):
-    """The sigmoid form of the kept-E path with a small spmf_ctx_set_e_cap: several row chunks, a
-    last chunk that ends inside a 32-row round (row sums of E masked there), and -- mixed -- the
-    scatter through the compacted Bernoulli column list."""
+def test_sigmoid_e_buffer_in_several_row_chunks(monkeypatch, kind, bf16x3):
+    """bf16x3 = 0: the sigmoid form of the kept-E path (exact-f32 kernels) with a small
+    spmf_ctx_set_e_cap: several row chunks, a last chunk that ends inside a 32-row round (row sums of E
+    masked there), and -- mixed -- the scatter through the compacted Bernoulli column list.
+    bf16x3 = 1: the same problem on the sigdot3 kernels (no E buffer): row and column counts off the
+    128 / 256 tile edges, several Q chunks with float-atomic epilogues, the compacted column list."""
     from spmf_amd import BernoulliFactorization, MixedFactorization, _lib
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", bf16x3)
     B, D, K, S = 3001, 90, 32, 1
     if kind == "mixed":
         cfg, x, params, mask = problem(B, D, K, S, 5150, 0.04, True)
