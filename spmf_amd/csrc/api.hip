@@ -182,10 +182,10 @@ static bool uses_dense3(const spmf_ctx* c) {
   return c->dense3 && likelihood_code(c) == 1 && c->KP == 64;
 }
 // The bf16x3 form of the sigmoid / softplus sums (dense3.hip sigdot3: Bernoulli and mixed contexts with the
-// linear decoder) at KP = 32; it recomputes the sigmoid in its second launch too.
+// linear decoder) at KP = 32 and 64; it recomputes the sigmoid in its second launch too.
 static bool uses_sig3(const spmf_ctx* c) {
   const int lik = likelihood_code(c);
-  return c->dense3 && (lik == 2 || lik == 3) && c->KP == 32;
+  return c->dense3 && (lik == 2 || lik == 3) && (c->KP == 32 || c->KP == 64);
 }
 static bool uses_e_buffer(const spmf_ctx* c) {
   return (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once &&
@@ -567,7 +567,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       }
       // Two waves per SIMD by registers: chunk counts that fill whole rounds of the resident workgroups.
       const int zt = (Dd + 127) / 128, wt = (int)((ct->n_rows + 127) / 128);
-      const int rpw = sigdot3_rows_per_wg(), slots = 256 * sigdot3_wgs_per_cu();
+      const int rpw = sigdot3_rows_per_wg(KP), slots = 256 * sigdot3_wgs_per_cu(KP);
       const int znb = (int)((ct->n_rows + rpw - 1) / rpw), wnb = (Dd + rpw - 1) / rpw;
       const int zc = pick_chunks(znb, zt, slots, 16), wc = pick_chunks(wnb, wt, slots, 256);
       ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzs, -1.f, dacc + 3, zc, zc > 1 ? 1 : 0, 1, nullptr, lbias,

@@ -562,17 +562,18 @@ __device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ i
 #define SPMF_SIG3_WPS 2      // waves per SIMD the kernel is compiled for (register budget 512 / WPS)
 #endif
 #ifndef SPMF_SIG3_NW
-#define SPMF_SIG3_NW 4       // waves per workgroup (32 P rows each): two 256-thread workgroups per CU, so a
-                             // workgroup at its per-tile barrier leaves the CU to the other (C5 dense: 1.85 -> 1.52 ms)
+#define SPMF_SIG3_NW 4       // waves per workgroup (32 P rows each) at KD = 32: two 256-thread workgroups per CU, so
+                             // a workgroup at its per-tile barrier leaves the CU to the other (C5 dense: 1.85 -> 1.52 ms)
 #endif
-constexpr int kSigNW = SPMF_SIG3_NW;
+// KD = 64: the staged Q tile is 110 KB (two buffers x three planes), one workgroup per CU: eight waves, like expdot3
+__host__ __device__ constexpr int sig_nw(int KD) { return KD == 64 ? 8 : SPMF_SIG3_NW; }
 template <int KD, bool BQ, bool ESUM, bool CSUM, int EPL>
-__global__ __launch_bounds__(kSigNW * 64, SPMF_SIG3_WPS) void sigdot3_kernel(
+__global__ __launch_bounds__(sig_nw(KD) * 64, SPMF_SIG3_WPS) void sigdot3_kernel(
     int NP, int NQ, const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ out, float sign,
     double* __restrict__ esum, int atomic_out, const float* __restrict__ bias, float* __restrict__ out2,
     const int32_t* __restrict__ out_rows, int accumulate, const float* __restrict__ p_scale) {
   static_assert(KD == 32 || KD == 64, "sigdot3: K padded to 32 or 64");
-  constexpr int KS = KD / 16, MT = KD / 32, NW = kSigNW, NT = NW * 64;
+  constexpr int KS = KD / 16, MT = KD / 32, NW = sig_nw(KD), NT = NW * 64;
   constexpr int PITCH = KD * 2 + 16;            // bytes per LDS row; 144 (KD 64) / 80 (KD 32): the 16 rows of a
                                                 // ds_read_b128 service group cover all 64 banks
   constexpr int IMG = kQT3 * PITCH;
@@ -739,30 +740,38 @@ __global__ __launch_bounds__(kSigNW * 64, SPMF_SIG3_WPS) void sigdot3_kernel(
 // (two waves per SIMD by registers: 8 waves per CU)
 int expdot3_rows_per_wg() { return kExpNW * 32; }
 int expdot3_wgs_per_cu() { return (8 / kExpNW) < (kExpNBUF == 2 ? 1 : 2) ? (8 / kExpNW) : (kExpNBUF == 2 ? 1 : 2); }
-int sigdot3_rows_per_wg() { return kSigNW * 32; }
-int sigdot3_wgs_per_cu() { return 8 / kSigNW; }
+int sigdot3_rows_per_wg(int KD) { return sig_nw(KD) * 32; }
+int sigdot3_wgs_per_cu(int KD) { return 8 / sig_nw(KD); }
 
 // (Z, W)-type launch: bias on the Q rows (bias_q); (W, Z)-type: bias on the P rows (bias_p).
 bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
-  // (KD = 64 compiles but spills at two waves per SIMD: not routed until it fits; dense.hip covers it)
-  if (KD != 32 || a.act != 1 || a.est || (a.bias_p && a.bias_q)) return false;
+  if ((KD != 32 && KD != 64) || a.act != 1 || a.est || (a.bias_p && a.bias_q)) return false;
   const int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
   if (chunks > 1 && !a.atomic_out) return false;
   if (a.p_scale && a.out_rows) return false;      // (p_scale is indexed by the P row, not the output row)
-  const int nbx = (a.NP + kSigNW * 32 - 1) / (kSigNW * 32);
+  const int nw = sig_nw(KD);
+  const int nbx = (a.NP + nw * 32 - 1) / (nw * 32);
   const bool bq = a.bias_q != nullptr;
   const float* bias = bq ? a.bias_q : a.bias_p;
   const bool es = a.esum != nullptr, cs = a.out2 != nullptr;
   const int epl = a.e_planes == 3 ? 3 : 2;
-#define SPMF_SIG3(BQ_, ES_, CS_, EPL_)                                                                     \
-  hipLaunchKernelGGL((sigdot3_kernel<32, BQ_, ES_, CS_, EPL_>), dim3(nbx, chunks), dim3(kSigNW * 64), 0, st, a.NP, a.NQ, \
-                     a.P, a.Q, a.out, a.sign, a.esum, a.atomic_out, bias, a.out2, a.out_rows, a.accumulate,  \
-                     a.p_scale)
-  // the two shapes the step uses, and one general form for any other caller
-  if (bq && es && !cs && epl == 3) SPMF_SIG3(true, true, false, 3);
-  else if (!bq && !es && cs && epl == 2) SPMF_SIG3(false, false, true, 2);
-  else if (bq) SPMF_SIG3(true, true, true, 3);
-  else SPMF_SIG3(false, true, true, 3);
+#define SPMF_SIG3(KD_, BQ_, ES_, CS_, EPL_)                                                                  \
+  hipLaunchKernelGGL((sigdot3_kernel<KD_, BQ_, ES_, CS_, EPL_>), dim3(nbx, chunks), dim3(sig_nw(KD_) * 64), 0, \
+                     st, a.NP, a.NQ, a.P, a.Q, a.out, a.sign, a.esum, a.atomic_out, bias, a.out2, a.out_rows,  \
+                     a.accumulate, a.p_scale)
+  // the two shapes the step uses; KD = 32 also has one general form for any other caller (at KD = 64 the
+  // general form spills at two waves per SIMD: not built, the caller falls back to dense.hip)
+  const bool zw = bq && es && !cs && epl == 3, wz = !bq && !es && cs && epl == 2;
+  if (KD == 64) {
+    if (zw) SPMF_SIG3(64, true, true, false, 3);
+    else if (wz) SPMF_SIG3(64, false, false, true, 2);
+    else return false;
+    return true;
+  }
+  if (zw) SPMF_SIG3(32, true, true, false, 3);
+  else if (wz) SPMF_SIG3(32, false, false, true, 2);
+  else if (bq) SPMF_SIG3(32, true, true, true, 3);
+  else SPMF_SIG3(32, false, true, true, 3);
 #undef SPMF_SIG3
   return true;
 }

@@ -102,13 +102,13 @@ void launch_expdot(int KD, const ExpdotArgs& a, hipStream_t st);
 // dense3.hip: the same operator (act 0, KD = 64, no biases / E store) on the bf16 matrix cores with
 // three-way split operands; false = this shape is not covered (use launch_expdot)
 bool launch_expdot3(int KD, const ExpdotArgs& a, hipStream_t st);
-// dense3.hip: the sigmoid / softplus operator (act 1: Bernoulli and mixed columns, KD = 32 or 64, one of
+// dense3.hip: the sigmoid / softplus operator (act 1: Bernoulli and mixed columns, KD = 32 or 64 (64: the step's two launch shapes only), one of
 // bias_p / bias_q, out2, out_rows; no E store) on the same bf16x3 operands; false = not covered
 bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st);
 int expdot3_rows_per_wg();
 int expdot3_wgs_per_cu();
-int sigdot3_rows_per_wg();
-int sigdot3_wgs_per_cu();
+int sigdot3_rows_per_wg(int KD);
+int sigdot3_wgs_per_cu(int KD);
 void launch_estdot(int KD, int NQ, int NP, int64_t ldE, const float* est, const float* P, float* out, float sign,
                    float* out2, const int32_t* out_rows, hipStream_t st);
 void launch_compact_rows(int n, int KD, const int32_t* cols, const float* Vp, const float* phi, float* Vb,
