@@ -441,9 +441,11 @@ class StepRunner:
                                               bool(getattr(all_reduce, "graph_safe", False)))
         self.max_graphs = max_graphs
         # batches with more stored entries than this run the SAME device-gated step eagerly: the
-        # step is then GPU-bound (launches queue ahead of it) and a replayed hipGraph is slower than
-        # the plain launches (122 880-row shard of C3, 1.25e7 entries: 0.542 ms replayed, 0.516 eager)
-        self.graph_max_nnz = 8_000_000
+        # step is then GPU-bound (launches queue ahead of it) and a replayed hipGraph is no faster than
+        # the plain launches, mostly slower (tools/graph_threshold_sweep.py on C3 minibatches,
+        # profiles/r04_graph_threshold_sweep.txt: 2.3e6 entries 0.265 replayed / 0.269 eager, 4.5e6
+        # 0.324 / 0.316, 1.25e7 0.581 / 0.571 ms); the replay pays for launch-bound steps (C1 / C2 sizes)
+        self.graph_max_nnz = 2_500_000
         self.graphs = {}           # key -> (graph, workspace ptr, pinned refs)
         self.seen = {}
         self.pool = None

@@ -15,7 +15,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out+'/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'].split('(')[0]
-        if 'expdot' not in k: continue
+        if 'expdot' not in k and 'sigdot' not in k: continue
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in agg.items():
     print(k)
