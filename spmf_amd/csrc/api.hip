@@ -58,9 +58,6 @@ struct spmf_ctx {
   float* est = nullptr;
   int64_t est_rows = 0;           // rows per chunk of the bound workspace
   int e_once = 1;                 // SPMF_DENSE_E_ONCE=0: recompute E in a second launch instead
-  int sigfused = 0;               // SPMF_SIG_FUSED=1: the sigmoid sums at KP = 32 in ONE kernel (dense3f.hip: the sigmoid
-                                  // computed once, both contractions) instead of the two sigdot3 launches
-  float* sfs = nullptr;           // its scratch (pre-split planes of z) in the workspace
   int fuse_rows = -1;             // dense-term contexts: one fused row pass + dense-kernel epilogue instead of
                                   // encode sweep -> dense -> stored-cell sweep.  -1 = where it measured faster:
                                   // the sigmoid forms at KP = 32 (C5 row launches 0.97 -> 0.84 ms); NOT the exp
@@ -149,7 +146,7 @@ static size_t var_size(const spmf_ctx* c, int i) {
 }
 
 struct Carve {
-  size_t acc, dacc, dprep, ppart, putau, Ap, Vp, phi, dbias, Vb, bb, z, gzs, gzd, est, sfs, total;
+  size_t acc, dacc, dprep, ppart, putau, Ap, Vp, phi, dbias, Vb, bb, z, gzs, gzd, est, total;
 };
 // Small batches run all S draws in ONE launch per kernel (gridDim.y = S): the per-draw tables and
 // row outputs then exist S times.  Only for the linear Poisson decoder, only while the S table
@@ -239,8 +236,6 @@ static Carve carve(const spmf_ctx* c, int64_t rows, int S) {
   k.est = o;
   if (uses_e_buffer(c))
     o += al((size_t)((D + 31) / 32) * 32 * (size_t)est_chunk_rows(c, rows) * sizeof(float));
-  k.sfs = o;
-  if (c->sigfused && uses_sig3(c) && c->KP == 32) o += al(sigfused3_scratch_bytes(rows));
   k.total = o;
   return k;
 }
@@ -272,7 +267,6 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   if (const char* e = getenv("SPMF_DENSE_E_ONCE")) c->e_once = e[0] != '0';
   if (const char* e = getenv("SPMF_DENSE_BF16X3")) c->dense3 = e[0] != '0';
   if (const char* e = getenv("SPMF_FUSE_ROWS")) c->fuse_rows = e[0] != '0' ? 1 : 0;
-  if (const char* e = getenv("SPMF_SIG_FUSED")) c->sigfused = e[0] != '0' ? 1 : 0;
   *out = c;
   return SPMF_OK;
 }
@@ -386,7 +380,6 @@ static int bind_ws(spmf_ctx* c, int64_t rows, int S) {
   c->gzs = (float*)(c->ws + k.gzs);
   c->gzd = (float*)(c->ws + k.gzd);
   c->est = uses_e_buffer(c) ? (float*)(c->ws + k.est) : nullptr;
-  c->sfs = (c->sigfused && uses_sig3(c) && c->KP == 32) ? (float*)(c->ws + k.sfs) : nullptr;
   c->est_rows = est_chunk_rows(c, rows);
   c->ws_rows = rows;
   c->ws_S = S;
@@ -572,14 +565,6 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         lbias = c->bb;
         orows = c->bcols;
       }
-      if (c->sfs) {
-        // ONE kernel: sigmoid once, both contractions (dense3f.hip); 512 P rows per workgroup, two per CU
-        const int rpw = sigfused3_rows_per_wg();
-        const int fc = pick_chunks((int)((ct->n_rows + rpw - 1) / rpw), (Dd + 127) / 128, 512, 16);
-        SigFusedArgs fa{(int)ct->n_rows, Dd, c->z, Wd, lbias, c->gzs, -1.f, rscale, dacc + 3, gVp, gphi_acc, orows,
-            -1.f, fc, c->sfs};
-        launch_sigfused3(KP, fa, st);
-      } else {
       // Two waves per SIMD by registers: chunk counts that fill whole rounds of the resident workgroups.
       const int zt = (Dd + 127) / 128, wt = (int)((ct->n_rows + 127) / 128);
       const int rpw = sigdot3_rows_per_wg(KP), slots = 256 * sigdot3_wgs_per_cu(KP);
@@ -593,7 +578,6 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       launch_sigdot3(KP, ez, st);   // gzs_b -= xi_b sum_d sigmoid(l_bd) V'_d ; dacc[3] = sum softplus
       ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 1, lbias, nullptr, gphi_acc, orows};
       launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b sigmoid z_b ; gphi_d -= sum_b sigmoid
-      }
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
     } else if (ct->n_rows > 0 && [&]() {
       // Poisson log_transform on the bf16x3 exp kernels with a packed entry stream: ONE fused row pass

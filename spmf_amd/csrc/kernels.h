@@ -107,27 +107,6 @@ bool launch_expdot3(int KD, const ExpdotArgs& a, hipStream_t st);
 bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st);
 int expdot3_rows_per_wg();
 int expdot3_wgs_per_cu();
-// dense3f.hip: both contractions of the sigmoid sums in ONE kernel (sigmoid computed once), K padded to 32:
-//   out[p] += sign * p_scale[p] * sum_q E_pq Q_q ; gV[out_rows[q]] += sign2 * sum_p E_pq P_p ;
-//   gphi[out_rows[q]] += sign2 * sum_p E_pq ; esum += sum softplus.   E = sigmoid(<P_p, Q_q> + bias_q[q])
-struct SigFusedArgs {
-  int NP, NQ;
-  const float *P, *Q;        // [NP,32], [NQ,32]
-  const float* bias_q;       // [NQ] or null
-  float* out;                // [NP,32], accumulated into
-  float sign;
-  const float* p_scale;      // [NP] or null
-  double* esum;              // may be null
-  float* gV;                 // [*,32] rows addressed through out_rows
-  float* gphi;               // may be null
-  const int32_t* out_rows;   // [NQ] or null (identity)
-  float sign2;
-  int q_chunks;              // gridDim.y; > 1: out is added with float atomics
-  void* scratch;             // sigfused3_scratch_bytes(NP) bytes: the pre-split planes of P
-};
-bool launch_sigfused3(int KD, const SigFusedArgs& a, hipStream_t st);
-size_t sigfused3_scratch_bytes(int64_t rows);
-int sigfused3_rows_per_wg();
 int sigdot3_rows_per_wg(int KD);
 int sigdot3_wgs_per_cu(int KD);
 void launch_estdot(int KD, int NQ, int NP, int64_t ldE, const float* est, const float* P, float* out, float sign,

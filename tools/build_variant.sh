@@ -10,7 +10,7 @@ out=$root/spmf_amd/variants
 tmp=$(mktemp -d)
 mkdir -p $out
 pids=()
-for f in api prep row_pass col_pass finish stats dense dense3 dense3f dense_ll surrogate; do
+for f in api prep row_pass col_pass finish stats dense dense3 dense_ll surrogate; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -DSPMF_BUILD --offload-arch=gfx950 \
       -Wno-unused-function -I$root/include -I$src $extra -c $src/$f.hip -o $tmp/$f.o &
   pids+=($!)
