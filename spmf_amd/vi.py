@@ -427,7 +427,11 @@ class StepRunner:
     step is captured into a hipGraph (torch.cuda.CUDAGraph: the library's
     launches go to torch's capturing stream) and replayed from then on.  Small
     batches are launch-bound (about 40 launches per step), which is what the
-    graph removes; large ones lose nothing."""
+    graph removes; batches above ``graph_max_nnz`` stored entries are GPU-bound
+    and run the same device-gated step as plain launches (a replay is no faster
+    there).  With ``all_reduce`` (a dist.ShardReducer) the step is this rank's
+    share of a row-sharded step; the collective is part of the captured graph
+    when the reducer carries the library's RCCL communicator."""
 
     def __init__(self, model, opt, dataset_rows, sample_size, use_graph=True, max_graphs=64,
                  all_reduce=None, seed=None):
