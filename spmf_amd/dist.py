@@ -101,9 +101,10 @@ class ShardReducer:
     ``comm``: a LibraryComm moves the packed fp32 accumulators with the library's
     own RCCL communicator; without one (default) torch.distributed does."""
 
-    def __init__(self, group=None, comm=None, overlap_prior=None):
+    def __init__(self, group=None, comm=None, overlap_prior=None, capture=None):
         self.group = group
         self.comm = comm
+        self.capture = capture         # None: see graph_safe
         self.active = dist.is_initialized() or comm is not None   # also with one rank (exercises the transport)
         self.world = dist.get_world_size(group) if dist.is_initialized() else (comm.world if comm else 1)
         self.rank = dist.get_rank(group) if dist.is_initialized() else (comm.rank if comm else 0)
@@ -122,8 +123,14 @@ class ShardReducer:
     def graph_safe(self):
         """The step's collective may be captured in a hipGraph: spmf_allreduce is a plain
         stream-ordered ncclAllReduce on the capturing stream.  torch.distributed's own
-        collectives (and the host-staged gloo rehearsal) stay eager."""
-        return self.comm is not None or not self.active
+        collectives (and the host-staged gloo rehearsal) stay eager.  The capture has only
+        ever run with ONE rank (no multi-GPU box so far), so with more ranks it is opt-in
+        (``capture=True``): the default there is the same device-gated step as plain launches,
+        which costs a few percent on launch-bound batches and nothing on GPU-bound ones
+        (profiles/r04_graph_threshold_sweep.txt)."""
+        if self.capture is not None:
+            return bool(self.capture) and (self.comm is not None or not self.active)
+        return (self.comm is not None and self.world == 1) or not self.active
 
     def sum_(self, acc):
         """The step's one collective, nothing else (no totals, no host read)."""
