@@ -37,8 +37,9 @@ def _last_json(text):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("transport", ["lib", "torch"])
 def test_torchrun_one_rank_rccl_matches_the_plain_run(transport):
-    """transport "torch": the driver's own launch (no SPMF_BENCH_COMM: torch.distributed's RCCL
-    process group moves the accumulators); "lib": the library's communicator (spmf_allreduce)."""
+    """transport "lib": the driver's own launch (no SPMF_BENCH_COMM: since round 4 the library's
+    communicator, spmf_allreduce, moves the accumulators); "torch": SPMF_BENCH_COMM=torch,
+    torch.distributed's RCCL process group."""
     args = ["bench.py", "--gpus", "1", "--workload", "small", "--steps", "3", "--warmup", "1",
             "--no-cpu-baseline", "--no-extras"]
     env = dict(os.environ)
@@ -49,8 +50,8 @@ def test_torchrun_one_rank_rccl_matches_the_plain_run(transport):
                            text=True, timeout=280)
     assert plain.returncode == 0, plain.stderr[-2000:]
     ref = _last_json(plain.stdout)
-    if transport == "lib":
-        env["SPMF_BENCH_COMM"] = "lib"
+    if transport == "torch":
+        env["SPMF_BENCH_COMM"] = "torch"
     else:
         env.pop("SPMF_BENCH_COMM", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
@@ -61,6 +62,8 @@ def test_torchrun_one_rank_rccl_matches_the_plain_run(transport):
     assert out["metric"] == ref["metric"] == "elbo_steps_per_sec"
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1
     assert out["config"]["parallelism"] == "row-shard dp1" and out["scaling"] == "strong"
+    assert ("library RCCL" if transport == "lib" else "torch.distributed") in out["config"]["allreduce_transport"]
+    assert ref["config"]["allreduce_transport"] is None
     assert out["value"] > 0 and math.isfinite(out["ms_per_step"])
     assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
     # the same matrix, the same seeded draw: the all-reduced step gives the same energy
