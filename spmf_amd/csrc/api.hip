@@ -187,9 +187,14 @@ static bool uses_sig3(const spmf_ctx* c) {
   const int lik = likelihood_code(c);
   return c->dense3 && (lik == 2 || lik == 3) && (c->KP == 32 || c->KP == 64);
 }
+// The Poisson exp decoder at KP = 32 (K <= 32: the reference's scRNA script runs P = 3,
+// bin/factorize_scrnaseq_counts.py) on the bf16x3 form as well: dense3.hip's sigdot3 family with ACT 0.
+static bool uses_exp3_32(const spmf_ctx* c) {
+  return c->dense3 && likelihood_code(c) == 1 && c->KP == 32;
+}
 static bool uses_e_buffer(const spmf_ctx* c) {
   return (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once &&
-         likelihood_code(c) != 4 && !uses_dense3(c) && !uses_sig3(c);
+         likelihood_code(c) != 4 && !uses_dense3(c) && !uses_sig3(c) && !uses_exp3_32(c);
 }
 
 // Q chunks (gridDim.y) of a P-stationary dense launch of nbx workgroup columns over ntiles Q tiles on
@@ -640,6 +645,19 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr,
             nullptr};
         launch_expdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+      } else if (uses_exp3_32(c) && !compact) {
+        // the same two launches at K padded to 32 (sigdot3 family, ACT 0); chunk counts that fill whole
+        // rounds of the resident workgroups
+        const int zt = (Dd + 127) / 128, wt = (int)((ct->n_rows + 127) / 128);
+        const int rpw = sigdot3_rows_per_wg(KP), slots = 256 * sigdot3_wgs_per_cu(KP);
+        const int zc = pick_chunks((int)((ct->n_rows + rpw - 1) / rpw), zt, slots, 16);
+        const int wc = pick_chunks((Dd + rpw - 1) / rpw, wt, slots, 256);
+        if (zc > 1) launch_zero(c->gzd, (size_t)ct->n_rows * KP * sizeof(float), st);
+        ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, zc, zc > 1 ? 1 : 0, 0, nullptr, nullptr,
+            nullptr, nullptr};
+        launch_sigdot3(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E ; dacc[4]: saturation
+        ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 0, nullptr, nullptr, nullptr, nullptr};
+        launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
       } else if (c->est && act != 2) {   // (act 2: E carries exp(X) too, its row sums are not the d/dphi sums)
         // E once: per row chunk, the Z-stationary kernel keeps E (exp, or the sigmoid of the
         // Bernoulli logits) and the second contraction (gV'_d -= sum_b E_bd z_b; Bernoulli:

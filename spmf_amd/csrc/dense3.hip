@@ -405,19 +405,44 @@ constexpr int kSigValu = SPMF_SIG3_VALU;
 // where every term of the sum has one sign (Q = z rows, z >= 0); where the Q rows have mixed signs (Q =
 // V' under the Normal priors of bernoulli.py:187-216) a sum can cancel to a small fraction of its terms
 // and the entry-wise 1e-5 needs the third plane (2^-26).
-template <int KD, bool EDGE, bool BQ, bool ESUM, bool CSUM, int EPL>
+// ACT 1: the sigmoid / softplus operator described above.  ACT 0: the exp operator of expdot3 (Poisson,
+// log_transform decoder: E = exp(min(X, kYSat)), esum = sum E, no bias) at K padded to 32, where expdot3
+// itself (K padded to 64) does not apply: a1 b1 and the five small products in separate accumulators as there
+// (exp amplifies the absolute error of X), E in two planes (every term of both sums is positive).
+template <int KD, int ACT, bool EDGE, bool BQ, bool ESUM, bool CSUM, int EPL>
 __device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ img, uint32_t lds_tr_base,
                                               const float* __restrict__ bq, float bp,
                                               const bf16x8 (&pb)[KD / 16][3], f32x16 (&acc)[KD / 32],
-                                              float& es_tile, float& colsum, int r, int h, int q0, int NQ,
-                                              bool p_in) {
+                                              float& es_tile, float& colsum, float& xmax, int r, int h, int q0,
+                                              int NQ, bool p_in) {
   constexpr int KS = KD / 16, MT = KD / 32, NSUB = kQT3 / 32;
   constexpr int PITCH = KD * 2 + 16;
   constexpr int IMG = kQT3 * PITCH;
-  f32x16 x[NSUB];
+  f32x16 x[NSUB], xlo[ACT == 0 ? NSUB : 1];
   u32x4 eb[NSUB][2][EPL];          // [sub][s2][plane]
   auto productA = [&](int sub) {
     f32x16 xi;
+    if (ACT == 0) {
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 xl = zero16;
+      xi = zero16;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          a[pl] = *reinterpret_cast<const bf16x8*>(img + pl * IMG + (32 * sub + r) * PITCH + (16 * s + 8 * h) * 2);
+        xl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], pb[s][0], xl, 0, 0, 0);
+        xl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], pb[s][1], xl, 0, 0, 0);
+        xl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], pb[s][2], xl, 0, 0, 0);
+        xl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], pb[s][0], xl, 0, 0, 0);
+        xl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], pb[s][1], xl, 0, 0, 0);
+        xi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], pb[s][0], xi, 0, 0, 0);
+      }
+      x[sub] = xi;
+      xlo[ACT == 0 ? sub : 0] = xl;
+      return;
+    }
     if (BQ) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -445,6 +470,28 @@ __device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ i
   };
   auto sigsplit = [&](int sub) {
     constexpr float kLog2e = 1.4426950408889634f;
+    if (ACT == 0) {
+      f32x2 part2 = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        float x0 = x[sub][i] + xlo[ACT == 0 ? sub : 0][i], x1 = x[sub][i + 1] + xlo[ACT == 0 ? sub : 0][i + 1];
+        if (EDGE) {
+          const int qa = q0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
+          x0 = (p_in && qa < NQ) ? x0 : -INFINITY;          // exp -> 0, and never the maximum
+          x1 = (p_in && qa + 1 < NQ) ? x1 : -INFINITY;
+        }
+        xmax = __builtin_fmaxf(xmax, __builtin_fmaxf(x0, x1));
+        const float e0 = __builtin_amdgcn_exp2f(fminf(x0 * kLog2e, kYSat * kLog2e));
+        const float e1 = __builtin_amdgcn_exp2f(fminf(x1 * kLog2e, kYSat * kLog2e));
+        part2[0] += e0;
+        part2[1] += e1;
+        const uint32_t p1 = pack_bf16(e0, e1);
+        eb[sub][i >> 3][0][(i & 7) >> 1] = p1;
+        eb[sub][i >> 3][1][(i & 7) >> 1] = pack_bf16(e0 - bf16_lo(p1), e1 - bf16_hi(p1));
+      }
+      es_tile += part2[0] + part2[1];
+      return;
+    }
     float pm0 = 0.f, pm1 = 0.f, dp0 = 1.f, dp1 = 1.f, cs0 = 0.f, cs1 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
@@ -567,12 +614,13 @@ __device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ i
 #endif
 // KD = 64: the staged Q tile is 110 KB (two buffers x three planes), one workgroup per CU: eight waves, like expdot3
 __host__ __device__ constexpr int sig_nw(int KD) { return KD == 64 ? 8 : SPMF_SIG3_NW; }
-template <int KD, bool BQ, bool ESUM, bool CSUM, int EPL>
+template <int KD, bool BQ, bool ESUM, bool CSUM, int EPL, int ACT = 1>
 __global__ __launch_bounds__(sig_nw(KD) * 64, SPMF_SIG3_WPS) void sigdot3_kernel(
     int NP, int NQ, const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ out, float sign,
     double* __restrict__ esum, int atomic_out, const float* __restrict__ bias, float* __restrict__ out2,
     const int32_t* __restrict__ out_rows, int accumulate, const float* __restrict__ p_scale) {
   static_assert(KD == 32 || KD == 64, "sigdot3: K padded to 32 or 64");
+  static_assert(ACT == 1 || (EPL == 2 && !BQ && !CSUM), "the exp form: two planes of E, no bias, no row sums");
   constexpr int KS = KD / 16, MT = KD / 32, NW = sig_nw(KD), NT = NW * 64;
   constexpr int PITCH = KD * 2 + 16;            // bytes per LDS row; 144 (KD 64) / 80 (KD 32): the 16 rows of a
                                                 // ds_read_b128 service group cover all 64 banks
@@ -623,6 +671,7 @@ __global__ __launch_bounds__(sig_nw(KD) * 64, SPMF_SIG3_WPS) void sigdot3_kernel
     }
   double es = 0.0;
   float colsum = 0.f, coltot = 0.f;
+  float xmax = 0.f;                 // ACT 0: largest exponent this lane saw (saturation at kYSat)
 
   float4 st0[NPC], st1[NPC];
   float bst = 0.f;
@@ -680,12 +729,12 @@ __global__ __launch_bounds__(sig_nw(KD) * 64, SPMF_SIG3_WPS) void sigdot3_kernel
     float es_tile = 0.f;
     const uint32_t trb = lds0 + buf * 3 * IMG + tr_lane;
     if (p_edge || q0 + kQT3 > NQ)
-      sigdot3_tile<KD, true, BQ, ESUM, CSUM, EPL>(&lds[buf][0][0], trb, bqs[buf], bp, pb, acc, es_tile, colsum, r, h,
-                                                  q0, NQ, p < NP);
+      sigdot3_tile<KD, ACT, true, BQ, ESUM, CSUM, EPL>(&lds[buf][0][0], trb, bqs[buf], bp, pb, acc, es_tile, colsum,
+                                                       xmax, r, h, q0, NQ, p < NP);
     else
-      sigdot3_tile<KD, false, BQ, ESUM, CSUM, EPL>(&lds[buf][0][0], trb, bqs[buf], bp, pb, acc, es_tile, colsum, r, h,
-                                                   q0, NQ, true);
-    if (ESUM) es += (double)es_tile;
+      sigdot3_tile<KD, ACT, false, BQ, ESUM, CSUM, EPL>(&lds[buf][0][0], trb, bqs[buf], bp, pb, acc, es_tile, colsum,
+                                                        xmax, r, h, q0, NQ, true);
+    if (ESUM || ACT == 0) es += (double)es_tile;
     if (((tile - tile0) % FOLD) == FOLD - 1) {             // block-uniform: close the run
       coltot += colsum;
       colsum = 0.f;
@@ -730,9 +779,14 @@ __global__ __launch_bounds__(sig_nw(KD) * 64, SPMF_SIG3_WPS) void sigdot3_kernel
     cs += __shfl_xor(cs, 32);                         // the two lane halves hold disjoint q rows
     if (h == 0 && p < NP && cs != 0.f) atomicAdd(&out2[prow], sign * cs);
   }
-  if (ESUM && esum) {
+  if ((ESUM || ACT == 0) && esum) {
     const double tsum = block_sum(es, red);
     if (t == 0) atomicAdd(esum, tsum);
+    if (ACT == 0) {
+      // esum[1] = dacc[4]: workgroups in which an exponent exceeded kYSat and was saturated there
+      const double ts = block_sum(xmax > kYSat ? 1.0 : 0.0, red);
+      if (t == 0 && ts != 0.0) atomicAdd(esum + 1, 1.0);
+    }
   }
 }
 
@@ -745,6 +799,17 @@ int sigdot3_wgs_per_cu(int KD) { return 8 / sig_nw(KD); }
 
 // (Z, W)-type launch: bias on the Q rows (bias_q); (W, Z)-type: bias on the P rows (bias_p).
 bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
+  if (a.act == 0) {
+    // the exp operator at K padded to 32 (launch_expdot3 covers 64): no biases, no row sums, no E store
+    if (KD != 32 || a.est || a.bias_p || a.bias_q || a.out2 || a.out_rows) return false;
+    const int chunks0 = a.q_chunks < 1 ? 1 : a.q_chunks;
+    if (chunks0 > 1 && !a.atomic_out) return false;
+    const int nbx0 = (a.NP + sig_nw(32) * 32 - 1) / (sig_nw(32) * 32);
+    hipLaunchKernelGGL((sigdot3_kernel<32, false, false, false, 2, 0>), dim3(nbx0, chunks0), dim3(sig_nw(32) * 64), 0,
+                       st, a.NP, a.NQ, a.P, a.Q, a.out, a.sign, a.esum, a.atomic_out, nullptr, nullptr, nullptr,
+                       a.accumulate, a.p_scale);
+    return true;
+  }
   if ((KD != 32 && KD != 64) || a.act != 1 || a.est || (a.bias_p && a.bias_q)) return false;
   const int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
   if (chunks > 1 && !a.atomic_out) return false;

@@ -35,9 +35,14 @@ CASES = [(37, 23, 3, 2, 0.3, True), (150, 90, 8, 1, 0.1, True), (260, 200, 32, 1
          (130, 70, 50, 1, 0.1, False), (300, 129, 64, 2, 0.05, True)]
 
 
-@pytest.mark.parametrize("B,D,K,S,density,scale_rows", CASES)
-def test_log_transform_energy_and_grads(B, D, K, S, density, scale_rows):
+@pytest.mark.parametrize("bf16x3", ["1", "0"])
+@pytest.mark.parametrize("B,D,K,S,density,scale_rows", CASES + [(1500, 700, 20, 1, 0.02, True)])
+def test_log_transform_energy_and_grads(monkeypatch, B, D, K, S, density, scale_rows, bf16x3):
+    """Both dense paths (read at spmf_ctx_create): the bf16x3 kernels (csrc/dense3.hip: expdot3 at K padded
+    to 64, the sigdot3 family's exp form at K padded to 32) and the exact-f32 MFMA kernels; the last case
+    spans several Q tiles and chunks."""
     from spmf_amd import PoissonFactorization
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", bf16x3)
     cfg, x, params = problem(B, D, K, S, 500 + B + K, density, scale_rows)
     pref, gref, _ = O.energy_and_grads(cfg, x, params)
     m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
@@ -62,6 +67,7 @@ def test_two_launch_form_still_matches_oracle(monkeypatch, B, D, K, S):
     exp launch instead of keeping it in HBM -- same oracle, same contract."""
     from spmf_amd import PoissonFactorization
     monkeypatch.setenv("SPMF_DENSE_E_ONCE", "0")
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", "0")        # (a switch of the exact-f32 kernels)
     cfg, x, params = problem(B, D, K, S, 900 + B + K, 0.05)
     pref, gref, _ = O.energy_and_grads(cfg, x, params)
     m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
@@ -74,11 +80,13 @@ def test_two_launch_form_still_matches_oracle(monkeypatch, B, D, K, S):
     assert_grads_entrywise(grads, gref, O.energy_grad_scales(cfg, x, params), 1e-5, "")
 
 
-def test_e_buffer_in_several_row_chunks():
-    """spmf_ctx_set_e_cap small enough that the rows go through the dense kernels in several
-    chunks (at C4 scale the Python class sizes the buffer for ONE chunk, so the chunk loop is
-    exercised here): 4000 rows with a 1 MiB cap = 3 chunks of 1408 / 1408 / 1184 rows."""
+def test_e_buffer_in_several_row_chunks(monkeypatch):
+    """spmf_ctx_set_e_cap small enough that the rows go through the exact-f32 dense kernels (the ones
+    that keep E: SPMF_DENSE_BF16X3=0) in several chunks (at C4 scale the Python class sizes the buffer for
+    ONE chunk, so the chunk loop is exercised here): 4000 rows with a 1 MiB cap = 3 chunks of
+    1408 / 1408 / 1184 rows."""
     from spmf_amd import PoissonFactorization, _lib
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", "0")
     B, D, K, S = 4000, 129, 64, 1
     cfg, x, params = problem(B, D, K, S, 4321, 0.03)
     pref, gref, _ = O.energy_and_grads(cfg, x, params)
@@ -172,11 +180,13 @@ def test_fit_reports_decoder_saturation(capsys):
     assert getattr(m2, "saturated_events", 0.0) == 0.0
 
 
-@pytest.mark.parametrize("B,D,S,ymax", [(300, 129, 2, 8.0), (700, 333, 1, 8.0), (513, 64, 1, 30.0),
-                                        (90, 1000, 1, 45.0), (90, 1000, 1, 60.0)])
-def test_bf16x3_dense_path_matches_oracle(monkeypatch, B, D, S, ymax):
-    """The default dense path at K = 64 (SPMF_DENSE_BF16X3, read at spmf_ctx_create): the exp sums
-    on the bf16 matrix cores with three-way split operands (csrc/dense3.hip).  Same oracle,
+@pytest.mark.parametrize("B,D,S,ymax,K", [(300, 129, 2, 8.0, 64), (700, 333, 1, 8.0, 64), (513, 64, 1, 30.0, 64),
+                                          (90, 1000, 1, 45.0, 64), (90, 1000, 1, 60.0, 64),
+                                          (700, 333, 1, 8.0, 24), (513, 64, 1, 30.0, 32), (90, 1000, 1, 45.0, 17)])
+def test_bf16x3_dense_path_matches_oracle(monkeypatch, B, D, S, ymax, K):
+    """The default dense path (SPMF_DENSE_BF16X3, read at spmf_ctx_create): the exp sums on the bf16
+    matrix cores with three-way split operands (csrc/dense3.hip: expdot3 at K padded to 64, the exp form of
+    the sigdot3 family at K padded to 32).  Same oracle,
     same 1e-5 contract, gradients entry by entry; exponents up to 60 -- exp amplifies the absolute
     error of <z, eta v>, and there the exact-f32 MFMA kernels themselves are at 1.6 - 2.3e-5 of
     the yardstick (tools/b3_err.py) while this path, which keeps a1 b1 and
@@ -184,7 +194,6 @@ def test_bf16x3_dense_path_matches_oracle(monkeypatch, B, D, S, ymax):
     32 / 64 / 256 tile edges; several Q chunks in the W-stationary launch (D = 1000)."""
     from spmf_amd import PoissonFactorization
     monkeypatch.setenv("SPMF_DENSE_BF16X3", "1")
-    K = 64
     cfg, x, params = problem(B, D, K, S, 2900 + B + D, 0.05)
     params["v"] *= ymax / 8.0                  # problem() scaled the largest exponent to 8
     pref, gref, _ = O.energy_and_grads(cfg, x, params)
