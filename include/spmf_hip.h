@@ -147,9 +147,11 @@ typedef struct spmf_counts {
   const uint32_t* pc_ent;
 } spmf_counts;
 
-/* ABI version of this header: 3.  (2 -> 3: spmf_counts.struct_size replaces a reserved slot
- * and is verified; pc_pad / ent / pc_ent are validated.)  A binding checks it at load time. */
-#define SPMF_ABI_VERSION 3
+/* ABI version of this header: 4.  (2 -> 3: spmf_counts.struct_size replaces a reserved slot
+ * and is verified; pc_pad / ent / pc_ent are validated.  3 -> 4: the device layout builder
+ * spmf_layout_* added; no struct or existing signature changed, a caller written for 3 runs
+ * unchanged.)  A binding checks it at load time. */
+#define SPMF_ABI_VERSION 4
 int spmf_version(void);
 
 /* sizeof(spmf_counts) / sizeof(spmf_sur_var) / sizeof(spmf_adam_var) as this
@@ -204,6 +206,58 @@ int spmf_counts_stats(spmf_ctx* ctx, int64_t n_rows, const int32_t* row_ptr,
                       const int32_t* col_idx, const float* val, double* colsum,
                       double* colnnz, float* row_sum, double* row_lgamma,
                       void* stream);
+
+/* ---- device layout builder ------------------------------------------- */
+/* Builds everything of a spmf_counts that is derived from the CSR arrays of one row shard
+ * (the reference hands its model a dense [B,D] batch, poisson.py:170,182; a caller of this
+ * library hands it CSR and gets the row-panel CSC, the column-pass work items and the packed
+ * entry streams back): on the device, stream-ordered, deterministic (the same input gives the
+ * same bytes), into ONE caller-owned buffer.
+ *
+ *   spmf_layout_sizes   bytes of the layout buffer (kept as long as the spmf_counts is used)
+ *                       and of the scratch buffer (free after the call returns)
+ *   spmf_layout_build   fills `layout`, then *out (zero-initialised by the callee; row_ptr /
+ *                       col_idx / val are the caller's arrays, lgamma_sum / row_scale / gval /
+ *                       pc_gval stay 0 / NULL: spmf_counts_stats and the model supply them) and
+ *                       *info.  Synchronises `stream` once, at the end, to read back the item
+ *                       count and the input checks.
+ *
+ * Input: canonical CSR of the shard -- row_ptr[0] == 0, row_ptr[n_rows] == nnz, non-decreasing,
+ * 0 <= col_idx < n_cols, no (row, column) pair stored twice (columns need not be sorted inside
+ * a row).  The first four are verified on the device (SPMF_E_ARG, nothing usable in *out).
+ * panel_rows >= 1 (spmf_amd/sparse.py balanced_panel_rows chooses it from K); col_split = 0 or
+ * the column split of spmf_ctx_set_column_split.  nnz < 2^31.
+ *
+ * Layout produced (what spmf_amd/sparse.py built with torch sorts until version 3 of
+ * this header; the two are compared array by array in tests/test_gpu_layout.py):
+ *   lists     entries ordered by (panel, column, row): pc_ptr, pc_row, pc_val with pc_pad = 64
+ *   items     every non-empty list cut into segments of <= info->segment entries (16 ... 256,
+ *             so that a panel offers a few thousand items), inside a panel ordered by column
+ *             half (col_split), then by descending length, ties in (column, segment) order
+ *   ent / pc_ent  when every stored value is an integer count in [0, 65535] and n_cols
+ *             (resp. panel_rows) <= 65536; NULL in *out otherwise
+ */
+typedef struct spmf_layout_info {
+  int32_t struct_size;            /* in: sizeof(spmf_layout_info) of the caller */
+  int32_t n_panels;
+  int32_t panel_rows;
+  int32_t segment;                /* longest work item */
+  int64_t n_items;
+  int32_t packed_ent;             /* 1: out->ent is set */
+  int32_t packed_pc_ent;          /* 1: out->pc_ent is set */
+  const int32_t* items_per_panel; /* [n_panels] device, inside `layout`: for max_items_per_panel of a panel range */
+  const int32_t* items_lower;     /* [n_panels] items of the lower column half (all of them without a split) */
+} spmf_layout_info;
+size_t spmf_sizeof_layout_info(void);
+int spmf_layout_sizes(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, int32_t panel_rows,
+                      size_t* layout_bytes, size_t* scratch_bytes);
+int spmf_layout_build(int device, int64_t n_rows, int64_t nnz, int32_t n_cols,
+                      const int32_t* row_ptr, const int32_t* col_idx, const float* val,
+                      int32_t panel_rows, int32_t col_split, void* layout, size_t layout_bytes,
+                      void* scratch, size_t scratch_bytes, spmf_counts* out,
+                      spmf_layout_info* info, void* stream);
+/* Message of the last failed spmf_layout_* call of the calling thread (host string). */
+const char* spmf_layout_last_error(void);
 
 /* ---- the hot path ------------------------------------------------------ */
 /* Phase 1: sparse data term for S draws.  Reads u,v,w,s (params[2,0,1,7])

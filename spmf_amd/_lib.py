@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPMF_LIB_PATH") or os.path.join(_HERE, "libspmf_hip.so")
 
 NVARS = 12
-ABI_VERSION = 3          # include/spmf_hip.h SPMF_ABI_VERSION
+ABI_VERSION = 4          # include/spmf_hip.h SPMF_ABI_VERSION
 VI_STATE_LEN = 16
 NPARTS = 14
 #: variable order of the C-ABI = the reference's var_list (poisson.py:403-539,572)
@@ -54,6 +54,14 @@ class CountsStruct(C.Structure):
     ]
 
 
+class LayoutInfo(C.Structure):
+    """struct spmf_layout_info"""
+    _fields_ = [("struct_size", C.c_int32), ("n_panels", C.c_int32), ("panel_rows", C.c_int32),
+                ("segment", C.c_int32), ("n_items", C.c_int64), ("packed_ent", C.c_int32),
+                ("packed_pc_ent", C.c_int32), ("items_per_panel", C.c_void_p),
+                ("items_lower", C.c_void_p)]
+
+
 PtrArray = C.c_void_p * NVARS
 
 
@@ -87,6 +95,14 @@ SIGNATURES = {
     "spmf_ctx_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "spmf_counts_stats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 7
                           + [C.c_void_p]),
+    "spmf_sizeof_layout_info": (C.c_size_t, []),
+    "spmf_layout_sizes": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "spmf_layout_build": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_size_t, C.POINTER(CountsStruct),
+                                    C.POINTER(LayoutInfo), C.c_void_p]),
+    "spmf_layout_last_error": (C.c_char_p, []),
     "spmf_data_pass": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int,
                                  PtrArray, C.c_void_p, C.c_void_p]),
     "spmf_acc_ptr": (C.c_void_p, [C.c_void_p]),
@@ -164,7 +180,7 @@ def load():
                         f"for {ABI_VERSION} (include/spmf_hip.h SPMF_ABI_VERSION): rebuild the library")
     # the ctypes mirrors must have the library's own struct sizes
     for fn, st in ((lib.spmf_sizeof_counts, CountsStruct), (lib.spmf_sizeof_sur_var, SurVar),
-                   (lib.spmf_sizeof_adam_var, AdamVar)):
+                   (lib.spmf_sizeof_adam_var, AdamVar), (lib.spmf_sizeof_layout_info, LayoutInfo)):
         if fn() != C.sizeof(st):
             raise SpmfError(f"{st.__name__}: ctypes mirror is {C.sizeof(st)} bytes, the library's "
                             f"struct {fn()} (include/spmf_hip.h and spmf_amd/_lib.py disagree)")

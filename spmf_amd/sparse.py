@@ -98,21 +98,20 @@ class SparseCounts:
         # multi-GPU overlap: work items of a panel sorted by column half first
         # (columns < col_split, then the rest); 0 = no split
         self.col_split = int(col_split)
-        self._build_panel_csc()
+        # the lists, the work items and the packed streams: the library's builder on the HIP
+        # device (csrc/layout.hip), the torch operators below for host-side tensors (CPU tests)
+        # or when SPMF_NATIVE_LAYOUT=0 asks for them (tests/test_gpu_layout.py compares the two)
+        self.native_layout = False
+        if dev.type == "cuda" and os.environ.get("SPMF_NATIVE_LAYOUT", "1") != "0":
+            self._build_native()
+        else:
+            self._build_panel_csc()
+            self._build_packed_rows()
         self.row_sum = None
         self.row_lgamma = None
         self.row_scale = None      # xi_b, set by PoissonFactorization
         self._xi_key = None
         self.gval = None           # g(x) = log(x/eta+1) per entry (log_transform only)
-        # packed copy of the CSR entries for the row pass (spmf_counts.ent): col << 16 | count,
-        # when the columns fit 16 bits and every stored value is an integer count below 65536
-        self.ent = None
-        if self.nnz > 0 and self.n_cols <= 65536 and os.environ.get("SPMF_PACKED_ENTRIES", "1") != "0":
-            v = self.val
-            if bool(((v >= 0) & (v <= 65535.0) & (v == torch.floor(v))).all()):
-                w = (self.col_idx.to(torch.int64) << 16) | v.to(torch.int64)
-                # bit pattern of a uint32 in an int32 tensor (torch has no uint32 arithmetic)
-                self.ent = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
         self.pc_gval = None
         self._g_key = None
         self._keep = []
@@ -152,6 +151,70 @@ class SparseCounts:
         col = nz[:, 1]
         val = t[mask].to(torch.float32)
         return cls(row_ptr, col, val, N, D, panel_rows, col_split, latent_dim)
+
+    def _build_native(self):
+        """spmf_layout_build (include/spmf_hip.h): one caller-owned buffer holds every derived
+        array; the attributes below are views into it."""
+        lib = _lib.load()
+        dev = self.device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        lb, sb = C.c_size_t(), C.c_size_t()
+
+        def ok(rc, what):
+            if rc != 0:
+                msg = lib.spmf_layout_last_error()
+                raise _lib.SpmfError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+        ok(lib.spmf_layout_sizes(idx, self.n_rows, self.nnz, self.n_cols, self.panel_rows,
+                                 C.byref(lb), C.byref(sb)), "spmf_layout_sizes")
+        with torch.cuda.device(idx):
+            layout = torch.empty(max(lb.value, 256), dtype=torch.uint8, device=dev)
+            scratch = torch.empty(max(sb.value, 256), dtype=torch.uint8, device=dev)
+            cs, info = _lib.CountsStruct(), _lib.LayoutInfo()
+            info.struct_size = C.sizeof(_lib.LayoutInfo)
+            ok(lib.spmf_layout_build(idx, self.n_rows, self.nnz, self.n_cols, self.row_ptr.data_ptr(),
+                                     self.col_idx.data_ptr(), self.val.data_ptr(), self.panel_rows,
+                                     self.col_split, layout.data_ptr(), layout.numel(),
+                                     scratch.data_ptr(), scratch.numel(), C.byref(cs), C.byref(info),
+                                     torch.cuda.current_stream(dev).cuda_stream), "spmf_layout_build")
+        del scratch
+        base = layout.data_ptr()
+
+        def view(ptr, n, dtype=torch.int32):
+            off = int(ptr) - base
+            return layout[off:off + 4 * n].view(dtype)
+
+        nP, D, nnz = int(info.n_panels), self.n_cols, self.nnz
+        assert nP == self.n_panels and int(info.panel_rows) == self.panel_rows
+        self._layout_buf = layout
+        self.pc_ptr = view(cs.pc_ptr, nP * (D + 1))
+        self.pc_row = view(cs.pc_row, nnz + PC_PAD)
+        self.pc_val = view(cs.pc_val, nnz + PC_PAD, torch.float32)
+        self.pc_pad = int(cs.pc_pad)
+        packed = os.environ.get("SPMF_PACKED_ENTRIES", "1") != "0"
+        self.pc_ent = view(cs.pc_ent, nnz + PC_PAD) if cs.pc_ent and packed else None
+        self.ent = view(cs.ent, nnz) if cs.ent and packed else None
+        n_items = int(info.n_items)
+        self.items = view(cs.items, 4 * n_items).view(n_items, 4)
+        self.item_ptr = view(cs.item_ptr, nP + 1)
+        self.item_mid = view(cs.item_mid, nP)
+        per_panel = view(info.items_per_panel, nP).to(torch.int64)
+        lower = view(info.items_lower, nP).to(torch.int64)
+        self.items_per_panel = per_panel
+        self.items_per_half = torch.stack([lower, per_panel - lower], 0)
+        self.segment = int(info.segment)
+        self.native_layout = True
+
+    def _build_packed_rows(self):
+        # packed copy of the CSR entries for the row pass (spmf_counts.ent): col << 16 | count,
+        # when the columns fit 16 bits and every stored value is an integer count below 65536
+        self.ent = None
+        if self.nnz > 0 and self.n_cols <= 65536 and os.environ.get("SPMF_PACKED_ENTRIES", "1") != "0":
+            v = self.val
+            if bool(((v >= 0) & (v <= 65535.0) & (v == torch.floor(v))).all()):
+                w = (self.col_idx.to(torch.int64) << 16) | v.to(torch.int64)
+                # bit pattern of a uint32 in an int32 tensor (torch has no uint32 arithmetic)
+                self.ent = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
 
     def _build_panel_csc(self):
         dev, N, D, P = self.device, self.n_rows, self.n_cols, self.panel_rows

@@ -1,0 +1,201 @@
+"""The library's device layout builder (csrc/layout.hip, spmf_layout_build) against the torch
+construction of the same arrays (spmf_amd/sparse.py _build_panel_csc / _build_items, the host-side
+statement of the layout): integer work, so every array must agree bit for bit.  The layout is
+what replaces the dense [B,D] batch the reference hands its model (poisson.py:170,182)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(rows, D, density, seed, values="counts", unsorted=False, empty_rows=False, dense_col=False,
+         duplicates=False):
+    rng = np.random.default_rng(seed)
+    cols, ptr = [], [0]
+    for b in range(rows):
+        if empty_rows and b % 3 == 1:
+            n = 0
+        else:
+            n = rng.binomial(D, density)
+        c = rng.choice(D, size=n, replace=False)
+        if dense_col and D > 2:
+            c = np.union1d(c, [1])
+        if not unsorted:
+            c = np.sort(c)
+        if duplicates and len(c) > 1:
+            c = np.concatenate([c, c[:1]])
+        cols.append(c)
+        ptr.append(ptr[-1] + len(c))
+    col = np.concatenate(cols).astype(np.int64) if cols else np.zeros(0, np.int64)
+    nnz = len(col)
+    if values == "counts":
+        val = rng.poisson(2.0, nnz) + 1.0
+    elif values == "big":
+        val = rng.integers(1, 200_000, nnz).astype(np.float64)
+    else:
+        val = rng.gamma(2.0, 1.0, nnz) + 0.25
+    return np.asarray(ptr, np.int64), col, val.astype(np.float32)
+
+
+def _build(ptr, col, val, rows, D, P, split, native):
+    from spmf_amd.sparse import SparseCounts
+    dev = torch.device("cuda", 0)
+    old = os.environ.get("SPMF_NATIVE_LAYOUT")
+    os.environ["SPMF_NATIVE_LAYOUT"] = "1" if native else "0"
+    try:
+        return SparseCounts(torch.as_tensor(ptr).to(dev), torch.as_tensor(col).to(dev),
+                            torch.as_tensor(val).to(dev), rows, D, P, col_split=split)
+    finally:
+        if old is None:
+            del os.environ["SPMF_NATIVE_LAYOUT"]
+        else:
+            os.environ["SPMF_NATIVE_LAYOUT"] = old
+
+
+ARRAYS = ("pc_ptr", "pc_row", "pc_val", "pc_ent", "ent", "items", "item_ptr", "item_mid",
+          "items_per_panel", "items_per_half")
+
+
+def _same(a, b, what):
+    assert a.native_layout and not b.native_layout
+    for k in ("n_rows", "n_cols", "nnz", "panel_rows", "n_panels", "pc_pad", "col_split"):
+        assert getattr(a, k) == getattr(b, k), (what, k)
+    for k in ARRAYS:
+        x, y = getattr(a, k), getattr(b, k)
+        assert (x is None) == (y is None), (what, k, x is None, y is None)
+        if x is not None:
+            assert x.dtype == y.dtype and x.shape == y.shape, (what, k, x.dtype, y.dtype, x.shape, y.shape)
+            assert torch.equal(x, y), (what, k)
+    # the descriptors the kernels get, for the whole shard and for a panel range
+    for pr in ((0, None), (1, 3)):
+        if pr[0] >= a.n_panels:
+            continue
+        ca, cb = a.batch_struct(*pr), b.batch_struct(*pr)
+        for k in ("n_rows", "nnz", "n_panels", "max_items_per_panel", "pc_pad", "row_base"):
+            assert getattr(ca, k) == getattr(cb, k), (what, pr, k)
+        assert list(ca.max_items_half) == list(cb.max_items_half)
+
+
+CASES = [
+    # rows, D, density, P, split, kwargs
+    ("counts, 12 panels", 3000, 700, 0.02, 256, 0, {}),
+    ("counts, column split", 3000, 700, 0.02, 256, 300, {}),
+    ("one panel", 900, 300, 0.05, 4096, 0, {}),
+    ("ragged last panel + empty rows", 1001, 257, 0.03, 100, 0, {"empty_rows": True}),
+    ("unsorted columns inside rows", 800, 200, 0.05, 64, 0, {"unsorted": True}),
+    ("a pair stored twice", 500, 100, 0.05, 64, 40, {"duplicates": True}),
+    ("real values: nothing packs", 1500, 400, 0.03, 128, 0, {"values": "real"}),
+    ("counts above 65535", 600, 300, 0.04, 128, 0, {"values": "big"}),
+    ("long lists: several segments per list", 5000, 30, 0.5, 5000, 0, {"dense_col": True}),
+    ("long lists, split", 6000, 24, 0.6, 3000, 10, {"dense_col": True}),
+    ("D above 65536: no packed rows", 300, 70_000, 0.0005, 64, 0, {}),
+    ("one row", 1, 50, 0.3, 8, 0, {}),
+    ("one column", 200, 1, 0.6, 32, 0, {}),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_native_layout_equals_the_torch_construction(case):
+    what, rows, D, dens, P, split, kw = case
+    ptr, col, val = _csr(rows, D, dens, seed=len(what) * 31 + rows, **kw)
+    a = _build(ptr, col, val, rows, D, P, split, native=True)
+    b = _build(ptr, col, val, rows, D, P, split, native=False)
+    _same(a, b, what)
+
+
+def test_panels_of_more_than_65536_rows_and_an_empty_shard():
+    rows, D = 70_000, 40
+    ptr, col, val = _csr(rows, D, 0.05, seed=5)
+    a = _build(ptr, col, val, rows, D, rows, 0, native=True)
+    b = _build(ptr, col, val, rows, D, rows, 0, native=False)
+    assert a.pc_ent is None and a.ent is not None
+    _same(a, b, "one 70 000-row panel")
+    z = np.zeros(0, np.int64)
+    for n in (0, 5):
+        a = _build(np.zeros(n + 1, np.int64), z, z.astype(np.float32), n, 30, 8, 0, native=True)
+        b = _build(np.zeros(n + 1, np.int64), z, z.astype(np.float32), n, 30, 8, 0, native=False)
+        _same(a, b, f"no stored entry, {n} rows")
+
+
+def test_builder_is_deterministic_and_feeds_the_kernels():
+    """Two builds give the same bytes; energy and gradients through a native layout equal those
+    through the torch-built one (same arrays, same kernels; float atomics aside)."""
+    import contextlib
+    import sys
+    from spmf_amd import PoissonFactorization
+    rows, D, K = 4000, 500, 8
+    ptr, col, val = _csr(rows, D, 0.03, seed=77)
+    a = _build(ptr, col, val, rows, D, 512, 0, native=True)
+    a2 = _build(ptr, col, val, rows, D, 512, 0, native=True)
+    for k in ARRAYS:
+        if getattr(a, k) is not None:
+            assert torch.equal(getattr(a, k), getattr(a2, k)), k
+    b = _build(ptr, col, val, rows, D, 512, 0, native=False)
+    dev = torch.device("cuda", 0)
+    outs = []
+    for sc in (a, b):
+        with contextlib.redirect_stdout(sys.stderr):
+            m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=0.01, device=dev)
+        colsum = torch.zeros(D, dtype=torch.float64, device=dev)
+        colnnz = torch.zeros_like(colsum)
+        sc.compute_stats(m._handle(), colsum, colnnz)
+        torch.manual_seed(5)
+        p = m.surrogate_distribution.sample(1)
+        parts, grads, _ = m.energy_and_grads({"counts": sc}, p)
+        outs.append((float(parts["x"][0]), float(parts["z"][0]), grads))
+    for i in (0, 1):        # (fp64 atomics: the order of the adds is not fixed)
+        assert abs(outs[0][i] - outs[1][i]) <= 1e-11 * abs(outs[1][i])
+    for k in ("u", "v", "w", "s"):      # float atomics: run-to-run noise of the column pass, array norm
+        ga, gb = outs[0][2][k], outs[1][2][k]
+        assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()), k
+
+
+def test_builder_rejects_what_would_make_the_kernels_read_out_of_bounds():
+    from spmf_amd import _lib
+    rows, D = 200, 50
+    ptr, col, val = _csr(rows, D, 0.1, seed=9)
+    bad = col.copy()
+    bad[7] = D                                   # a column index outside [0, D)
+    with pytest.raises(_lib.SpmfError, match="column index"):
+        _build(ptr, bad, val, rows, D, 64, 0, native=True)
+    bad = col.copy()
+    bad[3] = -1
+    with pytest.raises(_lib.SpmfError, match="column index"):
+        _build(ptr, bad, val, rows, D, 64, 0, native=True)
+    p2 = ptr.copy()
+    p2[10], p2[11] = p2[11], p2[10]              # decreasing offsets
+    if p2[10] != p2[11]:
+        with pytest.raises(_lib.SpmfError, match="row_ptr"):
+            _build(p2, col, val, rows, D, 64, 0, native=True)
+    p3 = ptr.copy()
+    p3[-1] += 4                                  # row_ptr[n_rows] != nnz
+    with pytest.raises(_lib.SpmfError, match="row_ptr"):
+        _build(p3, col, val, rows, D, 64, 0, native=True)
+    # buffers smaller than asked for, a foreign info struct
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    lb, sb = C.c_size_t(), C.c_size_t()
+    assert lib.spmf_layout_sizes(0, rows, len(col), D, 64, C.byref(lb), C.byref(sb)) == 0
+    lay = torch.empty(lb.value, dtype=torch.uint8, device=dev)
+    scr = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+    rp = torch.as_tensor(ptr).to(dev).to(torch.int32)
+    ci = torch.as_tensor(col).to(dev).to(torch.int32)
+    va = torch.as_tensor(val).to(dev)
+    cs, info = _lib.CountsStruct(), _lib.LayoutInfo()
+    info.struct_size = C.sizeof(_lib.LayoutInfo)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    args = (0, rows, len(col), D, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), 64, 0)
+    assert lib.spmf_layout_build(*args, lay.data_ptr(), lb.value - 256, scr.data_ptr(), sb.value,
+                                 C.byref(cs), C.byref(info), st) == -3
+    assert b"smaller" in lib.spmf_layout_last_error()
+    info.struct_size = 8
+    assert lib.spmf_layout_build(*args, lay.data_ptr(), lb.value, scr.data_ptr(), sb.value,
+                                 C.byref(cs), C.byref(info), st) == -1
+    info.struct_size = C.sizeof(_lib.LayoutInfo)
+    assert lib.spmf_layout_build(*args, lay.data_ptr(), lb.value, scr.data_ptr(), sb.value,
+                                 C.byref(cs), C.byref(info), st) == 0
+    assert cs.struct_size == C.sizeof(_lib.CountsStruct) and cs.nnz == len(col) and info.n_items > 0

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.spmf_version() == 3 and 'define SPMF_ABI_VERSION 3' in hdr
+    assert lib.spmf_version() == 4 and 'define SPMF_ABI_VERSION 4' in hdr
 
 
 def test_library_exports_only_the_c_abi(lib):
@@ -60,6 +60,24 @@ def test_struct_sizes_agree_between_library_ctypes_and_integration_stub(lib):
     assert C.sizeof(stub) == lib.spmf_sizeof_counts()
     assert [(n, getattr(stub, n).offset) for n, *_ in stub._fields_] == \
         [(n, getattr(_lib.CountsStruct, n).offset) for n, *_ in _lib.CountsStruct._fields_]
+
+
+def test_layout_builder_argument_errors_without_gpu(lib):
+    """spmf_layout_*: what is checked before the first device call."""
+    from spmf_amd import _lib
+    assert lib.spmf_sizeof_layout_info() == C.sizeof(_lib.LayoutInfo) == 48
+    lb, sb = C.c_size_t(), C.c_size_t()
+    assert lib.spmf_layout_sizes(0, 10, 5, 0, 4, C.byref(lb), C.byref(sb)) == -1       # n_cols < 1
+    assert b"n_cols" in lib.spmf_layout_last_error()
+    assert lib.spmf_layout_sizes(0, 10, -1, 7, 4, C.byref(lb), C.byref(sb)) == -1      # nnz < 0
+    assert lib.spmf_layout_sizes(0, 10, 2 ** 31, 7, 4, C.byref(lb), C.byref(sb)) == -4  # nnz must fit int32
+    assert lib.spmf_layout_sizes(0, 10, 5, 7, 0, C.byref(lb), C.byref(sb)) == -1       # panel_rows < 1
+    assert lib.spmf_layout_sizes(0, 10, 5, 7, 4, None, C.byref(sb)) == -1
+    cs, info = _lib.CountsStruct(), _lib.LayoutInfo()
+    info.struct_size = C.sizeof(_lib.LayoutInfo)
+    assert lib.spmf_layout_build(0, 10, 5, 7, None, None, None, 4, 0, None, 0, None, 0,
+                                 C.byref(cs), C.byref(info), None) == -1               # null buffers
+    assert b"null" in lib.spmf_layout_last_error()
 
 
 def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
