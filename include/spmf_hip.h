@@ -207,6 +207,13 @@ int spmf_counts_stats(spmf_ctx* ctx, int64_t n_rows, const int32_t* row_ptr,
                       double* colnnz, float* row_sum, double* row_lgamma,
                       void* stream);
 
+/* The column half of the same statistics from a built layout: colsum[D] / colnnz[D] (fp64,
+ * ACCUMULATED, either may be NULL) from the panel-CSC lists of `counts` -- one atomic per
+ * (panel, column) list instead of one per stored entry (C3: 6.7 -> 0.3 ms).  Sums of integer
+ * counts are exact in fp64, so both forms give the same numbers. */
+int spmf_counts_colstats(spmf_ctx* ctx, const spmf_counts* counts, double* colsum,
+                         double* colnnz, void* stream);
+
 /* ---- device layout builder ------------------------------------------- */
 /* Builds everything of a spmf_counts that is derived from the CSR arrays of one row shard
  * (the reference hands its model a dense [B,D] batch, poisson.py:170,182; a caller of this

@@ -95,6 +95,8 @@ SIGNATURES = {
     "spmf_ctx_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "spmf_counts_stats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 7
                           + [C.c_void_p]),
+    "spmf_counts_colstats": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
     "spmf_sizeof_layout_info": (C.c_size_t, []),
     "spmf_layout_sizes": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                     C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

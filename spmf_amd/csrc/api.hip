@@ -484,6 +484,18 @@ int spmf_counts_stats(spmf_ctx* c, int64_t n_rows, const int32_t* row_ptr, const
   return SPMF_OK;
 }
 
+int spmf_counts_colstats(spmf_ctx* c, const spmf_counts* ct, double* colsum, double* colnnz, void* stream) {
+  if (!c || !ct) return fail(c, SPMF_E_ARG, "counts_colstats: bad arguments");
+  int rc = check_counts(c, ct);
+  if (rc) return rc;
+  if (ct->nnz == 0 || ct->n_rows == 0 || (!colsum && !colnnz)) return SPMF_OK;
+  if (!ct->pc_ptr || !ct->pc_val || ct->n_panels < 1)
+    return fail(c, SPMF_E_ARG, "counts_colstats: panel-CSC arrays missing");
+  launch_colstats(ct->n_panels, ct->n_cols, ct->pc_ptr, ct->pc_val, colsum, colnnz, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
 // parts: bit 0 = zero, prep, row pass and the column pass of the lower column half (all columns
 // without a split); bit 1 = column pass of the upper half and the fp64 pack
 static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS],

@@ -230,5 +230,7 @@ struct StatsArgs {
   double* row_lgamma;
 };
 void launch_stats(const StatsArgs& a, hipStream_t st);
+void launch_colstats(int n_panels, int D, const int32_t* pc_ptr, const float* pc_val, double* colsum,
+                     double* colnnz, hipStream_t st);
 
 }  // namespace spmf

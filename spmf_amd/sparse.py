@@ -126,8 +126,10 @@ class SparseCounts:
         csr = _as_csr_arrays(x)
         if csr is not None:
             indptr, indices, data, shape = csr
-            return cls(torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(device),
-                       torch.as_tensor(np.asarray(indices, dtype=np.int64)).to(device),
+            # 4-byte offsets / indices over the host link when they fit (they must, to be a shard)
+            it = np.int32 if (len(indptr) == 0 or int(indptr[-1]) < 2 ** 31) and shape[1] < 2 ** 31 else np.int64
+            return cls(torch.as_tensor(np.asarray(indptr, dtype=it)).to(device),
+                       torch.as_tensor(np.asarray(indices, dtype=it)).to(device),
                        torch.as_tensor(np.asarray(data, dtype=np.float32)).to(device),
                        shape[0], shape[1], panel_rows, col_split, latent_dim)
         return cls.from_dense(x, device, panel_rows, col_split, latent_dim)
@@ -301,11 +303,17 @@ class SparseCounts:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = lib.spmf_counts_stats(
             ctx_handle, self.n_rows, self.row_ptr.data_ptr(), self.col_idx.data_ptr(),
-            self.val.data_ptr(),
-            colsum.data_ptr() if colsum is not None else None,
-            colnnz.data_ptr() if colnnz is not None else None,
+            self.val.data_ptr(), None, None,
             self.row_sum.data_ptr(), self.row_lgamma.data_ptr(), stream)
         _lib.check(ctx_handle, rc, "spmf_counts_stats")
+        if colsum is not None or colnnz is not None:
+            # the column half from the panel-CSC lists: one atomic per list, not per entry
+            cs = self.batch_struct()
+            rc = lib.spmf_counts_colstats(
+                ctx_handle, C.byref(cs),
+                colsum.data_ptr() if colsum is not None else None,
+                colnnz.data_ptr() if colnnz is not None else None, stream)
+            _lib.check(ctx_handle, rc, "spmf_counts_colstats")
 
     # The spmf_counts descriptors cached per (panel range, xi key, g key) hold RAW
     # device pointers to row_scale / gval / pc_gval.  Two models with different

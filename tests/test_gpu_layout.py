@@ -199,3 +199,42 @@ def test_builder_rejects_what_would_make_the_kernels_read_out_of_bounds():
     assert lib.spmf_layout_build(*args, lay.data_ptr(), lb.value, scr.data_ptr(), sb.value,
                                  C.byref(cs), C.byref(info), st) == 0
     assert cs.struct_size == C.sizeof(_lib.CountsStruct) and cs.nnz == len(col) and info.n_items > 0
+
+
+def test_statistics_csr_form_list_form_and_host_numbers_agree():
+    """compute_scales' column sums (poisson.py:118-135) and the per-row sums: the CSR form of
+    spmf_counts_stats, the list form of spmf_counts_colstats and numpy on the same data."""
+    import contextlib
+    import sys
+    from scipy.special import gammaln
+    from spmf_amd import PoissonFactorization, _lib
+    rows, D = 3000, 400
+    ptr, col, val = _csr(rows, D, 0.04, seed=21)
+    val[::7] = 300.0 + (np.arange(len(val[::7])) % 5)       # counts beyond the lgamma table
+    val[5::11] = 0.0                                          # stored zeros: not counted by colnnz
+    sc = _build(ptr, col, val, rows, D, 512, 0, native=True)
+    dev = torch.device("cuda", 0)
+    with contextlib.redirect_stdout(sys.stderr):
+        m = PoissonFactorization(latent_dim=4, feature_dim=D, u_tau_scale=0.01, device=dev)
+    lib, h = _lib.load(), m._handle()
+    cs_l = torch.zeros(D, dtype=torch.float64, device=dev)
+    cn_l = torch.zeros_like(cs_l)
+    sc.compute_stats(h, cs_l, cn_l)                           # rows: CSR kernel, columns: lists
+    cs_c = torch.zeros_like(cs_l)
+    cn_c = torch.zeros_like(cs_l)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    assert lib.spmf_counts_stats(h, rows, sc.row_ptr.data_ptr(), sc.col_idx.data_ptr(), sc.val.data_ptr(),
+                                 cs_c.data_ptr(), cn_c.data_ptr(), None, None, st) == 0
+    torch.cuda.synchronize()
+    want_sum = np.bincount(col, weights=val.astype(np.float64), minlength=D)
+    want_nnz = np.bincount(col, weights=(val > 0).astype(np.float64), minlength=D)
+    for got in (cs_l, cs_c):
+        assert np.array_equal(got.cpu().numpy(), want_sum)    # integer counts: exact in fp64
+    for got in (cn_l, cn_c):
+        assert np.array_equal(got.cpu().numpy(), want_nnz)
+    rs = np.add.reduceat(np.append(val.astype(np.float64), 0.0), ptr[:-1])
+    rs[np.diff(ptr) == 0] = 0.0
+    np.testing.assert_allclose(sc.row_sum.cpu().numpy(), rs, rtol=1e-6)
+    lg = np.add.reduceat(np.append(gammaln(val.astype(np.float64) + 1.0), 0.0), ptr[:-1])
+    lg[np.diff(ptr) == 0] = 0.0
+    np.testing.assert_allclose(sc.row_lgamma.cpu().numpy(), lg, rtol=1e-13, atol=1e-12)
