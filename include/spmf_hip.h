@@ -214,6 +214,15 @@ int spmf_counts_stats(spmf_ctx* ctx, int64_t n_rows, const int32_t* row_ptr,
 int spmf_counts_colstats(spmf_ctx* ctx, const spmf_counts* counts, double* colsum,
                          double* colnnz, void* stream);
 
+/* log_transform contexts: the encoder side g(x) = log(x / eta_d + 1) (encoder_function,
+ * poisson.py:41-42) of every stored entry of `counts`, in CSR order into gval (base pointer,
+ * indexed like col_idx / val) and in list order into pc_gval (base pointer, indexed like pc_val);
+ * either may be NULL.  eta[D] fp32.  The pc_pad entries behind the last list of the shard are the
+ * caller's (zero-filled): only list entries are written.  Depends on the counts and the column
+ * scales only: once per (shard, eta), then set spmf_counts.gval / pc_gval. */
+int spmf_counts_gvals(spmf_ctx* ctx, const spmf_counts* counts, const float* eta, float* gval,
+                      float* pc_gval, void* stream);
+
 /* ---- device layout builder ------------------------------------------- */
 /* Builds everything of a spmf_counts that is derived from the CSR arrays of one row shard
  * (the reference hands its model a dense [B,D] batch, poisson.py:170,182; a caller of this

@@ -97,6 +97,8 @@ SIGNATURES = {
                           + [C.c_void_p]),
     "spmf_counts_colstats": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "spmf_counts_gvals": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     "spmf_sizeof_layout_info": (C.c_size_t, []),
     "spmf_layout_sizes": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                     C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -496,6 +496,20 @@ int spmf_counts_colstats(spmf_ctx* c, const spmf_counts* ct, double* colsum, dou
   return SPMF_OK;
 }
 
+int spmf_counts_gvals(spmf_ctx* c, const spmf_counts* ct, const float* eta, float* gval, float* pc_gval,
+    void* stream) {
+  if (!c || !ct || !eta) return fail(c, SPMF_E_ARG, "counts_gvals: bad arguments");
+  int rc = check_counts(c, ct);
+  if (rc) return rc;
+  if (ct->nnz == 0 || ct->n_rows == 0) return SPMF_OK;
+  if (pc_gval && (!ct->pc_ptr || !ct->pc_val || ct->n_panels < 1))
+    return fail(c, SPMF_E_ARG, "counts_gvals: panel-CSC arrays missing");
+  launch_gvals(ct->nnz, ct->n_panels, ct->n_cols, ct->row_ptr, ct->col_idx, ct->val, ct->pc_ptr, ct->pc_val, eta,
+               gval, pc_gval, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
 // parts: bit 0 = zero, prep, row pass and the column pass of the lower column half (all columns
 // without a split); bit 1 = column pass of the upper half and the fp64 pack
 static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS],

@@ -230,6 +230,9 @@ struct StatsArgs {
   double* row_lgamma;
 };
 void launch_stats(const StatsArgs& a, hipStream_t st);
+void launch_gvals(int64_t nnz, int n_panels, int D, const int32_t* row_ptr, const int32_t* col, const float* val,
+                  const int32_t* pc_ptr, const float* pc_val, const float* eta, float* gval, float* pc_gval,
+                  hipStream_t st);
 void launch_colstats(int n_panels, int D, const int32_t* pc_ptr, const float* pc_val, double* colsum,
                      double* colnnz, hipStream_t st);
 

@@ -115,6 +115,53 @@ void launch_colstats(int n_panels, int D, const int32_t* pc_ptr, const float* pc
                      pc_ptr, pc_val, colsum, colnnz);
 }
 
+// encoder_function of the log_transform models (poisson.py:41-42): g(x) = log(x / eta_d + 1) per
+// stored entry, in CSR order and in list order -- data side, once per (batch, eta).
+__global__ __launch_bounds__(256) void gval_rows_kernel(int64_t nnz, const int32_t* __restrict__ row_ptr,
+                                                        const int32_t* __restrict__ col,
+                                                        const float* __restrict__ val,
+                                                        const float* __restrict__ eta, float* __restrict__ gval) {
+  const int64_t first = row_ptr[0];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride)
+    gval[first + i] = log1pf(val[first + i] / eta[col[first + i]]);
+}
+
+__global__ __launch_bounds__(256) void gval_lists_kernel(int64_t nlists, int D, const int32_t* __restrict__ pc_ptr,
+                                                         const float* __restrict__ pc_val,
+                                                         const float* __restrict__ eta,
+                                                         float* __restrict__ pc_gval) {
+  const int g = threadIdx.x % kColLanes;
+  const int64_t stride = (int64_t)gridDim.x * (256 / kColLanes);
+  for (int64_t k = (int64_t)blockIdx.x * (256 / kColLanes) + threadIdx.x / kColLanes; k < nlists; k += stride) {
+    const int64_t p = k / D;
+    const int d = (int)(k - p * D);
+    const int32_t* pp = pc_ptr + p * (D + 1) + d;
+    const int a = pp[0], e = pp[1];
+    if (e <= a) continue;
+    const float et = eta[d];
+    for (int i = a + g; i < e; i += kColLanes) pc_gval[i] = log1pf(pc_val[i] / et);
+  }
+}
+
+void launch_gvals(int64_t nnz, int n_panels, int D, const int32_t* row_ptr, const int32_t* col, const float* val,
+                  const int32_t* pc_ptr, const float* pc_val, const float* eta, float* gval, float* pc_gval,
+                  hipStream_t st) {
+  if (nnz <= 0) return;
+  if (gval) {
+    int64_t nb = (nnz + 1023) / 1024;
+    if (nb > (1 << 20)) nb = 1 << 20;
+    hipLaunchKernelGGL(gval_rows_kernel, dim3((unsigned)nb), dim3(256), 0, st, nnz, row_ptr, col, val, eta, gval);
+  }
+  if (pc_gval) {
+    const int64_t nlists = (int64_t)n_panels * D;
+    int64_t nb = (nlists + (256 / kColLanes) - 1) / (256 / kColLanes);
+    if (nb > (1 << 20)) nb = 1 << 20;
+    hipLaunchKernelGGL(gval_lists_kernel, dim3((unsigned)nb), dim3(256), 0, st, nlists, D, pc_ptr, pc_val, eta,
+                       pc_gval);
+  }
+}
+
 // Zero fill as a KERNEL.  hipMemsetAsync is avoided on the step path: captured into a
 // hipGraph its memset node was observed to run out of order with the kernels of the
 // PREVIOUS graph launch on the same stream (rare, timing dependent: accumulators zeroed

@@ -295,7 +295,7 @@ class PoissonFactorization:
             sc.compute_stats(self._handle())
         sc.set_row_scale(float(self.xi_u_global), self.scale_rows)
         if self.log_transform:
-            sc.set_log_transform(self._eta_device())
+            sc.set_log_transform(self._eta_device(), self._handle())
         return sc
 
     def _batch(self, data):

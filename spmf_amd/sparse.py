@@ -345,10 +345,11 @@ class SparseCounts:
         self.row_scale = held[key]
         self._xi_key = key
 
-    def set_log_transform(self, eta_dev):
+    def set_log_transform(self, eta_dev, ctx_handle=None):
         """g(x) = log(x/eta_d + 1) per stored entry (encoder_function,
         poisson.py:41-42), in CSR and panel-CSC order.  Data side: depends on
-        the counts and the fixed column scales only."""
+        the counts and the fixed column scales only.  With a context handle on the
+        HIP device: spmf_counts_gvals; torch operators otherwise (host-side tensors)."""
         held = self.__dict__.setdefault("_gvals", {})
         # identity of the eta tensor (a strong reference is kept, so its id cannot be
         # recycled while the entry lives) + its in-place version counter
@@ -356,7 +357,20 @@ class SparseCounts:
         if self._g_key == key:
             return
         if key not in held:
-            eta = eta_dev.to(self.device, torch.float32)
+            eta = eta_dev.to(self.device, torch.float32).contiguous()
+            if ctx_handle is not None and self.device.type == "cuda" and self.nnz > 0:
+                gval = torch.empty(self.nnz, dtype=torch.float32, device=self.device)
+                pc_gval = torch.zeros(self.nnz + PC_PAD, dtype=torch.float32, device=self.device)
+                cs = self.batch_struct()
+                rc = _lib.load().spmf_counts_gvals(
+                    ctx_handle, C.byref(cs), eta.data_ptr(), gval.data_ptr(), pc_gval.data_ptr(),
+                    torch.cuda.current_stream(self.device).cuda_stream)
+                _lib.check(ctx_handle, rc, "spmf_counts_gvals")
+                held[key] = (eta_dev, gval, pc_gval, eta)
+                self._trim_gvals(held)
+                _, self.gval, self.pc_gval = held[key][:3]
+                self._g_key = key
+                return
             gval = torch.log1p(self.val / eta[self.col_idx.to(torch.int64)]).contiguous()
             nP, D = self.n_panels, self.n_cols
             ptr = self.pc_ptr.view(nP, D + 1).to(torch.int64)
@@ -367,12 +381,15 @@ class SparseCounts:
                                  torch.zeros(PC_PAD, dtype=torch.float32,
                                              device=self.device)]).contiguous()
             held[key] = (eta_dev, gval, pc_gval)
-            while len(held) > self._MAX_G_KEYS:
-                old = next(iter(held))
-                del held[old]
-                self._drop_structs(2, old)
-        _, self.gval, self.pc_gval = held[key]
+            self._trim_gvals(held)
+        _, self.gval, self.pc_gval = held[key][:3]
         self._g_key = key
+
+    def _trim_gvals(self, held):
+        while len(held) > self._MAX_G_KEYS:
+            old = next(iter(held))
+            del held[old]
+            self._drop_structs(2, old)
 
     # ---- batches ---------------------------------------------------------
     def n_batches(self, batch_rows):

@@ -238,3 +238,27 @@ def test_statistics_csr_form_list_form_and_host_numbers_agree():
     lg = np.add.reduceat(np.append(gammaln(val.astype(np.float64) + 1.0), 0.0), ptr[:-1])
     lg[np.diff(ptr) == 0] = 0.0
     np.testing.assert_allclose(sc.row_lgamma.cpu().numpy(), lg, rtol=1e-13, atol=1e-12)
+
+
+def test_log_transform_streams_native_equal_torch():
+    """g(x) = log(x / eta_d + 1) (encoder_function, poisson.py:41-42) in CSR and list order:
+    spmf_counts_gvals against the torch statement, and against numpy in fp64."""
+    import contextlib
+    import sys
+    from spmf_amd import PoissonFactorization
+    rows, D = 2500, 300
+    ptr, col, val = _csr(rows, D, 0.05, seed=31, empty_rows=True)
+    dev = torch.device("cuda", 0)
+    eta = torch.as_tensor(np.random.default_rng(3).gamma(2.0, 1.0, D).astype(np.float32) + 0.1).to(dev)
+    with contextlib.redirect_stdout(sys.stderr):
+        m = PoissonFactorization(latent_dim=4, feature_dim=D, u_tau_scale=0.01, device=dev, log_transform=True)
+    a = _build(ptr, col, val, rows, D, 512, 0, native=True)
+    b = _build(ptr, col, val, rows, D, 512, 0, native=True)
+    a.set_log_transform(eta, m._handle())        # the library
+    b.set_log_transform(eta)                     # torch operators
+    assert a.gval.shape == b.gval.shape and a.pc_gval.shape == b.pc_gval.shape
+    torch.testing.assert_close(a.gval, b.gval, rtol=3e-7, atol=0)
+    torch.testing.assert_close(a.pc_gval, b.pc_gval, rtol=3e-7, atol=0)
+    assert float(a.pc_gval[a.nnz:].abs().max()) == 0.0            # the padding behind the last list
+    want = np.log1p(val.astype(np.float64) / eta.cpu().numpy().astype(np.float64)[col])
+    np.testing.assert_allclose(a.gval.cpu().numpy(), want, rtol=3e-7)
