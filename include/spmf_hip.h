@@ -275,6 +275,20 @@ int spmf_layout_build(int device, int64_t n_rows, int64_t nnz, int32_t n_cols,
 /* Message of the last failed spmf_layout_* call of the calling thread (host string). */
 const char* spmf_layout_last_error(void);
 
+/* Dense batches -- the reference's own input, data[count_key] as a [B,D] array
+ * (poisson.py:170,182; tests/spmf_test.py:17-22) -- to the CSR arrays above, on the device:
+ *   spmf_dense_row_ptr   row_ptr[n_rows+1] = offsets of the rows' stored cells (x != 0, so NaN cells
+ *                        are stored); scratch: spmf_dense_scratch_bytes(n_rows), 8-byte aligned;
+ *                        the total is row_ptr[n_rows] (saturating at 2^31-1: a shard must stay below)
+ *   spmf_dense_fill_csr  col_idx / val (sized by that total) in row-major, ascending-column order
+ * dense: fp32, row-major with leading dimension ld >= n_cols.  Both are stream-ordered and do not
+ * synchronise; the caller reads row_ptr[n_rows] between the two to size col_idx / val. */
+size_t spmf_dense_scratch_bytes(int64_t n_rows);
+int spmf_dense_row_ptr(int device, int64_t n_rows, int32_t n_cols, const float* dense, int64_t ld,
+                       int32_t* row_ptr, void* scratch, size_t scratch_bytes, void* stream);
+int spmf_dense_fill_csr(int device, int64_t n_rows, int32_t n_cols, const float* dense, int64_t ld,
+                        const int32_t* row_ptr, int32_t* col_idx, float* val, void* stream);
+
 /* ---- the hot path ------------------------------------------------------ */
 /* Phase 1: sparse data term for S draws.  Reads u,v,w,s (params[2,0,1,7])
  * and eta[D] (eta_i, poisson.py:88-91,142-149; ones when unscaled).  Leaves

@@ -107,6 +107,11 @@ SIGNATURES = {
                                     C.c_void_p, C.c_size_t, C.POINTER(CountsStruct),
                                     C.POINTER(LayoutInfo), C.c_void_p]),
     "spmf_layout_last_error": (C.c_char_p, []),
+    "spmf_dense_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "spmf_dense_row_ptr": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "spmf_dense_fill_csr": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "spmf_data_pass": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int,
                                  PtrArray, C.c_void_p, C.c_void_p]),
     "spmf_acc_ptr": (C.c_void_p, [C.c_void_p]),

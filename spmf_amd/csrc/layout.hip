@@ -346,6 +346,125 @@ __global__ __launch_bounds__(256) void layout_panel_items_kernel(int nP, int seg
   atomicMax(&info[I_MAXHI], e - m);
 }
 
+// ---- dense [B,D] batches (the reference's own input: data[count_key], poisson.py:170) -> CSR ----
+constexpr int kRowsPerBlock = 1024;     // rows whose counts one workgroup of the offset pass scans
+
+__device__ __forceinline__ int wave_count_row(const float* __restrict__ row, int D, int lane) {
+  int n = 0;
+  for (int c = lane; c < D; c += 64) n += row[c] != 0.f ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  return n;
+}
+
+// wave per row: stored cells of the row -> cnt[b]; a block's rows are consecutive
+__global__ __launch_bounds__(256) void dense_count_kernel(int64_t B, int D, const float* __restrict__ dense,
+                                                          int64_t ld, int32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = wave; b < B; b += nwaves) {
+    const int n = wave_count_row(dense + b * ld, D, lane);
+    if (lane == 0) cnt[b] = n;
+  }
+}
+
+// sums of kRowsPerBlock consecutive counts
+__global__ __launch_bounds__(256) void dense_blocksum_kernel(int64_t B, const int32_t* __restrict__ cnt,
+                                                             int64_t* __restrict__ bsum) {
+  __shared__ int64_t red[4];
+  const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
+  int64_t s = 0;
+  for (int i = threadIdx.x; i < kRowsPerBlock; i += 256)
+    if (r0 + i < B) s += cnt[r0 + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup: exclusive scan of the block sums in place, the total behind them
+__global__ __launch_bounds__(256) void dense_scan_blocks_kernel(int64_t nblk, int64_t* __restrict__ bsum) {
+  __shared__ int64_t part[256];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nblk; base += 256) {
+    const int64_t i = base + threadIdx.x;
+    const int64_t v = i < nblk ? bsum[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {           // Hillis-Steele, inclusive
+      const int64_t t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblk) bsum[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += part[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[nblk] = carry;
+}
+
+// workgroup per kRowsPerBlock rows: counts -> offsets (in place: cnt[b] becomes row_ptr[b]; row_ptr[B] = total)
+__global__ __launch_bounds__(256) void dense_offsets_kernel(int64_t B, const int64_t* __restrict__ bsum,
+                                                            int32_t* __restrict__ row_ptr) {
+  __shared__ int64_t part[256];
+  const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x * 4;
+  const int64_t total = bsum[gridDim.x];
+  int c[4];
+  int64_t s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c[j] = r0 + j < B ? row_ptr[r0 + j] : 0;
+    s += c[j];
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int64_t t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int64_t off = bsum[blockIdx.x] + part[threadIdx.x] - s;
+  const int64_t cap = 2147483647;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (r0 + j < B) row_ptr[r0 + j] = (int32_t)(off < cap ? off : cap);
+    off += c[j];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) row_ptr[B] = (int32_t)(total < cap ? total : cap);
+}
+
+// wave per row: the stored cells of the row in column order
+__global__ __launch_bounds__(256) void dense_fill_kernel(int64_t B, int D, const float* __restrict__ dense, int64_t ld,
+                                                         const int32_t* __restrict__ row_ptr,
+                                                         int32_t* __restrict__ col, float* __restrict__ val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = wave; b < B; b += nwaves) {
+    const float* __restrict__ row = dense + b * ld;
+    int64_t at = row_ptr[b];
+    for (int c0 = 0; c0 < D; c0 += 64) {
+      const int c = c0 + lane;
+      const float x = c < D ? row[c] : 0.f;
+      const bool st = c < D && x != 0.f;
+      const unsigned long long m = __ballot(st);
+      if (st) {
+        const int64_t i = at + __popcll(m & ((1ull << lane) - 1ull));
+        col[i] = c;
+        val[i] = x;
+      }
+      at += __popcll(m);
+    }
+  }
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 template <typename KeyT>
@@ -436,6 +555,48 @@ const char* layout_last_error() { return g_layout_err.c_str(); }
 using namespace spmf;
 
 extern "C" {
+
+size_t spmf_dense_scratch_bytes(int64_t n_rows) {
+  const int64_t nblk = n_rows > 0 ? (n_rows + kRowsPerBlock - 1) / kRowsPerBlock : 1;
+  return (size_t)(nblk + 2) * 8;
+}
+
+int spmf_dense_row_ptr(int device, int64_t n_rows, int32_t n_cols, const float* dense, int64_t ld,
+                       int32_t* row_ptr, void* scratch, size_t scratch_bytes, void* stream) {
+  if (n_rows < 0 || n_cols < 1 || !row_ptr || !scratch || (n_rows > 0 && !dense) || ld < n_cols)
+    return lfail(SPMF_E_ARG, "dense_row_ptr: bad arguments (n_rows >= 0, n_cols >= 1, ld >= n_cols, non-null buffers)");
+  if (n_rows >= (int64_t(1) << 31)) return lfail(SPMF_E_UNSUPPORTED, "dense_row_ptr: n_rows must fit int32");
+  if (scratch_bytes < spmf_dense_scratch_bytes(n_rows) || ((uintptr_t)scratch & 7))
+    return lfail(SPMF_E_WORKSPACE, "dense_row_ptr: scratch smaller than spmf_dense_scratch_bytes or not 8-byte aligned");
+  LCHK(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  int64_t* bsum = (int64_t*)scratch;
+  const int64_t nblk = n_rows > 0 ? (n_rows + kRowsPerBlock - 1) / kRowsPerBlock : 1;
+  if (n_rows > 0) {
+    const int64_t want = (n_rows + 3) / 4;
+    hipLaunchKernelGGL(dense_count_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, st, n_rows,
+                       (int)n_cols, dense, ld, row_ptr);
+  }
+  hipLaunchKernelGGL(dense_blocksum_kernel, dim3((unsigned)nblk), dim3(256), 0, st, n_rows, row_ptr, bsum);
+  hipLaunchKernelGGL(dense_scan_blocks_kernel, dim3(1), dim3(256), 0, st, nblk, bsum);
+  hipLaunchKernelGGL(dense_offsets_kernel, dim3((unsigned)nblk), dim3(256), 0, st, n_rows, bsum, row_ptr);
+  LCHK(hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_dense_fill_csr(int device, int64_t n_rows, int32_t n_cols, const float* dense, int64_t ld,
+                        const int32_t* row_ptr, int32_t* col_idx, float* val, void* stream) {
+  if (n_rows < 0 || n_cols < 1 || !row_ptr || ld < n_cols)
+    return lfail(SPMF_E_ARG, "dense_fill_csr: bad arguments");
+  if (n_rows == 0) return SPMF_OK;
+  if (!dense || !col_idx || !val) return lfail(SPMF_E_ARG, "dense_fill_csr: null buffers");
+  LCHK(hipSetDevice(device));
+  const int64_t want = (n_rows + 3) / 4;
+  hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0,
+                     (hipStream_t)stream, n_rows, (int)n_cols, dense, ld, row_ptr, col_idx, val);
+  LCHK(hipGetLastError());
+  return SPMF_OK;
+}
 
 size_t spmf_sizeof_layout_info(void) { return sizeof(spmf_layout_info); }
 

@@ -145,6 +145,32 @@ class SparseCounts:
         if t.dim() != 2:
             raise ValueError("counts must be [rows, features]")
         N, D = t.shape
+        if t.device.type == "cuda" and os.environ.get("SPMF_NATIVE_LAYOUT", "1") != "0":
+            # the library's compaction (csrc/layout.hip): count, offsets, fill -- three passes over
+            # the dense batch instead of mask / nonzero / index with int64 intermediates
+            lib = _lib.load()
+            t = t.to(torch.float32).contiguous()
+            idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+            st = torch.cuda.current_stream(t.device).cuda_stream
+
+            def ok(rc, what):
+                if rc != 0:
+                    msg = lib.spmf_layout_last_error()
+                    raise _lib.SpmfError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+            row_ptr = torch.empty(N + 1, dtype=torch.int32, device=t.device)
+            nb = int(lib.spmf_dense_scratch_bytes(N))
+            scratch = torch.empty((nb + 7) // 8, dtype=torch.int64, device=t.device)
+            ok(lib.spmf_dense_row_ptr(idx, N, D, t.data_ptr(), D, row_ptr.data_ptr(), scratch.data_ptr(),
+                                      scratch.numel() * 8, st), "spmf_dense_row_ptr")
+            nnz = int(row_ptr[N])
+            if nnz >= 2 ** 31 - 1:
+                raise ValueError("nnz per shard must fit int32")
+            col = torch.empty(nnz, dtype=torch.int32, device=t.device)
+            val = torch.empty(nnz, dtype=torch.float32, device=t.device)
+            ok(lib.spmf_dense_fill_csr(idx, N, D, t.data_ptr(), D, row_ptr.data_ptr(), col.data_ptr(),
+                                       val.data_ptr(), st), "spmf_dense_fill_csr")
+            return cls(row_ptr, col, val, N, D, panel_rows, col_split, latent_dim)
         mask = t != 0
         counts = mask.sum(1)
         row_ptr = torch.zeros(N + 1, dtype=torch.int64, device=device)

@@ -262,3 +262,57 @@ def test_log_transform_streams_native_equal_torch():
     assert float(a.pc_gval[a.nnz:].abs().max()) == 0.0            # the padding behind the last list
     want = np.log1p(val.astype(np.float64) / eta.cpu().numpy().astype(np.float64)[col])
     np.testing.assert_allclose(a.gval.cpu().numpy(), want, rtol=3e-7)
+
+
+@pytest.mark.parametrize("shape", [(700, 333), (1, 5), (2049, 64), (5000, 1), (3, 70_000), (0, 7)])
+def test_dense_batches_to_csr_native_equals_torch_and_numpy(shape):
+    """The reference's own batch format (dense [B,D], tests/spmf_test.py:17-22) through the library's
+    compaction kernels: same CSR as numpy's nonzero(), same layout as the torch path."""
+    from spmf_amd.sparse import SparseCounts
+    rows, D = shape
+    rng = np.random.default_rng(rows * 7 + D)
+    x = rng.poisson(0.05 if D > 1000 else 0.4, size=(rows, D)).astype(np.float32)
+    if rows > 2:
+        x[1] = 0.0                                  # an empty row
+        x[2, :] = 3.0                               # a full row
+    dev = torch.device("cuda", 0)
+    a = SparseCounts.from_dense(x, dev, 256)
+    old = os.environ.get("SPMF_NATIVE_LAYOUT")
+    os.environ["SPMF_NATIVE_LAYOUT"] = "0"
+    try:
+        b = SparseCounts.from_dense(x, dev, 256)
+    finally:
+        if old is None:
+            del os.environ["SPMF_NATIVE_LAYOUT"]
+        else:
+            os.environ["SPMF_NATIVE_LAYOUT"] = old
+    r, c = np.nonzero(x)
+    assert a.nnz == len(r) == b.nnz
+    assert np.array_equal(a.row_ptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(r, minlength=rows))]))
+    assert np.array_equal(a.col_idx.cpu().numpy(), c) and np.array_equal(a.val.cpu().numpy(), x[r, c])
+    for k in ("row_ptr", "col_idx", "val"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    if rows > 0:
+        _same(a, b, f"dense {shape}")
+    # a strided view (leading dimension > D) and NaN cells, through the C entry points
+    if rows >= 3 and D >= 5:
+        from spmf_amd import _lib
+        lib = _lib.load()
+        big = torch.as_tensor(x).to(dev)
+        big[0, 1] = float("nan")
+        wide = torch.zeros(rows, D + 3, dtype=torch.float32, device=dev)
+        wide[:, :D] = big
+        rp = torch.empty(rows + 1, dtype=torch.int32, device=dev)
+        scr = torch.empty(int(lib.spmf_dense_scratch_bytes(rows)) // 8 + 1, dtype=torch.int64, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        assert lib.spmf_dense_row_ptr(0, rows, D, wide.data_ptr(), D + 3, rp.data_ptr(), scr.data_ptr(),
+                                      scr.numel() * 8, st) == 0
+        n = int(rp[rows])
+        ci = torch.empty(n, dtype=torch.int32, device=dev)
+        va = torch.empty(n, dtype=torch.float32, device=dev)
+        assert lib.spmf_dense_fill_csr(0, rows, D, wide.data_ptr(), D + 3, rp.data_ptr(), ci.data_ptr(),
+                                       va.data_ptr(), st) == 0
+        xb = big.cpu().numpy()
+        rr, cc = np.nonzero((xb != 0) | np.isnan(xb))
+        assert n == len(rr) and np.array_equal(ci.cpu().numpy(), cc)
+        assert np.array_equal(va.cpu().numpy(), xb[rr, cc], equal_nan=True)
