@@ -422,16 +422,40 @@ class SparseCounts:
         ppb = max(1, batch_rows // self.panel_rows)
         return -(-self.n_panels // ppb)
 
+    def _host_panels(self):
+        """Host mirrors of the per-panel numbers a descriptor needs (first stored entry of every
+        panel, items per panel and per column half, Σ lgamma(x+1) per panel): read back ONCE, so
+        that cutting a descriptor for a panel range is host arithmetic -- a fresh minibatch of a
+        resident shard costs no device synchronisation (it was six: 0.2-0.3 ms beside a 0.13 ms
+        step)."""
+        hp = self.__dict__.get("_hp")
+        if hp is None:
+            nP, P = self.n_panels, self.panel_rows
+            edges = torch.clamp(torch.arange(nP + 1, dtype=torch.int64) * P, max=self.n_rows).to(self.device)
+            starts = self.row_ptr[edges].to(torch.int64).cpu().numpy()
+            ipp = self.items_per_panel.cpu().numpy()
+            iph = self.items_per_half.cpu().numpy()
+            hp = self._hp = {"starts": starts, "ipp": ipp, "iph": iph, "lg": None, "lg_of": None}
+        if self.row_lgamma is not None and hp["lg_of"] is not self.row_lgamma:
+            nP, P = self.n_panels, self.panel_rows
+            pad = nP * P - self.n_rows
+            lg = self.row_lgamma if pad == 0 else torch.cat(
+                [self.row_lgamma, torch.zeros(pad, dtype=torch.float64, device=self.device)])
+            hp["lg"] = lg.view(nP, P).sum(1).cpu().numpy() if self.n_rows else np.zeros(nP)
+            hp["lg_of"] = self.row_lgamma
+        return hp
+
     def batch_struct(self, p0=0, p1=None):
         """spmf_counts descriptor of panels [p0, p1)."""
         p1 = self.n_panels if p1 is None else min(p1, self.n_panels)
         r0 = p0 * self.panel_rows
         r1 = min(p1 * self.panel_rows, self.n_rows)
+        hp = self._host_panels()
         cs = _lib.CountsStruct()
         cs.struct_size = C.sizeof(_lib.CountsStruct)      # ABI guard, verified by the library
         cs.n_rows = r1 - r0
-        lo = int(self.row_ptr[r0]) if self.nnz else 0
-        hi = int(self.row_ptr[r1]) if self.nnz else 0
+        lo = int(hp["starts"][p0]) if self.nnz else 0
+        hi = int(hp["starts"][p1]) if self.nnz else 0
         cs.nnz = hi - lo
         cs.n_cols = self.n_cols
         cs.n_panels = p1 - p0
@@ -445,19 +469,19 @@ class SparseCounts:
         cs.pc_ptr = self.pc_ptr.data_ptr() + 4 * p0 * (self.n_cols + 1)
         cs.pc_row = self.pc_row.data_ptr()
         cs.pc_val = self.pc_val.data_ptr()
-        cs.lgamma_sum = (float(self.row_lgamma[r0:r1].sum())
-                         if self.row_lgamma is not None else 0.0)
+        cs.lgamma_sum = (float(hp["lg"][p0:p1].sum())
+                         if self.row_lgamma is not None and p1 > p0 else 0.0)
         cs.item_ptr = self.item_ptr.data_ptr() + 4 * p0
         cs.items = self.items.data_ptr()
-        cs.max_items_per_panel = (int(self.items_per_panel[p0:p1].max())
-                                  if self.items.numel() else 0)
+        cs.max_items_per_panel = (int(hp["ipp"][p0:p1].max())
+                                  if self.items.numel() and p1 > p0 else 0)
         cs.pc_pad = int(self.pc_pad)
         if self.col_split > 0:
             cs.item_mid = self.item_mid.data_ptr() + 4 * p0
             cs.col_split = self.col_split
             for h in range(2):
-                cs.max_items_half[h] = (int(self.items_per_half[h, p0:p1].max())
-                                        if self.items.numel() else 0)
+                cs.max_items_half[h] = (int(hp["iph"][h, p0:p1].max())
+                                        if self.items.numel() and p1 > p0 else 0)
         cs.gval = self.gval.data_ptr() if self.gval is not None else None
         cs.ent = self.ent.data_ptr() if getattr(self, "ent", None) is not None else None
         cs.pc_ent = self.pc_ent.data_ptr() if getattr(self, "pc_ent", None) is not None else None
