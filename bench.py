@@ -512,6 +512,34 @@ def main():
         except Exception as e:                      # no librccl on the box: report, do not fail
             extras["allreduce_1rank_us"] = None
             extras["allreduce_error"] = str(e)[:120]
+    if world == 1 and not args.no_extras:
+        # the data-format step in front of the path: the device layout of this whole
+        # workload built again from its resident CSR arrays by the library (csrc/layout.hip), and the
+        # statistics pre-pass (row sums + column sums of compute_scales)
+        from spmf_amd.sparse import SparseCounts as _SC
+
+        def _build():
+            return _SC(sc.row_ptr, sc.col_idx, sc.val, sc.n_rows, sc.n_cols, sc.panel_rows)
+        try:
+            sc2 = _build()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                sc2 = _build()
+            torch.cuda.synchronize()
+            extras["layout_build_ms"] = 1e3 * (time.perf_counter() - t0) / 3
+            extras["layout_native"] = bool(sc2.native_layout)
+            cs2 = torch.zeros(D, dtype=torch.float64, device=dev)
+            sc2.compute_stats(model._handle(), cs2, torch.zeros_like(cs2))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                sc2.compute_stats(model._handle(), cs2, torch.zeros_like(cs2))
+            torch.cuda.synchronize()
+            extras["stats_ms"] = 1e3 * (time.perf_counter() - t0) / 3
+            del sc2, cs2
+        except Exception as e:
+            extras["layout_error"] = str(e)[:200]
     if world == 1 and not args.no_extras and args.workload == "c3":
         # a second BASELINE config in the driver-timed record
         try:

@@ -168,8 +168,9 @@ class SparseCounts:
                 raise ValueError("nnz per shard must fit int32")
             col = torch.empty(nnz, dtype=torch.int32, device=t.device)
             val = torch.empty(nnz, dtype=torch.float32, device=t.device)
-            ok(lib.spmf_dense_fill_csr(idx, N, D, t.data_ptr(), D, row_ptr.data_ptr(), col.data_ptr(),
-                                       val.data_ptr(), st), "spmf_dense_fill_csr")
+            if nnz > 0:
+                ok(lib.spmf_dense_fill_csr(idx, N, D, t.data_ptr(), D, row_ptr.data_ptr(), col.data_ptr(),
+                                           val.data_ptr(), st), "spmf_dense_fill_csr")
             return cls(row_ptr, col, val, N, D, panel_rows, col_split, latent_dim)
         mask = t != 0
         counts = mask.sum(1)
