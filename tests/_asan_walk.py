@@ -67,9 +67,38 @@ for flags in (0, 1, 2 | 1, 4, 4 | 2, 8, 16 | 1):
         assert lib.spmf_allreduce(h, 4096, 8, None) == -1 and b"comm_init" in lib.spmf_last_error(h)
         assert lib.spmf_comm_init(h, None, 0, 1) == -1
         assert lib.spmf_comm_destroy(h) == 0
+        assert lib.spmf_counts_colstats(h, None, None, None, None) == -1
+        assert lib.spmf_counts_colstats(h, C.byref(cs), None, None, None) == -1          # n_cols != D
+        assert lib.spmf_counts_gvals(h, C.byref(cs), None, None, None, None) == -1
         ms = (C.c_float * 6)()
         assert lib.spmf_last_timing(h, ms) == -1
         lib.spmf_ctx_destroy(h)
+# the layout builder: geometry and buffer arithmetic, everything checked before the first device call
+assert lib.spmf_sizeof_layout_info() == C.sizeof(_lib.LayoutInfo)
+lb, sb = C.c_size_t(), C.c_size_t()
+for args in ((10, 5, 0, 4), (10, -1, 7, 4), (-1, 5, 7, 4), (10, 5, 7, 0)):
+    assert lib.spmf_layout_sizes(0, *args, C.byref(lb), C.byref(sb)) == -1 and lib.spmf_layout_last_error()
+assert lib.spmf_layout_sizes(0, 10, 2 ** 31, 7, 4, C.byref(lb), C.byref(sb)) == -4
+assert lib.spmf_layout_sizes(0, 2 ** 31, 5, 7, 4, C.byref(lb), C.byref(sb)) == -4
+assert lib.spmf_layout_sizes(0, 10, 5, 7, 4, None, None) == -1
+cs0, info = _lib.CountsStruct(), _lib.LayoutInfo()
+assert lib.spmf_layout_build(0, 10, 5, 7, 4096, 4096, 4096, 4, 0, 4096, 1 << 20, 4096, 1 << 20,
+                             C.byref(cs0), C.byref(info), None) == -1 and b"struct_size" in lib.spmf_layout_last_error()
+info.struct_size = C.sizeof(_lib.LayoutInfo)
+assert lib.spmf_layout_build(0, 10, 5, 7, 4096, None, None, 4, 0, 4096, 1 << 20, 4096, 1 << 20,
+                             C.byref(cs0), C.byref(info), None) == -1            # col_idx / val missing
+assert lib.spmf_layout_build(0, 10, 5, 7, 4096, 4096, 4096, 4, 9, 4096, 1 << 20, 4096, 1 << 20,
+                             C.byref(cs0), C.byref(info), None) == -1            # col_split > n_cols
+assert lib.spmf_layout_build(0, 10, 5, 7, 4096, 4096, 4096, 4, 0, 4097, 1 << 20, 4096, 1 << 20,
+                             C.byref(cs0), C.byref(info), None) == -1            # misaligned buffer
+assert lib.spmf_layout_build(0, 10, 5, 7, 4096, 4096, 4096, 4, 0, 4096, 1 << 20, 4096, 1 << 20,
+                             None, C.byref(info), None) == -1
+assert lib.spmf_dense_scratch_bytes(0) == 24 and lib.spmf_dense_scratch_bytes(1025) == 32
+assert lib.spmf_dense_row_ptr(0, 5, 0, 4096, 4, 4096, 4096, 64, None) == -1
+assert lib.spmf_dense_row_ptr(0, 5, 4, 4096, 3, 4096, 4096, 64, None) == -1     # ld < n_cols
+assert lib.spmf_dense_row_ptr(0, 5, 4, 4096, 4, 4096, 4096, 8, None) == -3      # scratch too small
+assert lib.spmf_dense_fill_csr(0, 5, 4, 4096, 3, 4096, 4096, 4096, None) == -1
+assert lib.spmf_dense_fill_csr(0, 0, 4, None, 4, 4096, None, None, None) == 0
 buf = (C.c_char * 128)()
 assert lib.spmf_comm_unique_id(buf) in (0, -4) and lib.spmf_comm_unique_id(None) == -1
 lib.spmf_ctx_destroy(None)
