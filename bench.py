@@ -634,7 +634,8 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 from pmc_traffic import kernels_sha
                 doc = json.load(open(pmc))
-                if doc.get("_kernels_sha") == kernels_sha():
+                # (collected on the workload at its named size and one GPU: not quoted for --rows runs or shards)
+                if doc.get("_kernels_sha") == kernels_sha() and args.rows is None and world == 1:
                     traffic = doc.get(args.workload, {}).get(dom, {}).get("traffic_bytes")
             except Exception:
                 traffic = None
