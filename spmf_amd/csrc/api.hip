@@ -192,6 +192,11 @@ static bool uses_sig3(const spmf_ctx* c) {
 static bool uses_exp3_32(const spmf_ctx* c) {
   return c->dense3 && likelihood_code(c) == 1 && c->KP == 32;
 }
+// Bernoulli + log_transform (code 4: logit = exp(<z, V'>) - 1 + phi, bernoulli.py:60-61) at KP = 32 on the same
+// family (ACT 2: exp accumulators as ACT 0, sigmoid / softplus epilogue as ACT 1, E = sigmoid * exp).
+static bool uses_sigexp3(const spmf_ctx* c) {
+  return c->dense3 && likelihood_code(c) == 4 && c->KP == 32;
+}
 static bool uses_e_buffer(const spmf_ctx* c) {
   return (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) && c->e_once &&
          likelihood_code(c) != 4 && !uses_dense3(c) && !uses_sig3(c) && !uses_exp3_32(c);
@@ -684,6 +689,21 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         launch_sigdot3(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E ; dacc[4]: saturation
         ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 0, nullptr, nullptr, nullptr, nullptr};
         launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+      } else if (uses_sigexp3(c) && !compact) {
+        // Bernoulli + log_transform at K padded to 32: (Z, W) with the bias on the Q rows, the softplus sum and
+        // three planes of E = sigmoid exp (V' has mixed signs), (W, Z) with the bias on the P rows and the
+        // sigmoid row sums for d/dphi
+        const int zt = (Dd + 127) / 128, wt = (int)((ct->n_rows + 127) / 128);
+        const int rpw = sigdot3_rows_per_wg(KP), slots = 256 * sigdot3_wgs_per_cu(KP);
+        const int zc = pick_chunks((int)((ct->n_rows + rpw - 1) / rpw), zt, slots, 16);
+        const int wc = pick_chunks((Dd + rpw - 1) / rpw, wt, slots, 256);
+        if (zc > 1) launch_zero(c->gzd, (size_t)ct->n_rows * KP * sizeof(float), st);
+        ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, zc, zc > 1 ? 1 : 0, 2, nullptr, lbias,
+            nullptr, nullptr};
+        ez.e_planes = 3;
+        launch_sigdot3(KP, ez, st);   // gzd_b = sum_d sigmoid(l) exp(X) V'_d ; dacc[3] = sum softplus(l)
+        ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 2, lbias, nullptr, gphi_acc, orows};
+        launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b ; gphi_d -= sum_b sigmoid(l)
       } else if (c->est && act != 2) {   // (act 2: E carries exp(X) too, its row sums are not the d/dphi sums)
         // E once: per row chunk, the Z-stationary kernel keeps E (exp, or the sigmoid of the
         // Bernoulli logits) and the second contraction (gV'_d -= sum_b E_bd z_b; Bernoulli:

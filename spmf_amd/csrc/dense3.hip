@@ -418,11 +418,12 @@ __device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ i
   constexpr int KS = KD / 16, MT = KD / 32, NSUB = kQT3 / 32;
   constexpr int PITCH = KD * 2 + 16;
   constexpr int IMG = kQT3 * PITCH;
-  f32x16 x[NSUB], xlo[ACT == 0 ? NSUB : 1];
+  constexpr bool XSPLIT = ACT != 1;      // the exp forms: a1 b1 and the five small products apart
+  f32x16 x[NSUB], xlo[XSPLIT ? NSUB : 1];
   u32x4 eb[NSUB][2][EPL];          // [sub][s2][plane]
   auto productA = [&](int sub) {
     f32x16 xi;
-    if (ACT == 0) {
+    if (XSPLIT) {
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       f32x16 xl = zero16;
       xi = zero16;
@@ -440,7 +441,7 @@ __device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ i
         xi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], pb[s][0], xi, 0, 0, 0);
       }
       x[sub] = xi;
-      xlo[ACT == 0 ? sub : 0] = xl;
+      xlo[XSPLIT ? sub : 0] = xl;
       return;
     }
     if (BQ) {
@@ -474,7 +475,7 @@ __device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ i
       f32x2 part2 = {0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        float x0 = x[sub][i] + xlo[ACT == 0 ? sub : 0][i], x1 = x[sub][i + 1] + xlo[ACT == 0 ? sub : 0][i + 1];
+        float x0 = x[sub][i] + xlo[XSPLIT ? sub : 0][i], x1 = x[sub][i + 1] + xlo[XSPLIT ? sub : 0][i + 1];
         if (EDGE) {
           const int qa = q0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
           x0 = (p_in && qa < NQ) ? x0 : -INFINITY;          // exp -> 0, and never the maximum
@@ -496,6 +497,17 @@ __device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ i
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
       float l0 = x[sub][i], l1 = x[sub][i + 1];
+      float ex0 = 1.f, ex1 = 1.f;
+      if (ACT == 2) {
+        // Bernoulli + log_transform (bernoulli.py:60-61): l = exp(X) - 1 + bias, saturating like the Poisson
+        // form; the second product takes E = sigmoid(l) exp(X) = d softplus(l) / dX
+        ex0 = __builtin_amdgcn_exp2f(fminf((l0 + xlo[XSPLIT ? sub : 0][i]) * kLog2e, kYSat * kLog2e));
+        ex1 = __builtin_amdgcn_exp2f(fminf((l1 + xlo[XSPLIT ? sub : 0][i + 1]) * kLog2e, kYSat * kLog2e));
+        const float b0 = BQ ? bq[32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h] : bp;
+        const float b1 = BQ ? bq[32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h + 1] : bp;
+        l0 = (ex0 - 1.f) + b0;
+        l1 = (ex1 - 1.f) + b1;
+      }
       if (EDGE) {
         const int qa = q0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
         l0 = (p_in && qa < NQ) ? l0 : -INFINITY;          // sigmoid -> 0, softplus -> 0
@@ -524,6 +536,10 @@ __device__ __forceinline__ void sigdot3_tile(const unsigned char* __restrict__ i
       if (CSUM) {
         cs0 += s0;
         cs1 += s1;
+      }
+      if (ACT == 2) {
+        s0 *= ex0;
+        s1 *= ex1;
       }
       const uint32_t p1 = pack_bf16(s0, s1);
       const float r0 = s0 - bf16_lo(p1), r1 = s1 - bf16_hi(p1);
@@ -620,7 +636,7 @@ __global__ __launch_bounds__(sig_nw(KD) * 64, SPMF_SIG3_WPS) void sigdot3_kernel
     double* __restrict__ esum, int atomic_out, const float* __restrict__ bias, float* __restrict__ out2,
     const int32_t* __restrict__ out_rows, int accumulate, const float* __restrict__ p_scale) {
   static_assert(KD == 32 || KD == 64, "sigdot3: K padded to 32 or 64");
-  static_assert(ACT == 1 || (EPL == 2 && !BQ && !CSUM), "the exp form: two planes of E, no bias, no row sums");
+  static_assert(ACT != 0 || (EPL == 2 && !BQ && !CSUM), "the exp form: two planes of E, no bias, no row sums");
   constexpr int KS = KD / 16, MT = KD / 32, NW = sig_nw(KD), NT = NW * 64;
   constexpr int PITCH = KD * 2 + 16;            // bytes per LDS row; 144 (KD 64) / 80 (KD 32): the 16 rows of a
                                                 // ds_read_b128 service group cover all 64 banks
@@ -810,7 +826,7 @@ bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
                        a.accumulate, a.p_scale);
     return true;
   }
-  if ((KD != 32 && KD != 64) || a.act != 1 || a.est || (a.bias_p && a.bias_q)) return false;
+  if ((KD != 32 && KD != 64) || (a.act != 1 && a.act != 2) || a.est || (a.bias_p && a.bias_q)) return false;
   const int chunks = a.q_chunks < 1 ? 1 : a.q_chunks;
   if (chunks > 1 && !a.atomic_out) return false;
   if (a.p_scale && a.out_rows) return false;      // (p_scale is indexed by the P row, not the output row)
@@ -827,6 +843,19 @@ bool launch_sigdot3(int KD, const ExpdotArgs& a, hipStream_t st) {
   // the two shapes the step uses; KD = 32 also has one general form for any other caller (at KD = 64 the
   // general form spills at two waves per SIMD: not built, the caller falls back to dense.hip)
   const bool zw = bq && es && !cs && epl == 3, wz = !bq && !es && cs && epl == 2;
+  if (a.act == 2) {
+    // Bernoulli + log_transform: the two shapes of the step at K padded to 32
+    if (KD != 32 || !(zw || wz)) return false;
+    if (zw)
+      hipLaunchKernelGGL((sigdot3_kernel<32, true, true, false, 3, 2>), dim3(nbx, chunks), dim3(sig_nw(32) * 64), 0, st,
+                         a.NP, a.NQ, a.P, a.Q, a.out, a.sign, a.esum, a.atomic_out, bias, a.out2, a.out_rows,
+                         a.accumulate, a.p_scale);
+    else
+      hipLaunchKernelGGL((sigdot3_kernel<32, false, false, true, 2, 2>), dim3(nbx, chunks), dim3(sig_nw(32) * 64), 0, st,
+                         a.NP, a.NQ, a.P, a.Q, a.out, a.sign, a.esum, a.atomic_out, bias, a.out2, a.out_rows,
+                         a.accumulate, a.p_scale);
+    return true;
+  }
   if (KD == 64) {
     if (zw) SPMF_SIG3(64, true, true, false, 3);
     else if (wz) SPMF_SIG3(64, false, false, true, 2);

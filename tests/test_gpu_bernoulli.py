@@ -59,10 +59,15 @@ def problem_logt(B, D, K, S, seed, density):
     return cfg, x, params
 
 
+@pytest.mark.parametrize("bf16x3", ["1", "0"])
 @pytest.mark.parametrize("B,D,K,S,density", [(37, 23, 3, 2, 0.3), (150, 90, 8, 1, 0.1),
-                                             (260, 200, 32, 1, 0.05), (300, 129, 64, 2, 0.05)])
-def test_bernoulli_log_transform_energy_and_grads(B, D, K, S, density):
+                                             (260, 200, 32, 1, 0.05), (300, 129, 64, 2, 0.05),
+                                             (1300, 700, 20, 1, 0.03)])
+def test_bernoulli_log_transform_energy_and_grads(monkeypatch, B, D, K, S, density, bf16x3):
+    """Both dense paths (read at spmf_ctx_create): K <= 32 on the bf16x3 kernels (dense3.hip sigdot3, ACT 2),
+    and the exact-f32 kernels; K = 64 runs the f32 kernels either way."""
     from spmf_amd import BernoulliFactorization
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", bf16x3)
     cfg, x, params = problem_logt(B, D, K, S, 1700 + B + K, density)
     pref, gref, _ = O.energy_and_grads(cfg, x, params)
     m = BernoulliFactorization(latent_dim=K, feature_dim=D, u_tau_scale=cfg.u_tau_scale,
@@ -84,8 +89,10 @@ def test_bernoulli_log_transform_energy_and_grads(B, D, K, S, density):
         assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1.0), k
 
 
-def test_bernoulli_log_transform_sweep_and_fit():
+@pytest.mark.parametrize("bf16x3", ["1", "0"])
+def test_bernoulli_log_transform_sweep_and_fit(monkeypatch, bf16x3):
     from spmf_amd import BernoulliFactorization
+    monkeypatch.setenv("SPMF_DENSE_BF16X3", bf16x3)
     rng = np.random.default_rng(79)
     for case in range(8):
         B, D = int(rng.integers(2, 300)), int(rng.integers(2, 300))

@@ -10,9 +10,11 @@ out=$root/spmf_amd/variants
 tmp=$(mktemp -d)
 mkdir -p $out
 pids=()
-for f in api prep row_pass col_pass finish stats dense dense3 dense_ll surrogate; do
+for f in api prep row_pass col_pass finish stats dense dense3 dense_ll surrogate layout; do
+  per=""
+  [ $f = dense3 ] && per="-fno-slp-vectorize"      # as in csrc/Makefile
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -DSPMF_BUILD --offload-arch=gfx950 \
-      -Wno-unused-function -I$root/include -I$src $extra -c $src/$f.hip -o $tmp/$f.o &
+      -Wno-unused-function -I$root/include -I$src $per $extra -c $src/$f.hip -o $tmp/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p || { echo "build_variant: a compile failed"; rm -rf $tmp; exit 1; }; done
