@@ -171,38 +171,41 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
       }
   };
   // issue order: A0 | A1 + E0 | C0 | A2 + E1 | C1 | A3 + E2 | C2 + E3 | C3
+  // SPMF_EXP3_DSLEAD (experiment, 0 = off): LDS reads as a scheduling group of their own -- a lead of that
+  // many reads at the head of a phase, then SPMF_EXP3_DSPER reads behind every MFMA -- instead of wherever the
+  // register-pressure heuristic sinks them (next to their use)
+#ifndef SPMF_EXP3_DSLEAD
+#define SPMF_EXP3_DSLEAD 0
+#endif
+#ifndef SPMF_EXP3_DSPER
+#define SPMF_EXP3_DSPER 1
+#endif
+#define SPMF_EXP3_PHASE(N_, V_)                                                                   \
+  do {                                                                                            \
+    if (SPMF_EXP3_DSLEAD > 0) __builtin_amdgcn_sched_group_barrier(0x100, SPMF_EXP3_DSLEAD, 0);    \
+    _Pragma("unroll") for (int i = 0; i < (N_); ++i) {                                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+      if (SPMF_EXP3_DSLEAD > 0) __builtin_amdgcn_sched_group_barrier(0x100, SPMF_EXP3_DSPER, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x002, (V_), 0);                                       \
+    }                                                                                             \
+  } while (0)
   productA(0);
   productA(1);
   expsplit(0);
-#pragma unroll
-  for (int i = 0; i < 24; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-  }
+  SPMF_EXP3_PHASE(24, 5);
   productC(0);
   productA(2);
   expsplit(1);
-#pragma unroll
-  for (int i = 0; i < 44; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-  }
+  SPMF_EXP3_PHASE(44, 3);
   productC(1);
   productA(3);
   expsplit(2);
-#pragma unroll
-  for (int i = 0; i < 44; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-  }
+  SPMF_EXP3_PHASE(44, 3);
   productC(2);
   expsplit(3);
-#pragma unroll
-  for (int i = 0; i < 20; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-  }
+  SPMF_EXP3_PHASE(20, 6);
   productC(3);
+#undef SPMF_EXP3_PHASE
 }
 
 #ifndef SPMF_EXP3_NW
