@@ -513,6 +513,17 @@ def main():
             extras["allreduce_1rank_us"] = None
             extras["allreduce_error"] = str(e)[:120]
     if world == 1 and not args.no_extras:
+        # "measure a copy kernel for the attainable HBM ceiling and report both": one
+        # 1 GiB device-to-device copy (read + write bytes), beside the 8 TB/s nominal peak
+        try:
+            src_ = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            dst_ = torch.empty_like(src_)
+            cp_ms = timed(lambda: dst_.copy_(src_), 10, 3)
+            extras["hbm_copy_gbps"] = 2 * src_.numel() * 4 / (cp_ms * 1e-3) / 1e9
+            del src_, dst_
+        except Exception as e:
+            extras["hbm_copy_error"] = str(e)[:120]
+    if world == 1 and not args.no_extras:
         # the data-format step in front of the path: the device layout of this whole
         # workload built again from its resident CSR arrays by the library (csrc/layout.hip), and the
         # statistics pre-pass (row sums + column sums of compute_scales)
@@ -677,6 +688,9 @@ def main():
             "achieved_hbm_gbps_step": b_tot_g / world / (ms_step * 1e-3) / 1e9,
             "frac_hbm_roofline_step": b_tot_g / world / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_step": b_tot_g,
+            # the same fraction against the copy rate measured on this box (also.hbm_copy_gbps), when it was
+            "frac_hbm_measured_copy_step": (b_tot_g / world / (ms_step * 1e-3) / 1e9 / extras["hbm_copy_gbps"]
+                                            if extras.get("hbm_copy_gbps") else None),
             "kernel_ms": {k: round(float(v), 4) for k, v in kern.items()},
             "roofline": roof or {"bound": "hbm", "kernel": dom, "achieved": achieved,
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
