@@ -88,6 +88,12 @@ __device__ __forceinline__ Split3 split3(float x) {
 // see it (A = first product of a sub-tile, E = exp + split, C = second product):
 //   A0 | A1 + E0 | C0 | A2 + E1 | C1 | A3 + E2 | C2 + E3 | C3
 // with sched_group_barrier asking for one MFMA per few vector instructions where both are present.
+// SPMF_EXP3_WHATIF (timing experiments only, WRONG numbers): bit 0 = the first product reads one LDS plane
+// instead of three, bit 1 = the second product does: what the matrix pipe does when two thirds of those reads go;
+// bit 2 = no v_exp in the epilogue
+#ifndef SPMF_EXP3_WHATIF
+#define SPMF_EXP3_WHATIF 0
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int kQT3 = 128;
@@ -108,7 +114,7 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
       bf16x8 a[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        a[pl] = *reinterpret_cast<const bf16x8*>(img + pl * IMG + (32 * sub + r) * kPitch3 + (16 * s + 8 * h) * 2);
+        a[pl] = *reinterpret_cast<const bf16x8*>(img + (SPMF_EXP3_WHATIF & 1 ? 0 : pl) * IMG + (32 * sub + r) * kPitch3 + (16 * s + 8 * h) * 2);
       xl[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], pb[s][0], s == 0 ? zero16 : xl[sub], 0, 0, 0);
       xl[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], pb[s][1], xl[sub], 0, 0, 0);
       xl[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], pb[s][2], xl[sub], 0, 0, 0);
@@ -132,8 +138,12 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
       xmax = __builtin_fmaxf(xmax, __builtin_fmaxf(x[0], x[1]));
       const f32x2 y = x * kLog2e;
       f32x2 e;
-      e[0] = __builtin_amdgcn_exp2f(fminf(y[0], kYSat * kLog2e));
-      e[1] = __builtin_amdgcn_exp2f(fminf(y[1], kYSat * kLog2e));
+      if (SPMF_EXP3_WHATIF & 4) {                       // (timing experiment: no exponential)
+        e = y;
+      } else {
+        e[0] = __builtin_amdgcn_exp2f(fminf(y[0], kYSat * kLog2e));
+        e[1] = __builtin_amdgcn_exp2f(fminf(y[1], kYSat * kLog2e));
+      }
       part2 += e;
       const uint32_t p1 = pack_bf16(e[0], e[1]);
       const f32x2 hi = {bf16_lo(p1), bf16_hi(p1)};
@@ -153,7 +163,7 @@ __device__ __forceinline__ void expdot3_tile(const unsigned char* __restrict__ i
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           // lds_tr_base: this lane's address inside a 4-row x 16-column block (rows = q, columns = k)
-          const uint32_t ad = lds_tr_base + pl * IMG + (32 * sub + 16 * s2) * kPitch3 + 32 * m * 2;
+          const uint32_t ad = lds_tr_base + (SPMF_EXP3_WHATIF & 2 ? 0 : pl) * IMG + (32 * sub + 16 * s2) * kPitch3 + 32 * m * 2;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4*)(uintptr_t)ad);
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
