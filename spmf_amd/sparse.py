@@ -11,8 +11,13 @@ the HIP path keeps one shard of the matrix as
   * per-row         ``row_sum`` (f32), ``row_lgamma`` = sum lgamma(x+1) (f64)
 
 A *batch* is a contiguous range of panels, so minibatching never re-sorts.
-torch is storage + one-time layout plumbing (sort/cumsum at build time); the
-per-row statistics come from the HIP pre-pass kernel ``spmf_counts_stats``.
+On the HIP device the layout is built by the library (``spmf_layout_build``,
+``spmf_dense_row_ptr`` / ``spmf_dense_fill_csr`` for dense batches,
+``spmf_counts_stats`` / ``spmf_counts_colstats`` / ``spmf_counts_gvals`` for the
+statistics and the log_transform streams): torch is storage.  The torch
+construction of the same arrays below is the host-side statement of the layout
+(CPU tensors, and the reference the library is compared with bit for bit in
+tests/test_gpu_layout.py; ``SPMF_NATIVE_LAYOUT=0`` selects it on the GPU).
 """
 from __future__ import annotations
 
