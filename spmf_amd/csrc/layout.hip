@@ -52,6 +52,22 @@ int lfail(int code, const std::string& m) {
 
 inline size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// The entry points below take a device ordinal: they make it current for their own launches and put
+// the caller's current device back on every return path (a process that drives several GPUs keeps its own).
+struct DeviceScope {
+  int prev = -1;
+  hipError_t err;
+  explicit DeviceScope(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+    else if (err != hipSuccess) prev = -1;
+    else prev = -1;                     // already current: nothing to restore
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 struct Geo {
   int64_t B, nnz, nkeys, max_items;
   int D, P, nP, seg, key_bits, item_bits;
@@ -568,7 +584,8 @@ int spmf_dense_row_ptr(int device, int64_t n_rows, int32_t n_cols, const float* 
   if (n_rows >= (int64_t(1) << 31)) return lfail(SPMF_E_UNSUPPORTED, "dense_row_ptr: n_rows must fit int32");
   if (scratch_bytes < spmf_dense_scratch_bytes(n_rows) || ((uintptr_t)scratch & 7))
     return lfail(SPMF_E_WORKSPACE, "dense_row_ptr: scratch smaller than spmf_dense_scratch_bytes or not 8-byte aligned");
-  LCHK(hipSetDevice(device));
+  DeviceScope dev_scope(device);
+  LCHK(dev_scope.err);
   hipStream_t st = (hipStream_t)stream;
   int64_t* bsum = (int64_t*)scratch;
   const int64_t nblk = n_rows > 0 ? (n_rows + kRowsPerBlock - 1) / kRowsPerBlock : 1;
@@ -590,7 +607,8 @@ int spmf_dense_fill_csr(int device, int64_t n_rows, int32_t n_cols, const float*
     return lfail(SPMF_E_ARG, "dense_fill_csr: bad arguments");
   if (n_rows == 0) return SPMF_OK;
   if (!dense || !col_idx || !val) return lfail(SPMF_E_ARG, "dense_fill_csr: null buffers");
-  LCHK(hipSetDevice(device));
+  DeviceScope dev_scope(device);
+  LCHK(dev_scope.err);
   const int64_t want = (n_rows + 3) / 4;
   hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0,
                      (hipStream_t)stream, n_rows, (int)n_cols, dense, ld, row_ptr, col_idx, val);
@@ -609,7 +627,8 @@ int spmf_layout_sizes(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, i
   int rc = make_geo(n_rows, nnz, n_cols, panel_rows, &g);
   if (rc) return rc;
   *layout_bytes = carve_layout(g).total;
-  LCHK(hipSetDevice(device));
+  DeviceScope dev_scope(device);
+  LCHK(dev_scope.err);
   ScratchCarve s;
   rc = carve_scratch(g, nullptr, &s);
   if (rc) return rc;
@@ -631,7 +650,8 @@ int spmf_layout_build(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, c
   Geo g;
   int rc = make_geo(n_rows, nnz, n_cols, panel_rows, &g);
   if (rc) return rc;
-  LCHK(hipSetDevice(device));
+  DeviceScope dev_scope(device);
+  LCHK(dev_scope.err);
   hipStream_t st = (hipStream_t)stream;
   const LayoutCarve L = carve_layout(g);
   ScratchCarve S;
