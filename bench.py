@@ -222,6 +222,59 @@ def c5_extra(dev, steps=10, warmup=3):
     return out
 
 
+def c4_extra(dev, steps=4, warmup=2):
+    """BASELINE config 4 (the scRNA script's model: 500k x 30k counts at 3 %, log_transform decoder, K = 64)
+    on this one GPU, for the `also` block of the default line, set up exactly as `--workload c4` does:
+    ms per energy + gradient step, the kernel taps, the bf16x3 dense kernels on the algorithmic 6*B*D*K
+    against the f32-MFMA peak (the same convention as C5).  After the headline's timed region."""
+    import contextlib
+    import ctypes as C
+    import torch
+    from spmf_amd import PoissonFactorization, _lib, synth
+    from spmf_amd.sparse import balanced_panel_rows
+    rows, D, density, K, _desc = WORKLOADS["c4"]
+    pr = balanced_panel_rows(rows, K)
+    sc = synth.scrna_like(rows, D, dev, 20241218 + 4, first_chunk=0, panel_rows=pr, chunk_rows=25_000,
+                          target_density=density)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1.0 / (rows * D) ** 0.5,
+                                     device=dev, panel_rows=pr, log_transform=True)
+    colsum = torch.zeros(D, dtype=torch.float64, device=dev)
+    colnnz = torch.zeros(D, dtype=torch.float64, device=dev)
+    sc.compute_stats(model._handle(), colsum, colnnz)
+    cmean = colsum / float(rows)              # bin/factorize_scrnaseq_counts.py:93-99, as in main()
+    model.eta_i = torch.clamp(cmean, min=1e-3).reshape(1, D)
+    model.xi_u_global = float(cmean.sum())
+    torch.manual_seed(20241218)
+    params = model.surrogate_distribution.sample(1)
+    batch = {"counts": sc}
+    lib, h = _lib.load(), model._handle()
+    for _ in range(warmup):
+        model.energy_and_grads(batch, params)
+    torch.cuda.synchronize()
+    lib.spmf_ctx_enable_timing(h, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        parts, _, nnf = model.energy_and_grads(batch, params)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    t6 = (C.c_float * 6)()
+    _lib.check(h, lib.spmf_last_timing(h, t6), "spmf_last_timing")
+    lib.spmf_ctx_enable_timing(h, 0)
+    tf = 6.0 * rows * D * K / (t6[5] * 1e-3) / 1e12
+    out = {"c4_ms_per_step": ms, "c4_steps_per_sec": 1e3 / ms, "c4_nnz": int(sc.nnz),
+           "c4_kernel_ms": {"prep": round(t6[0], 4), "row_pass": round(t6[1], 4), "col_pass": round(t6[2], 4),
+                            "finish": round(t6[3], 4), "dense": round(t6[5], 4)},
+           "c4_dense_tflops_algorithmic": tf, "c4_dense_frac": tf / MFMA_F32_PEAK_TFLOPS,
+           "c4_dense_frac_of": "algorithmic 6*B*D*K against the f32-MFMA peak (157.3 TF/s); the kernels run on the "
+                               "bf16 pipe with three-way split operands",
+           "c4_saturated": float(model.last_saturated.sum()), "c4_n_nonfinite": float(nnf.sum()),
+           "c4_elbo_x": float(parts["x"][0])}
+    del model, sc, params
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries below this script print there too
     # (RCCL writes a version banner from C when a communicator is created), so file
@@ -557,6 +610,12 @@ def main():
             extras.update(c5_extra(dev))
         except Exception as e:
             extras["c5_error"] = str(e)[:200]
+        # ... and a third (C4: seconds to generate on the device, 15 GB resident)
+        if os.environ.get("SPMF_BENCH_C4_EXTRA", "1") != "0":
+            try:
+                extras.update(c4_extra(dev))
+            except Exception as e:
+                extras["c4_error"] = str(e)[:200]
     if world == 1 and not args.no_extras:
         # "surrogate at its init values and after 50 seeded Adam steps" -- the same
         # energy + gradient step timed again at draws from the trained surrogate
