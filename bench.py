@@ -275,6 +275,51 @@ def c4_extra(dev, steps=4, warmup=2):
     return out
 
 
+def c2_extra(dev, steps=50, warmup=5):
+    """BASELINE config 2 (100k x 5k at 1 %, K = 16, linear decoder) as `--workload c2` sets it up, for the
+    `also` block of the default line: launch-latency-sized, ms per energy + gradient step."""
+    import contextlib
+    import ctypes as C
+    import torch
+    from spmf_amd import PoissonFactorization, _lib, synth
+    from spmf_amd.sparse import balanced_panel_rows
+    rows, D, density, K, _desc = WORKLOADS["c2"]
+    pr = balanced_panel_rows(rows, K)
+    sc = synth.linear_structure(rows, D, density, dev, first_chunk=0, panel_rows=pr)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1.0 / (rows * D) ** 0.5,
+                                     device=dev, panel_rows=pr)
+    colsum = torch.zeros(D, dtype=torch.float64, device=dev)
+    colnnz = torch.zeros(D, dtype=torch.float64, device=dev)
+    sc.compute_stats(model._handle(), colsum, colnnz)
+    cm = colsum / colnnz
+    model.eta_i = torch.where(cm > 1, cm, torch.ones_like(cm)).reshape(1, D)
+    model.xi_u_global = float(torch.nansum(cm))
+    torch.manual_seed(20241218)
+    params = model.surrogate_distribution.sample(1)
+    batch = {"counts": sc}
+    lib, h = _lib.load(), model._handle()
+    for _ in range(warmup):
+        model.energy_and_grads(batch, params)
+    torch.cuda.synchronize()
+    lib.spmf_ctx_enable_timing(h, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        parts, _, nnf = model.energy_and_grads(batch, params)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    t6 = (C.c_float * 6)()
+    _lib.check(h, lib.spmf_last_timing(h, t6), "spmf_last_timing")
+    lib.spmf_ctx_enable_timing(h, 0)
+    out = {"c2_ms_per_step": ms, "c2_steps_per_sec": 1e3 / ms, "c2_nnz": int(sc.nnz),
+           "c2_kernel_ms": {"prep": round(t6[0], 4), "row_pass": round(t6[1], 4), "col_pass": round(t6[2], 4),
+                            "finish": round(t6[3], 4)},
+           "c2_n_nonfinite": float(nnf.sum()), "c2_elbo_x": float(parts["x"][0])}
+    del model, sc, params
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries below this script print there too
     # (RCCL writes a version banner from C when a communicator is created), so file
@@ -610,6 +655,10 @@ def main():
             extras.update(c5_extra(dev))
         except Exception as e:
             extras["c5_error"] = str(e)[:200]
+        try:
+            extras.update(c2_extra(dev))
+        except Exception as e:
+            extras["c2_error"] = str(e)[:200]
         # ... and a third (C4: seconds to generate on the device, 15 GB resident)
         if os.environ.get("SPMF_BENCH_C4_EXTRA", "1") != "0":
             try:
