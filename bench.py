@@ -170,15 +170,35 @@ def c1_dense_cpu_baseline():
     return 1.0 / (0.5 * (ts[4] + ts[5])), cores
 
 
+def _timed_steps(model, batch, params, steps, warmup):
+    """ms per energy + gradient step and the kernel taps (spmf_last_timing) of `steps` calls after `warmup`."""
+    import ctypes as C
+    import torch
+    from spmf_amd import _lib
+    lib, h = _lib.load(), model._handle()
+    for _ in range(warmup):
+        model.energy_and_grads(batch, params)
+    torch.cuda.synchronize()
+    lib.spmf_ctx_enable_timing(h, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        parts, _, nnf = model.energy_and_grads(batch, params)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    t6 = (C.c_float * 6)()
+    _lib.check(h, lib.spmf_last_timing(h, t6), "spmf_last_timing")
+    lib.spmf_ctx_enable_timing(h, 0)
+    return ms, t6, parts, nnf
+
+
 def c5_extra(dev, steps=10, warmup=3):
     """BASELINE config 5 (mixed likelihood: 200k x 10k, even columns Poisson, odd columns
     Bernoulli, K = 32) on this one GPU, for the `also` block of the default line: ms per energy +
     gradient step, the kernel taps, and the dense sigmoid kernels against the f32-MFMA peak on
     the algorithmic 6*B*D_bern*K.  Generated after the headline's timed region."""
     import contextlib
-    import ctypes as C
     import torch
-    from spmf_amd import MixedFactorization, _lib, synth
+    from spmf_amd import MixedFactorization, synth
     from spmf_amd.sparse import balanced_panel_rows
     rows, D, _density, K, _desc = WORKLOADS["c5"]
     pr = balanced_panel_rows(rows, K)
@@ -196,19 +216,7 @@ def c5_extra(dev, steps=10, warmup=3):
     torch.manual_seed(20241218)
     params = model.surrogate_distribution.sample(1)
     batch = {"counts": sc}
-    lib, h = _lib.load(), model._handle()
-    for _ in range(warmup):
-        model.energy_and_grads(batch, params)
-    torch.cuda.synchronize()
-    lib.spmf_ctx_enable_timing(h, 1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        parts, _, nnf = model.energy_and_grads(batch, params)
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / steps
-    t6 = (C.c_float * 6)()
-    _lib.check(h, lib.spmf_last_timing(h, t6), "spmf_last_timing")
-    lib.spmf_ctx_enable_timing(h, 0)
+    ms, t6, parts, nnf = _timed_steps(model, batch, params, steps, warmup)
     d_bern = int(mask.sum())
     tf = 6.0 * rows * d_bern * max(32, K) / (t6[5] * 1e-3) / 1e12
     out = {"c5_ms_per_step": ms, "c5_steps_per_sec": 1e3 / ms, "c5_nnz": int(sc.nnz),
@@ -228,9 +236,8 @@ def c4_extra(dev, steps=4, warmup=2):
     ms per energy + gradient step, the kernel taps, the bf16x3 dense kernels on the algorithmic 6*B*D*K
     against the f32-MFMA peak (the same convention as C5).  After the headline's timed region."""
     import contextlib
-    import ctypes as C
     import torch
-    from spmf_amd import PoissonFactorization, _lib, synth
+    from spmf_amd import PoissonFactorization, synth
     from spmf_amd.sparse import balanced_panel_rows
     rows, D, density, K, _desc = WORKLOADS["c4"]
     pr = balanced_panel_rows(rows, K)
@@ -248,19 +255,7 @@ def c4_extra(dev, steps=4, warmup=2):
     torch.manual_seed(20241218)
     params = model.surrogate_distribution.sample(1)
     batch = {"counts": sc}
-    lib, h = _lib.load(), model._handle()
-    for _ in range(warmup):
-        model.energy_and_grads(batch, params)
-    torch.cuda.synchronize()
-    lib.spmf_ctx_enable_timing(h, 1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        parts, _, nnf = model.energy_and_grads(batch, params)
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / steps
-    t6 = (C.c_float * 6)()
-    _lib.check(h, lib.spmf_last_timing(h, t6), "spmf_last_timing")
-    lib.spmf_ctx_enable_timing(h, 0)
+    ms, t6, parts, nnf = _timed_steps(model, batch, params, steps, warmup)
     tf = 6.0 * rows * D * K / (t6[5] * 1e-3) / 1e12
     out = {"c4_ms_per_step": ms, "c4_steps_per_sec": 1e3 / ms, "c4_nnz": int(sc.nnz),
            "c4_kernel_ms": {"prep": round(t6[0], 4), "row_pass": round(t6[1], 4), "col_pass": round(t6[2], 4),
@@ -279,9 +274,8 @@ def c2_extra(dev, steps=50, warmup=5):
     """BASELINE config 2 (100k x 5k at 1 %, K = 16, linear decoder) as `--workload c2` sets it up, for the
     `also` block of the default line: launch-latency-sized, ms per energy + gradient step."""
     import contextlib
-    import ctypes as C
     import torch
-    from spmf_amd import PoissonFactorization, _lib, synth
+    from spmf_amd import PoissonFactorization, synth
     from spmf_amd.sparse import balanced_panel_rows
     rows, D, density, K, _desc = WORKLOADS["c2"]
     pr = balanced_panel_rows(rows, K)
@@ -298,19 +292,7 @@ def c2_extra(dev, steps=50, warmup=5):
     torch.manual_seed(20241218)
     params = model.surrogate_distribution.sample(1)
     batch = {"counts": sc}
-    lib, h = _lib.load(), model._handle()
-    for _ in range(warmup):
-        model.energy_and_grads(batch, params)
-    torch.cuda.synchronize()
-    lib.spmf_ctx_enable_timing(h, 1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        parts, _, nnf = model.energy_and_grads(batch, params)
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / steps
-    t6 = (C.c_float * 6)()
-    _lib.check(h, lib.spmf_last_timing(h, t6), "spmf_last_timing")
-    lib.spmf_ctx_enable_timing(h, 0)
+    ms, t6, parts, nnf = _timed_steps(model, batch, params, steps, warmup)
     out = {"c2_ms_per_step": ms, "c2_steps_per_sec": 1e3 / ms, "c2_nnz": int(sc.nnz),
            "c2_kernel_ms": {"prep": round(t6[0], 4), "row_pass": round(t6[1], 4), "col_pass": round(t6[2], 4),
                             "finish": round(t6[3], 4)},

@@ -79,6 +79,14 @@ def _as_csr_arrays(x):
     return None
 
 
+def _layout_check(lib, rc, what):
+    """Raise on a failed spmf_layout_* / spmf_dense_* call (context-free entry points: the message
+    is the calling thread's spmf_layout_last_error)."""
+    if rc != 0:
+        msg = lib.spmf_layout_last_error()
+        raise _lib.SpmfError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
 class SparseCounts:
     """One row shard of the count matrix in the layout the kernels read."""
 
@@ -159,9 +167,7 @@ class SparseCounts:
             st = torch.cuda.current_stream(t.device).cuda_stream
 
             def ok(rc, what):
-                if rc != 0:
-                    msg = lib.spmf_layout_last_error()
-                    raise _lib.SpmfError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+                _layout_check(lib, rc, what)
 
             row_ptr = torch.empty(N + 1, dtype=torch.int32, device=t.device)
             nb = int(lib.spmf_dense_scratch_bytes(N))
@@ -195,9 +201,7 @@ class SparseCounts:
         lb, sb = C.c_size_t(), C.c_size_t()
 
         def ok(rc, what):
-            if rc != 0:
-                msg = lib.spmf_layout_last_error()
-                raise _lib.SpmfError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+            _layout_check(lib, rc, what)
 
         ok(lib.spmf_layout_sizes(idx, self.n_rows, self.nnz, self.n_cols, self.panel_rows,
                                  C.byref(lb), C.byref(sb)), "spmf_layout_sizes")
