@@ -592,6 +592,30 @@ def main():
         except Exception as e:                      # no librccl on the box: report, do not fail
             extras["allreduce_1rank_us"] = None
             extras["allreduce_error"] = str(e)[:120]
+    if world == 1 and not args.no_extras and not logt and mixed_mask is None:
+        # the deterministic mode (spmf_ctx_set_deterministic) on the same resident workload: ms per step,
+        # the kernel taps, and whether two steps give the same bits (parts and all gradients)
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                mdet = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1.0 / (rows * D) ** 0.5,
+                                            device=dev, panel_rows=args.panel_rows, deterministic=True)
+            mdet.eta_i, mdet.xi_u_global = model.eta_i, model.xi_u_global
+            pa, ga, _ = mdet.energy_and_grads(batch, params)
+            pa = {k: v.clone() for k, v in pa.items()}
+            ga = {k: v.clone() for k, v in ga.items()}
+            pb, gb, _ = mdet.energy_and_grads(batch, params)
+            same = all(torch.equal(pa[k], pb[k]) for k in pa) and all(torch.equal(ga[k], gb[k]) for k in ga)
+            pd_, gd_, _ = model.energy_and_grads(batch, params)
+            dmax = max(float((ga[k] - gd_[k]).abs().max()) / max(float(gd_[k].abs().max()), 1e-30) for k in ga)
+            det_ms, t6d, _, _ = _timed_steps(mdet, batch, params, max(3, min(args.steps, 10)), 2)
+            extras["det_ms_per_step"] = det_ms
+            extras["det_kernel_ms"] = {"prep": round(t6d[0], 4), "row_pass": round(t6d[1], 4),
+                                       "col_pass_and_reduce": round(t6d[2], 4), "finish": round(t6d[3], 4)}
+            extras["det_bit_identical_repeat"] = bool(same)
+            extras["det_vs_default_grad_max_rel"] = dmax
+            del mdet, pa, ga, pb, gb, pd_, gd_
+        except Exception as e:
+            extras["det_error"] = str(e)[:200]
     if world == 1 and not args.no_extras:
         # "measure a copy kernel for the attainable HBM ceiling and report both": one
         # 1 GiB device-to-device copy (read + write bytes), beside the 8 TB/s nominal peak

@@ -145,13 +145,26 @@ typedef struct spmf_counts {
    * in the order (and with the pc_pad) of pc_row / pc_val; needs panel_rows <= 65536 as well
    * (rejected otherwise).  Used by the four-per-lane fetch only; NULL otherwise. */
   const uint32_t* pc_ent;
+  /* Optional, for the deterministic mode (spmf_ctx_set_deterministic): the work items in their
+   * GENERATION order -- (panel, column, segment) -- so that the per-item partial sums of the column
+   * pass can be added up column by column in a fixed order:
+   *   list_first[p * D + d] .. list_first[p * D + d + 1]   raw indices of the items cut from list
+   *                       (p, d) (pointer already offset to the batch's first panel, like pc_ptr with
+   *                       stride D; n_panels * D + 1 entries are read)
+   *   item_pos[r]         position of raw item r in `items` (absolute item index, base pointer)
+   *   n_items             items of THIS batch: item_ptr[n_panels] - item_ptr[0]
+   * spmf_layout_build fills them; NULL / 0 when unused. */
+  const int32_t* list_first;
+  const int32_t* item_pos;
+  int64_t n_items;
 } spmf_counts;
 
-/* ABI version of this header: 4.  (2 -> 3: spmf_counts.struct_size replaces a reserved slot
+/* ABI version of this header: 5.  (2 -> 3: spmf_counts.struct_size replaces a reserved slot
  * and is verified; pc_pad / ent / pc_ent are validated.  3 -> 4: the device layout builder
- * spmf_layout_* added; no struct or existing signature changed, a caller written for 3 runs
- * unchanged.)  A binding checks it at load time. */
-#define SPMF_ABI_VERSION 4
+ * spmf_layout_* added.  4 -> 5: spmf_counts grows by list_first / item_pos / n_items for the
+ * deterministic mode -- a caller built against 4 is refused by the struct_size check, not
+ * misread.)  A binding checks it at load time. */
+#define SPMF_ABI_VERSION 5
 int spmf_version(void);
 
 /* sizeof(spmf_counts) / sizeof(spmf_sur_var) / sizeof(spmf_adam_var) as this
@@ -185,6 +198,18 @@ int spmf_ctx_set_bernoulli_columns(spmf_ctx* ctx, const int32_t* cols, int n);
  * C4, 500k x 30k: 8 chunks at 8 GiB, one at 64 GiB).  Call before
  * spmf_workspace_bytes / spmf_ctx_set_workspace: it changes the workspace size. */
 int spmf_ctx_set_e_cap(spmf_ctx* ctx, size_t bytes);
+
+/* Deterministic mode (Poisson likelihood, linear decoder, no column split): the step's float and
+ * fp64 atomics are replaced by single-writer partial sums added up in a fixed order -- per-item
+ * partials of the column pass summed column by column in (panel, segment) order, per-workgroup
+ * scalar sums of the row pass summed in workgroup order -- so the 14 parts and all 12 gradients of
+ * a step are bit-identical from run to run (and replicas of a row-sharded job cannot drift apart
+ * through rounding order).  Costs the column pass its atomics' bandwidth twice (write + read of
+ * n_items * (2*KP + 4) floats): C3 2.80 -> see profiles/.  `scratch`: caller-owned device buffer of
+ * spmf_det_scratch_bytes(ctx, n_items, S) bytes for the largest batch (n_items = spmf_counts.n_items),
+ * 256-byte aligned; NULL switches the mode off.  The counts must carry list_first / item_pos. */
+size_t spmf_det_scratch_bytes(const spmf_ctx* ctx, int64_t n_items, int S);
+int spmf_ctx_set_deterministic(spmf_ctx* ctx, void* scratch, size_t bytes);
 
 /* Bytes of caller-owned device workspace needed for batches of up to
  * max_rows rows and S draws.  With SPMF_FLAG_LOG_TRANSFORM / BERNOULLI / MIXED this

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPMF_LIB_PATH") or os.path.join(_HERE, "libspmf_hip.so")
 
 NVARS = 12
-ABI_VERSION = 4          # include/spmf_hip.h SPMF_ABI_VERSION
+ABI_VERSION = 5          # include/spmf_hip.h SPMF_ABI_VERSION
 VI_STATE_LEN = 16
 NPARTS = 14
 #: variable order of the C-ABI = the reference's var_list (poisson.py:403-539,572)
@@ -51,6 +51,7 @@ class CountsStruct(C.Structure):
         ("item_mid", C.c_void_p), ("col_split", C.c_int32),
         ("max_items_half", C.c_int32 * 2), ("struct_size", C.c_int32),
         ("ent", C.c_void_p), ("pc_ent", C.c_void_p),
+        ("list_first", C.c_void_p), ("item_pos", C.c_void_p), ("n_items", C.c_int64),
     ]
 
 
@@ -92,6 +93,8 @@ SIGNATURES = {
     "spmf_ctx_set_column_types": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spmf_ctx_set_bernoulli_columns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "spmf_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int]),
+    "spmf_det_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int]),
+    "spmf_ctx_set_deterministic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "spmf_ctx_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "spmf_counts_stats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 7
                           + [C.c_void_p]),

@@ -29,6 +29,10 @@ struct spmf_ctx {
   float* acc = nullptr;
   double* dacc = nullptr;
   double* dprep = nullptr;
+  // deterministic mode (spmf_ctx_set_deterministic): caller-owned scratch for the row pass's per-workgroup
+  // scalar slots and the column pass's per-item partial sums; null = off
+  char* det_buf = nullptr;
+  size_t det_bytes = 0;
   double* fpart = nullptr;   // finish kernel: per-block prior-part sums
   float* futau = nullptr;    //                per-block u_tau gradient sums
   float *Ap = nullptr, *Vp = nullptr, *phi = nullptr, *z = nullptr, *gzs = nullptr, *gzd = nullptr, *dbias = nullptr;
@@ -515,6 +519,34 @@ int spmf_counts_gvals(spmf_ctx* c, const spmf_counts* ct, const float* eta, floa
   return SPMF_OK;
 }
 
+// deterministic-mode scratch, per draw: [kDetMeta + kDetMaxBlocks * (kDaccHead + KP) doubles | n_items * det_part_len floats]
+static size_t det_slot_doubles(int KP) { return (size_t)kDetMeta + (size_t)kDetMaxBlocks * (kDaccHead + KP); }
+static size_t det_slots_bytes(int KP) { return (det_slot_doubles(KP) * sizeof(double) + 255) & ~size_t(255); }
+static size_t det_part_bytes(int KP, int64_t n_items) {
+  return ((size_t)(n_items > 0 ? n_items : 0) * det_part_len(KP) * sizeof(float) + 255) & ~size_t(255);
+}
+size_t spmf_det_scratch_bytes(const spmf_ctx* c, int64_t n_items, int S) {
+  if (!c || S < 1) return 0;
+  return (size_t)S * (det_slots_bytes(c->KP) + det_part_bytes(c->KP, n_items));
+}
+int spmf_ctx_set_deterministic(spmf_ctx* c, void* scratch, size_t bytes) {
+  if (!c) return SPMF_E_ARG;
+  if (!scratch) {
+    c->det_buf = nullptr;
+    c->det_bytes = 0;
+    return SPMF_OK;
+  }
+  if (likelihood_code(c) != 0) return fail(c, SPMF_E_UNSUPPORTED,
+      "set_deterministic: Poisson likelihood with the linear decoder only (the dense sums of the other contexts "
+      "accumulate with float atomics)");
+  if (c->Dh > 0) return fail(c, SPMF_E_UNSUPPORTED, "set_deterministic: not together with the column split");
+  if ((uintptr_t)scratch & 255) return fail(c, SPMF_E_ARG, "set_deterministic: scratch must be 256-byte aligned");
+  if (bytes < spmf_det_scratch_bytes(c, 0, 1)) return fail(c, SPMF_E_WORKSPACE, "set_deterministic: scratch too small");
+  c->det_buf = (char*)scratch;
+  c->det_bytes = bytes;
+  return SPMF_OK;
+}
+
 // parts: bit 0 = zero, prep, row pass and the column pass of the lower column half (all columns
 // without a split); bit 1 = column pass of the upper half and the fp64 pack
 static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS],
@@ -531,6 +563,15 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
   if (ct->n_rows > 0 && ct->nnz > 0 && (!ct->pc_row || !ct->pc_val || !ct->item_ptr || !ct->items || ct->n_panels < 1)) return fail(c, SPMF_E_ARG, "counts: panel-CSC arrays / work items missing");
   for (int i : {0, 1, 2, 7})
     if (!params[i]) return fail(c, SPMF_E_ARG, "data_pass: params v,w,u,s must be non-null");
+  const bool det = c->det_buf != nullptr;
+  if (det) {
+    if (logt != 0 || c->Dh > 0 || parts_mask != 3) return fail(c, SPMF_E_UNSUPPORTED,
+        "deterministic mode: Poisson / linear decoder without the column split only");
+    if (ct->nnz > 0 && ct->n_rows > 0 && (!ct->list_first || !ct->item_pos || ct->n_items < 0)) return fail(c,
+        SPMF_E_ARG, "deterministic mode: counts.list_first / item_pos / n_items missing (spmf_layout_build fills them)");
+    if (spmf_det_scratch_bytes(c, ct->n_items, S) > c->det_bytes) return fail(c, SPMF_E_WORKSPACE,
+        "deterministic mode: scratch smaller than spmf_det_scratch_bytes for this batch");
+  }
   rc = bind_ws(c, ct->n_rows, S);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -543,6 +584,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
   if (!split && parts_mask != 3) return fail(c, SPMF_E_ARG, "data_pass_split needs spmf_ctx_set_column_split");
   if (parts_mask != 3 && S != 1) return fail(c, SPMF_E_UNSUPPORTED, "data_pass_split: one draw per step only");
   const bool first = parts_mask & 1, second = parts_mask & 2;
+  const size_t det_draw = det ? det_slots_bytes(KP) + det_part_bytes(KP, ct->n_items) : 0;
   // acc | dacc (contiguous in the carve) are zeroed by the first prep launch of the step,
   // slice by slice in its tile blocks; dprep is written, not accumulated (prep.hip)
   if (c->timing && first) {
@@ -576,6 +618,10 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
           dacc, 0, 0, nullptr, nullptr, nbat, D, dacc_stride};
       ra.ent = ct->ent;
+      if (det) {
+        ra.det_slots = (double*)(c->det_buf + (size_t)s * det_draw);
+        ra.det_stride = (int64_t)(det_draw / sizeof(double));
+      }
       launch_row_pass(KP, ra, st);
     } else if (ct->n_rows > 0 && uses_sig3(c)) {
       // Bernoulli / mixed columns with the linear decoder on the bf16x3 sigmoid kernels: ONE fused row
@@ -757,6 +803,12 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
             split ? hf + 1 : 0, nbat, ct->n_rows, (int64_t)al_, ct->pc_pad};
         ca.pc_ent = ct->pc_ent;
         ca.panel_rows = ct->panel_rows;
+        if (det) {
+          ca.det_slots = (const double*)(c->det_buf + (size_t)s * det_draw);
+          ca.det_stride = (int64_t)(det_draw / sizeof(double));
+          ca.det_part = (float*)(c->det_buf + (size_t)s * det_draw + det_slots_bytes(KP));
+          ca.det_part_stride = (int64_t)(det_draw / sizeof(float));
+        }
         if (hf == (split ? 1 : 0)) {
           // the fp64 scalars of the row pass are complete before this launch starts: its
           // extra first block folds them into the accumulator tail (the former pack launch)
@@ -768,6 +820,13 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
           launch_col_pass(KP, ca, st);
         }
       }
+    }
+    if (det && ct->n_rows > 0 && ct->nnz > 0) {
+      // the per-item partial sums, column by column in (panel, segment) order, into the zeroed accumulators
+      DetReduceArgs dr{D, KP, ct->n_panels, nbat, ct->list_first, ct->item_pos, ct->item_ptr,
+          (const float*)(c->det_buf + (size_t)s * det_draw + det_slots_bytes(KP)), (int64_t)(det_draw / sizeof(float)),
+          acc + L.gA_off(0), acc + L.gV_off(0), acc + L.gphi_off(0), (int64_t)al_};
+      launch_det_reduce(dr, st);
     }
     if (second) {
       if (!packed) {

@@ -61,12 +61,22 @@ namespace spmf {
 // pass's fp64 scalars into the accumulator tail as (hi, lo) float pairs, so that ONE fp32
 // all-reduce finishes the step.  The row pass is a previous launch: its sums are complete.
 template <int KP>
-__device__ __forceinline__ void pack_block(const double* __restrict__ dacc, float* __restrict__ tail) {
+__device__ __forceinline__ void pack_block(const double* __restrict__ dacc, float* __restrict__ tail,
+                                           const double* __restrict__ det_slots) {
   const int i = threadIdx.x;
   if (i < kDaccHead + KP) {
     double v = 0.0;
+    if (det_slots) {
+      // deterministic mode: the row pass's workgroups left their sums in their own slots; add them in
+      // workgroup order (slots 3..5 -- dense sum, saturation, spare -- are not produced by this mode's
+      // linear decoder and stay 0)
+      const int nb = (int)det_slots[0];
+      const double* sl = det_slots + kDetMeta + i;
+      for (int b = 0; b < nb; ++b) v += sl[(size_t)b * (kDaccHead + KP)];
+    } else {
 #pragma unroll
-    for (int r = 0; r < kDaccRep; ++r) v += dacc[(size_t)r * (kDaccHead + KP) + i];
+      for (int r = 0; r < kDaccRep; ++r) v += dacc[(size_t)r * (kDaccHead + KP) + i];
+    }
     const float hi = (float)v;
     tail[2 * i] = hi;
     tail[2 * i + 1] = (float)(v - (double)hi);
@@ -95,11 +105,13 @@ __global__ __launch_bounds__(256, EPL == 4 ? COL_WIDE_WAVES : 1) void col_pass_k
     const uint8_t* __restrict__ ctype, const int32_t* __restrict__ item_mid, int half_sel,
     int64_t Brows, int64_t acc_stride, const double* __restrict__ pack_dacc,
     float* __restrict__ pack_tail, int64_t dacc_stride, const uint32_t* __restrict__ pc_ent,
-    int panel_rows) {
+    int panel_rows, float* __restrict__ det_part, int64_t det_part_stride,
+    const double* __restrict__ det_slots, int64_t det_stride) {
   static_assert(EPL == 1 || EPL == 4, "entries per lane and fetch: 1 or 4");
   static_assert(!PACKED || EPL == 4, "the packed lists are read by the wide fetch only");
   if (pack_dacc && blockIdx.x == 0) {
-    pack_block<KP>(pack_dacc + (size_t)blockIdx.y * dacc_stride, pack_tail + (size_t)blockIdx.y * acc_stride);
+    pack_block<KP>(pack_dacc + (size_t)blockIdx.y * dacc_stride, pack_tail + (size_t)blockIdx.y * acc_stride,
+                   det_slots ? det_slots + (size_t)blockIdx.y * det_stride : nullptr);
     return;
   }
   if (gridDim.y > 1) {   // S draws per launch
@@ -281,6 +293,18 @@ __global__ __launch_bounds__(256, EPL == 4 ? COL_WIDE_WAVES : 1) void col_pass_k
   // (a wave leaves through 8 float-atomic wave instructions, each covering two whole 128-B gradient
   //  rows: the shape MI355X runs atomics at full rate; n_items * (2KP+1)*4 B, 0.49 GB on C3.  The
   //  owner form that needs no atomics was measured and rejected: profiles/r04_col_owner_probe.txt)
+  if (det_part) {
+    // deterministic mode: the item's sums go to its own slot (single writer, plain 16-B stores);
+    // det_reduce_kernel adds a column's items up in (panel, segment) order
+    if (ok) {
+      float4* dst = reinterpret_cast<float4*>(det_part + (size_t)blockIdx.y * det_part_stride +
+                                              (size_t)(it - item_ptr[0]) * det_part_len(KP));
+      dst[sub] = gV;
+      dst[LPN + sub] = gA;
+      if (sub == 0) dst[2 * LPN] = make_float4(gph, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   float4* st4 = reinterpret_cast<float4*>(&stage[wid][grp][0]);
   st4[sub] = gV;
   st4[LPN + sub] = gA;
@@ -315,7 +339,7 @@ static bool launch_col_t(const ColArgs& a, hipStream_t st) {
   dim3((unsigned)nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, a.D, a.n_panels, a.row_base, bpp,   \
       a.item_ptr, items, a.pc_row, a.pc_val, a.pc_gval, a.Vp, a.phi, a.z, a.gzs, a.gAp, a.gVp, \
       a.gphi, a.ctype, a.item_mid, a.half_sel, a.B, a.acc_stride, a.pack_dacc, a.pack_tail,     \
-      a.dacc_stride, a.pc_ent, a.panel_rows
+      a.dacc_stride, a.pc_ent, a.panel_rows, a.det_part, a.det_part_stride, a.det_slots, a.det_stride
   const bool wide = COL_WIDE && a.pc_pad >= KP - 1;   // 4*LPN - 1 entries of readable padding
   // packed lists (spmf_counts.pc_ent: row in panel << 16 | count) when the batch carries them
   const bool packed = wide && a.pc_ent && a.panel_rows > 0 && a.panel_rows <= 65536;
@@ -336,6 +360,61 @@ static bool launch_col_t(const ColArgs& a, hipStream_t st) {
 #undef SPMF_COL_LAUNCH
 #undef SPMF_COL_ARGS
   return true;
+}
+
+// Deterministic mode: one lane group per column adds the partial sums of the column's work items in
+// generation order -- panel by panel, segment by segment -- into gV', gA', gphi (zeroed by the prep
+// launch; single writer per column).  Reads n_items * det_part_len floats once.
+template <int KP>
+__global__ __launch_bounds__(256) void det_reduce_kernel(int D, int n_panels, const int32_t* __restrict__ list_first,
+                                                         const int32_t* __restrict__ item_pos,
+                                                         const int32_t* __restrict__ item_ptr,
+                                                         const float* __restrict__ part, int64_t part_stride,
+                                                         float* __restrict__ gAp, float* __restrict__ gVp,
+                                                         float* __restrict__ gphi, int64_t acc_stride) {
+  constexpr int LPN = KP / 4;
+  const int sub = threadIdx.x % LPN;
+  const int d = blockIdx.x * (256 / LPN) + threadIdx.x / LPN;
+  if (d >= D) return;
+  part += (size_t)blockIdx.y * part_stride;
+  gAp += (size_t)blockIdx.y * acc_stride;
+  gVp += (size_t)blockIdx.y * acc_stride;
+  gphi += (size_t)blockIdx.y * acc_stride;
+  const int it0 = item_ptr[0];
+  float4 gV = make_float4(0.f, 0.f, 0.f, 0.f), gA = gV;
+  float gph = 0.f;
+  for (int p = 0; p < n_panels; ++p) {
+    const int32_t* lf = list_first + (size_t)p * D + d;
+    const int r0 = lf[0], r1 = lf[1];
+    for (int r = r0; r < r1; ++r) {
+      const float4* src = reinterpret_cast<const float4*>(part + (size_t)(item_pos[r] - it0) * det_part_len(KP));
+      const float4 a = src[sub], b = src[LPN + sub];
+      gV.x += a.x; gV.y += a.y; gV.z += a.z; gV.w += a.w;
+      gA.x += b.x; gA.y += b.y; gA.z += b.z; gA.w += b.w;
+      if (sub == 0) gph += src[2 * LPN].x;
+    }
+  }
+  reinterpret_cast<float4*>(gVp + (size_t)d * KP)[sub] = gV;
+  reinterpret_cast<float4*>(gAp + (size_t)d * KP)[sub] = gA;
+  if (sub == 0) gphi[d] = gph;
+}
+
+void launch_det_reduce(const DetReduceArgs& a, hipStream_t st) {
+  if (a.D <= 0 || a.n_panels <= 0) return;
+#define SPMF_DET(KP_)                                                                                        \
+  hipLaunchKernelGGL((det_reduce_kernel<KP_>), dim3((a.D + 256 / (KP_ / 4) - 1) / (256 / (KP_ / 4)),          \
+                                                    a.S > 1 ? a.S : 1),                                       \
+                     dim3(256), 0, st, a.D, a.n_panels, a.list_first, a.item_pos, a.item_ptr, a.part,        \
+                     a.part_stride, a.gAp, a.gVp, a.gphi, a.acc_stride)
+  switch (a.KP) {
+    case 4: SPMF_DET(4); break;
+    case 8: SPMF_DET(8); break;
+    case 16: SPMF_DET(16); break;
+    case 32: SPMF_DET(32); break;
+    case 64: SPMF_DET(64); break;
+    default: break;
+  }
+#undef SPMF_DET
 }
 
 bool launch_col_pass(int KP, const ColArgs& a, hipStream_t st) {

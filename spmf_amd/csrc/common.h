@@ -66,6 +66,12 @@ constexpr int kFinishCols = FINISH_FTD;
 // fp64 atomics of thousands of blocks do not serialise on 4+KP addresses;
 // the pack kernel folds the replicas.
 constexpr int kDaccRep = 16;
+// Deterministic mode (spmf_ctx_set_deterministic): per-workgroup scalar slots of the row pass instead of
+// its fp64 atomics -- at most this many workgroups (ROW_MAX_BLOCKS), slot -1 = the launch's workgroup count;
+// per-item partial sums of the column pass: 2*KP + 4 floats per work item (gV', gA', gphi + padding)
+constexpr int kDetMaxBlocks = 4096;
+constexpr int kDetMeta = 8;      // doubles in front of the slots ([0] = workgroups of the row-pass launch)
+__host__ __device__ inline int det_part_len(int KP) { return 2 * KP + 4; }
 
 // fp32 accumulator tail: the fp64 scalars as (hi,lo) float pairs.
 __host__ __device__ inline int acc_tail_len(int KP) { return 2 * (kDaccHead + KP); }

@@ -46,6 +46,10 @@ struct RowArgs {
   // mode 3 with the exp decoder (LIK 1): `val` is g(x) (sweep 1) and the counts of sweep 2 come out of `ent`
   // (must be non-null); only the LDS-phi launch shapes have this form: launch_row_pass returns false otherwise
   int dual = 0;
+  // deterministic mode: the workgroups' scalar sums go to their own slots (kDetMeta + kDetMaxBlocks *
+  // (kDaccHead + KP) doubles per draw, stride det_stride) instead of the fp64 atomics on dacc
+  double* det_slots = nullptr;
+  int64_t det_stride = 0;
 };
 bool launch_row_pass(int KP, const RowArgs& a, hipStream_t st);   // false: a.dual asked for a form this shape lacks (nothing launched)
 
@@ -75,7 +79,26 @@ struct ColArgs {
   const double* pack_dacc = nullptr;
   float* pack_tail = nullptr;
   int64_t dacc_stride = 0;
+  // deterministic mode: per-item partial sums (det_part_len(KP) floats per item of the batch, item index
+  // relative to item_ptr[0]; stride det_part_stride floats per draw) instead of the float atomics, and the
+  // pack block reads the row pass's per-workgroup slots
+  float* det_part = nullptr;
+  int64_t det_part_stride = 0;
+  const double* det_slots = nullptr;
+  int64_t det_stride = 0;
 };
+// deterministic mode: adds the per-item partials up column by column in (panel, segment) order
+struct DetReduceArgs {
+  int D, KP, n_panels, S;
+  const int32_t* list_first;   // [n_panels * D + 1], offset to the batch's first panel
+  const int32_t* item_pos;
+  const int32_t* item_ptr;     // [0] = first item of the batch
+  const float* part;
+  int64_t part_stride;
+  float *gAp, *gVp, *gphi;
+  int64_t acc_stride;
+};
+void launch_det_reduce(const DetReduceArgs& a, hipStream_t st);
 
 struct ExpdotArgs {
   int NP, NQ;

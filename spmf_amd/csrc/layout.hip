@@ -111,7 +111,7 @@ int make_geo(int64_t B, int64_t nnz, int D, int P, Geo* g) {
 }
 
 struct LayoutCarve {
-  size_t pc_ptr, pc_row, pc_val, pc_ent, ent, item_ptr, item_mid, per_panel, lower, items, total;
+  size_t pc_ptr, pc_row, pc_val, pc_ent, ent, item_ptr, item_mid, per_panel, lower, items, list_first, item_pos, total;
 };
 LayoutCarve carve_layout(const Geo& g) {
   LayoutCarve c{};
@@ -127,12 +127,14 @@ LayoutCarve carve_layout(const Geo& g) {
   c.per_panel = take((size_t)g.nP * 4);
   c.lower = take((size_t)g.nP * 4);
   c.items = take((size_t)g.max_items * 16);
+  c.list_first = take(((size_t)g.nkeys + 1) * 4);     // raw index of each list's first work item
+  c.item_pos = take((size_t)g.max_items * 4);          // raw item -> position in `items`
   c.total = o;
   return c;
 }
 
 struct ScratchCarve {
-  size_t key_in, key_out, word_in, excl, nseg, first, raw, ikey_in, ikey_out, ival_in, ival_out, info, temp,
+  size_t key_in, key_out, word_in, excl, nseg, raw, ikey_in, ikey_out, ival_in, ival_out, info, temp,
       temp_bytes, total;
 };
 
@@ -153,7 +155,6 @@ int carve_scratch(const Geo& g, hipStream_t st, ScratchCarve* out) {
   c.word_in = take(((size_t)g.nnz + 1) * 4);
   c.excl = take(((size_t)g.nkeys + 1) * 4);
   c.nseg = take(((size_t)g.nkeys + 1) * 4);
-  c.first = take(((size_t)g.nkeys + 1) * 4);
   c.raw = take((size_t)g.max_items * 16);
   c.ikey_in = take((size_t)g.max_items * 4);
   c.ikey_out = take((size_t)g.max_items * 4);
@@ -324,9 +325,14 @@ __global__ __launch_bounds__(256) void layout_items_kernel(int64_t nkeys, int D,
 __global__ __launch_bounds__(256) void layout_gather_items_kernel(const int* __restrict__ info,
                                                                   const int4* __restrict__ raw,
                                                                   const uint32_t* __restrict__ sval,
-                                                                  int4* __restrict__ items) {
+                                                                  int4* __restrict__ items,
+                                                                  int32_t* __restrict__ item_pos) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < info[I_NITEMS]) items[j] = raw[sval[j]];
+  if (j < info[I_NITEMS]) {
+    const uint32_t r = sval[j];
+    items[j] = raw[r];
+    item_pos[r] = (int32_t)j;        // the permutation inverted: raw (generation-order) item -> sorted position
+  }
 }
 
 __device__ __forceinline__ int lower_bound_u32(const uint32_t* __restrict__ a, int n, uint32_t v) {
@@ -494,7 +500,7 @@ int run_build(const Geo& g, const int32_t* row_ptr, const int32_t* col, const fl
   uint32_t* ent = g.D <= 65536 ? (uint32_t*)(layout + L.ent) : nullptr;
   int* info = (int*)(scratch + S.info);
   int32_t* excl = (int32_t*)(scratch + S.excl);
-  int32_t* first = (int32_t*)(scratch + S.first);
+  int32_t* first = (int32_t*)(layout + L.list_first);
   void* temp = scratch + S.temp;
   size_t tb = S.temp_bytes;
   const int64_t want = (g.B + 3) / 4;
@@ -541,7 +547,8 @@ int run_build(const Geo& g, const int32_t* row_ptr, const int32_t* col, const fl
       LCHK(rocprim::radix_sort_pairs(temp, tb, ikey_in, ikey_out, ival_in, ival_out, (size_t)g.max_items, 0u,
                                      (unsigned)g.item_bits, st));
       hipLaunchKernelGGL(layout_gather_items_kernel, dim3(blocks_for(g.max_items)), dim3(256), 0, st, info,
-                         (const int4*)(scratch + S.raw), ival_out, (int4*)(layout + L.items));
+                         (const int4*)(scratch + S.raw), ival_out, (int4*)(layout + L.items),
+                         (int32_t*)(layout + L.item_pos));
       hipLaunchKernelGGL(layout_panel_items_kernel, dim3(blocks_for(g.nP)), dim3(256), 0, st, g.nP, g.seg, ikey_out,
                          (int32_t*)(layout + L.item_ptr), (int32_t*)(layout + L.item_mid),
                          (int32_t*)(layout + L.per_panel), (int32_t*)(layout + L.lower), info);
@@ -694,6 +701,9 @@ int spmf_layout_build(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, c
   c.max_items_half[1] = hi[I_MAXHI];
   c.col_split = col_split;
   c.pc_pad = kPcPad;
+  c.list_first = (const int32_t*)(lb + L.list_first);
+  c.item_pos = (const int32_t*)(lb + L.item_pos);
+  c.n_items = hi[I_NITEMS];
   c.ent = values_pack && g.D <= 65536 ? (const uint32_t*)(lb + L.ent) : nullptr;
   c.pc_ent = values_pack && packed_words ? (const uint32_t*)(lb + L.pc_ent) : nullptr;
   *out = c;

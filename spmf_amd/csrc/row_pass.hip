@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     const double* __restrict__ dprep, float* __restrict__ z, float* __restrict__ gzs,
     double* __restrict__ dacc, int mode, const float* __restrict__ gzd,
     const uint8_t* __restrict__ ctype, int Dcols, int64_t dacc_stride,
-    const uint32_t* __restrict__ ent) {
+    const uint32_t* __restrict__ ent, double* __restrict__ det_slots, int64_t det_stride) {
   if (gridDim.y > 1) {   // S draws per launch: tables, outputs and accumulators of draw blockIdx.y
     const size_t sd = blockIdx.y;
     Ap += sd * (size_t)Dcols * KP;
@@ -409,6 +409,27 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
   const double ll_b = block_sum(ll_acc, red);
   const double zq_b = block_sum(zsq_acc, red);
   const double nf_b = block_sum(nnf_acc, red);
+  if (det_slots) {
+    // deterministic mode: this workgroup's sums in its own slot; the pack block of the column pass adds
+    // the slots up in workgroup order
+    double* sl = det_slots + (size_t)blockIdx.y * det_stride;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sl[0] = (double)gridDim.x;
+    sl += kDetMeta + (size_t)blockIdx.x * (kDaccHead + KP);
+    if (threadIdx.x == 0) {
+      sl[0] = ll_b;
+      sl[1] = zq_b;
+      sl[2] = nf_b;
+      sl[3] = sl[4] = sl[5] = 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < KP) {
+      double t = 0.0;
+      const int nw = blockDim.x >> 6;
+      for (int i = 0; i < nw; ++i) t += zred[i][threadIdx.x];
+      sl[kDaccHead + threadIdx.x] = t;
+    }
+    return;
+  }
   dacc += (size_t)(blockIdx.x % kDaccRep) * (kDaccHead + KP);
   if (threadIdx.x == 0) {
     atomicAdd(&dacc[0], ll_b);
@@ -461,7 +482,7 @@ static bool launch_row_lds_t(const RowArgs& a, hipStream_t st) {
   const int nb = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   hipLaunchKernelGGL((row_pass_kernel<KP, LIK, BT, PACKED>), dim3(nb, a.S > 1 ? a.S : 1), dim3(BT), lds, st,
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z,
-                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent);
+                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent, a.det_slots, a.det_stride);
   return true;
 }
 
@@ -515,7 +536,7 @@ static bool launch_row_t(const RowArgs& a, hipStream_t st) {
 #define SPMF_ROW_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, \
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, \
-                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent)
+                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent, a.det_slots, a.det_stride)
   if (a.logt == 4) SPMF_ROW_LAUNCH(4);
   else if (a.logt == 3) SPMF_ROW_LAUNCH(3);
   else if (a.logt == 2) SPMF_ROW_LAUNCH(2);

@@ -90,6 +90,12 @@ class PoissonFactorization:
             ("cuda" if torch.cuda.is_available() else "cpu"))
         self._ctx = None
         self._ws = None
+        # deterministic=True (build-defined keyword, not in the reference): bit-reproducible energy and
+        # gradients -- the step's atomics replaced by fixed-order sums (spmf_ctx_set_deterministic);
+        # Poisson likelihood with the linear decoder only
+        self.deterministic = bool(kwargs.pop("deterministic", False))
+        self._det_buf = None
+        self._det_ctx = None
         self._eta_dev = None
         self._eta_key = None
         self._batch_cache = {}
@@ -237,6 +243,19 @@ class PoissonFactorization:
             _lib.check(h, lib.spmf_ctx_set_workspace(h, self._ws_ptr, self._ws.numel() - off),
                        "spmf_ctx_set_workspace")
 
+    def _ensure_det_scratch(self, n_items, S):
+        """Scratch of the deterministic mode for a batch of ``n_items`` work items and S draws."""
+        lib, h = _lib.load(), self._handle()
+        need = int(lib.spmf_det_scratch_bytes(h, int(n_items), int(S)))
+        if self._det_buf is None or self._det_buf.numel() < need + 256 or self._det_ctx != h:
+            if self._det_buf is None or self._det_buf.numel() < need + 256:
+                self._det_buf = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            self._det_ctx = h
+            base = self._det_buf.data_ptr()
+            off = (-base) % 256
+            _lib.check(h, lib.spmf_ctx_set_deterministic(h, base + off, self._det_buf.numel() - off),
+                       "spmf_ctx_set_deterministic")
+
     def _eta_device(self):
         """eta_i as a [D] fp32 device vector (ones when unscaled)."""
         e = self.eta_i
@@ -367,6 +386,8 @@ class PoissonFactorization:
         sc, cs = self._batch(data)
         S, P = self._pack_params(params)
         self._ensure_workspace(cs.n_rows, S)
+        if self.deterministic:
+            self._ensure_det_scratch(cs.n_items, S)
         eta = self._eta_device()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         # the C-ABI takes twelve slots in VAR_ORDER; variables the model does not have

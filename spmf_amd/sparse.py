@@ -236,6 +236,8 @@ class SparseCounts:
         self.items = view(cs.items, 4 * n_items).view(n_items, 4)
         self.item_ptr = view(cs.item_ptr, nP + 1)
         self.item_mid = view(cs.item_mid, nP)
+        self.list_first = view(cs.list_first, nP * D + 1)     # deterministic mode: items in generation order
+        self.item_pos = view(cs.item_pos, n_items)
         per_panel = view(info.items_per_panel, nP).to(torch.int64)
         lower = view(info.items_lower, nP).to(torch.int64)
         self.items_per_panel = per_panel
@@ -317,6 +319,14 @@ class SparseCounts:
         items = torch.stack([start[order], length[order], col[order],
                              torch.zeros_like(col[order])], 1)
         self.items = items.to(torch.int32).contiguous()
+        # the items in generation order -- (panel, column, segment) -- for the deterministic mode:
+        # first raw item of every list, and where each raw item went in the sort
+        lf = torch.zeros(nseg.numel() + 1, dtype=torch.int64, device=dev)
+        lf[1:] = torch.cumsum(nseg, 0)
+        self.list_first = lf.to(torch.int32).contiguous()
+        pos = torch.empty(order.numel(), dtype=torch.int64, device=dev)
+        pos[order] = torch.arange(order.numel(), device=dev, dtype=torch.int64)
+        self.item_pos = pos.to(torch.int32).contiguous()
         per_panel = torch.bincount(panel, minlength=nP)
         ip = torch.zeros(nP + 1, dtype=torch.int64, device=dev)
         ip[1:] = torch.cumsum(per_panel, 0)
@@ -445,7 +455,8 @@ class SparseCounts:
             starts = self.row_ptr[edges].to(torch.int64).cpu().numpy()
             ipp = self.items_per_panel.cpu().numpy()
             iph = self.items_per_half.cpu().numpy()
-            hp = self._hp = {"starts": starts, "ipp": ipp, "iph": iph, "lg": None, "lg_of": None}
+            iptr = np.concatenate([[0], np.cumsum(ipp)]).astype(np.int64)
+            hp = self._hp = {"starts": starts, "ipp": ipp, "iph": iph, "iptr": iptr, "lg": None, "lg_of": None}
         if self.row_lgamma is not None and hp["lg_of"] is not self.row_lgamma:
             nP, P = self.n_panels, self.panel_rows
             pad = nP * P - self.n_rows
@@ -492,6 +503,10 @@ class SparseCounts:
             for h in range(2):
                 cs.max_items_half[h] = (int(hp["iph"][h, p0:p1].max())
                                         if self.items.numel() and p1 > p0 else 0)
+        if getattr(self, "list_first", None) is not None:
+            cs.list_first = self.list_first.data_ptr() + 4 * p0 * self.n_cols
+            cs.item_pos = self.item_pos.data_ptr()
+            cs.n_items = int(hp["iptr"][p1] - hp["iptr"][p0])
         cs.gval = self.gval.data_ptr() if self.gval is not None else None
         cs.ent = self.ent.data_ptr() if getattr(self, "ent", None) is not None else None
         cs.pc_ent = self.pc_ent.data_ptr() if getattr(self, "pc_ent", None) is not None else None

@@ -591,7 +591,8 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
     #  a foreign all_reduce hook, which only knows how to sum the accumulators)
     device_loop = getattr(model, "_custom_codec", None) is None and (
         all_reduce is None or hasattr(all_reduce, "batch_totals"))
-    sync_every = int(kwargs.get("sync_every", 200))
+    # (a deterministic model's replicas apply bit-identical updates: the guard re-broadcast is not needed)
+    sync_every = 0 if getattr(model, "deterministic", False) else int(kwargs.get("sync_every", 200))
     since_sync = 0
     if device_loop:
         opt.init_state(clip_value)

@@ -15,7 +15,7 @@ for name, (res, args) in _lib.SIGNATURES.items():
     fn = getattr(lib, name)
     fn.restype, fn.argtypes = res, args
 
-assert lib.spmf_version() == 4 and lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct)
+assert lib.spmf_version() == 5 and lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct)
 h = C.c_void_p()
 assert lib.spmf_ctx_create(0, 100, 10, 0, C.byref(h)) == -1
 assert lib.spmf_ctx_create(0, 0, 10, 0, C.byref(h)) == -1
@@ -67,6 +67,24 @@ for flags in (0, 1, 2 | 1, 4, 4 | 2, 8, 16 | 1):
         assert lib.spmf_allreduce(h, 4096, 8, None) == -1 and b"comm_init" in lib.spmf_last_error(h)
         assert lib.spmf_comm_init(h, None, 0, 1) == -1
         assert lib.spmf_comm_destroy(h) == 0
+        # deterministic mode: scratch arithmetic, the contexts it is refused for
+        n0, n1 = lib.spmf_det_scratch_bytes(h, 0, 1), lib.spmf_det_scratch_bytes(h, 1000, 1)
+        assert n1 - n0 == (1000 * (2 * kp + 4) * 4 + 255) // 256 * 256 and lib.spmf_det_scratch_bytes(h, 1000, 3) == 3 * n1
+        if flags in (0, 1, 16 | 1):
+            assert lib.spmf_ctx_set_deterministic(h, 4096 + 8, n1) == -1      # misaligned
+            assert lib.spmf_ctx_set_deterministic(h, 4096, 100) == -3          # too small
+            assert lib.spmf_ctx_set_deterministic(h, 4096, n1) == 0
+            cs_d = _lib.CountsStruct()
+            cs_d.struct_size = C.sizeof(_lib.CountsStruct)
+            cs_d.n_cols = 1000
+            cs_d.n_rows, cs_d.nnz, cs_d.row_ptr, cs_d.col_idx, cs_d.val = 8, 8, 4096, 4096, 4096
+            cs_d.pc_row = cs_d.pc_val = cs_d.item_ptr = cs_d.items = cs_d.pc_ptr = 4096
+            cs_d.n_panels, cs_d.panel_rows = 1, 8
+            assert lib.spmf_data_pass(h, C.byref(cs_d), 1, _lib.PtrArray(*([4096] * 12)), 4096, None) == -1
+            assert b"list_first" in lib.spmf_last_error(h)                      # counts without the item order
+            assert lib.spmf_ctx_set_deterministic(h, None, 0) == 0             # off again
+        else:
+            assert lib.spmf_ctx_set_deterministic(h, 4096, n1) == -4 and b"linear decoder" in lib.spmf_last_error(h)
         assert lib.spmf_counts_colstats(h, None, None, None, None) == -1
         assert lib.spmf_counts_colstats(h, C.byref(cs), None, None, None) == -1          # n_cols != D
         assert lib.spmf_counts_gvals(h, C.byref(cs), None, None, None, None) == -1

@@ -57,7 +57,7 @@ def _build(ptr, col, val, rows, D, P, split, native):
 
 
 ARRAYS = ("pc_ptr", "pc_row", "pc_val", "pc_ent", "ent", "items", "item_ptr", "item_mid",
-          "items_per_panel", "items_per_half")
+          "items_per_panel", "items_per_half", "list_first", "item_pos")
 
 
 def _same(a, b, what):
@@ -75,7 +75,7 @@ def _same(a, b, what):
         if pr[0] >= a.n_panels:
             continue
         ca, cb = a.batch_struct(*pr), b.batch_struct(*pr)
-        for k in ("n_rows", "nnz", "n_panels", "max_items_per_panel", "pc_pad", "row_base"):
+        for k in ("n_rows", "nnz", "n_panels", "max_items_per_panel", "pc_pad", "row_base", "n_items"):
             assert getattr(ca, k) == getattr(cb, k), (what, pr, k)
         assert list(ca.max_items_half) == list(cb.max_items_half)
 

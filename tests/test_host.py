@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.spmf_version() == 4 and 'define SPMF_ABI_VERSION 4' in hdr
+    assert lib.spmf_version() == 5 and 'define SPMF_ABI_VERSION 5' in hdr
 
 
 def test_library_exports_only_the_c_abi(lib):
@@ -48,7 +48,7 @@ def test_struct_sizes_agree_between_library_ctypes_and_integration_stub(lib):
     """spmf_sizeof_*: the library's own struct sizes == the ctypes mirrors in
     spmf_amd/_lib.py == the stub INTEGRATION.md tells a maintainer to copy."""
     from spmf_amd import _lib
-    assert lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct) == 176
+    assert lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct) == 200
     assert lib.spmf_sizeof_sur_var() == C.sizeof(_lib.SurVar)
     assert lib.spmf_sizeof_adam_var() == C.sizeof(_lib.AdamVar)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
@@ -131,9 +131,12 @@ def test_counts_struct_abi_guard_rejects_foreign_layouts(lib):
 def test_counts_struct_layout_matches_header():
     from spmf_amd._lib import CountsStruct
     # 2*int64 + 4*int32 + 7 pointers + double + 2 pointers + (2 pointers, 2 int32)
-    # + column split: pointer + 4 int32 + the packed entry stream's pointer
-    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8 + 16 + 16 + 8 + 8 + 16 + 16
+    # + column split: pointer + 4 int32 + the packed entry streams' pointers
+    # + the deterministic mode's item order: 2 pointers + int64
+    assert C.sizeof(CountsStruct) == 16 + 16 + 7 * 8 + 8 + 16 + 16 + 8 + 8 + 16 + 16 + 24
     assert CountsStruct.ent.offset == 160 and CountsStruct.pc_ent.offset == 168
+    assert CountsStruct.list_first.offset == 176 and CountsStruct.item_pos.offset == 184
+    assert CountsStruct.n_items.offset == 192
     assert CountsStruct.item_mid.offset == 136 and CountsStruct.col_split.offset == 144
     assert CountsStruct.max_items_half.offset == 148
     assert CountsStruct.gval.offset == 96

@@ -13,7 +13,7 @@ sys.path.insert(0, ".")
 from spmf_amd.sparse import SparseCounts  # noqa: E402
 
 ARRAYS = ("row_ptr", "col_idx", "val", "pc_ptr", "pc_row", "pc_val", "pc_ent", "ent", "items", "item_ptr",
-          "item_mid", "items_per_panel", "items_per_half")
+          "item_mid", "items_per_panel", "items_per_half", "list_first", "item_pos")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 4242
 rng = np.random.default_rng(seed)
