@@ -607,6 +607,7 @@ def main():
             same = all(torch.equal(pa[k], pb[k]) for k in pa) and all(torch.equal(ga[k], gb[k]) for k in ga)
             pd_, gd_, _ = model.energy_and_grads(batch, params)
             dmax = max(float((ga[k] - gd_[k]).abs().max()) / max(float(gd_[k].abs().max()), 1e-30) for k in ga)
+            extras["det_vs_default_differing_entries"] = int(sum(int((ga[k] != gd_[k]).sum()) for k in ga))
             det_ms, t6d, _, _ = _timed_steps(mdet, batch, params, max(3, min(args.steps, 10)), 2)
             extras["det_ms_per_step"] = det_ms
             extras["det_kernel_ms"] = {"prep": round(t6d[0], 4), "row_pass": round(t6d[1], 4),
