@@ -249,6 +249,11 @@ class PoissonFactorization:
         need = int(lib.spmf_det_scratch_bytes(h, int(n_items), int(S)))
         if self._det_buf is None or self._det_buf.numel() < need + 256 or self._det_ctx != h:
             if self._det_buf is None or self._det_buf.numel() < need + 256:
+                # a step captured into a hipGraph (vi.StepRunner) keeps the pointer it was captured with:
+                # an outgrown buffer stays alive beside the new one (growth by halves bounds how many)
+                if self._det_buf is not None:
+                    self.__dict__.setdefault("_det_old", []).append(self._det_buf)
+                    need = max(need, 3 * self._det_buf.numel() // 2)
                 self._det_buf = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
             self._det_ctx = h
             base = self._det_buf.data_ptr()

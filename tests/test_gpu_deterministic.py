@@ -100,3 +100,34 @@ def test_deterministic_fit_repeats_exactly_and_unsupported_contexts_say_so():
     torch.manual_seed(1)
     with pytest.raises(_lib.SpmfError, match="linear decoder only"):
         b.energy_and_grads({"counts": (X > 0).astype(np.float64)}, b.surrogate_distribution.sample(1))
+
+
+def test_deterministic_minibatch_training_under_graph_replay_repeats_exactly():
+    """The device-gated VI loop over panel-range minibatches of growing size (the scratch is re-sized between
+    captured steps), replayed from hipGraphs: two runs with the same seeds end in the same trainables, bit for bit."""
+    from spmf_amd import vi
+    from spmf_amd.sparse import SparseCounts
+    rows, D, K = 4000, 300, 8
+    X = _counts(rows, D, 0.04, seed=17)
+    dev = torch.device("cuda", 0)
+    finals = []
+    for rep in range(2):
+        sc = SparseCounts.from_any(X, dev, 250)
+        m = _model(K, D, rows, True, panel_rows=250)
+        torch.manual_seed(21)
+        m.create_distributions()
+        colsum = torch.zeros(D, dtype=torch.float64, device=dev)
+        colnnz = torch.zeros_like(colsum)
+        sc.compute_stats(m._handle(), colsum, colnnz)
+        batches = [{"counts": sc, "panels": (0, 2)}, {"counts": sc, "panels": (2, 7)}, {"counts": sc, "panels": (7, 16)}]
+        opt = vi.AdamHIP(m, m.surrogate_distribution.trainable_variables, 1e-2)
+        opt.init_state(5.0)
+        run = vi.StepRunner(m, opt, rows, 2, use_graph=True, seed=99)
+        for ep in range(4):
+            for b in batches:
+                run.step(b)
+        torch.cuda.synchronize()
+        assert run.replays > 0
+        finals.append([p.detach().clone() for p in m.surrogate_distribution.trainable_variables])
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)
