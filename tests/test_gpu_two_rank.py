@@ -243,3 +243,53 @@ def test_two_rank_custom_callables_equal_single_process():
     for k, v in grads.items():
         a, b = res["grads"][k], v.cpu().numpy()
         assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), (k, np.abs(a - b).max(), np.abs(b).max())
+
+
+def _det_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from spmf_amd import PoissonFactorization, SparseCounts
+    from spmf_amd.dist import ShardReducer, shard_bounds, sync_seed
+    X = _data()
+    N, D = X.shape
+    r0, r1 = shard_bounds(N, world, rank, granule=64)
+    torch.manual_seed(5)
+    m = PoissonFactorization(latent_dim=3, feature_dim=D, u_tau_scale=1 / math.sqrt(N * D), device="cuda",
+                             panel_rows=64, deterministic=True)
+    sc = SparseCounts.from_any(X[r0:r1], "cuda", 64)
+    red = ShardReducer()
+    m.compute_scales(lambda: [{"counts": sc}], all_reduce=red)
+    sync_seed(79)
+    calls = []
+    orig = red.sync_replicas
+    red.sync_replicas = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    losses = m.fit(lambda: [{"counts": sc}], dataset_size=red.dataset_rows, sample_size=2, num_steps=14,
+                   learning_rate=0.02, rel_tol=1e-12, verbose=False, all_reduce=red, sync_every=2)
+    n_sync = len(calls)                         # (the diagnostic below broadcasts through sync_replicas itself)
+    drift = red.replicas_max_abs_diff(m.surrogate_distribution.trainable_variables)
+    if rank == 0:
+        q.put({"losses": losses, "drift": drift, "syncs": n_sync})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_deterministic_replicas_stay_identical_without_the_guard_broadcast():
+    """deterministic=True: every rank applies bit-identical updates from the same all-reduced buffer, so
+    `fit` drops ShardReducer.sync_replicas (asked for every 2 steps here, never called) and the replicas
+    still agree exactly after 14 steps."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_det_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=500)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res["syncs"] == 0 and res["drift"] == 0.0 and len(res["losses"]) == 14
+    assert all(math.isfinite(v) for v in res["losses"])
