@@ -383,15 +383,46 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(int D, int n_panels, co
   const int it0 = item_ptr[0];
   float4 gV = make_float4(0.f, 0.f, 0.f, 0.f), gA = gV;
   float gph = 0.f;
-  for (int p = 0; p < n_panels; ++p) {
-    const int32_t* lf = list_first + (size_t)p * D + d;
-    const int r0 = lf[0], r1 = lf[1];
-    for (int r = r0; r < r1; ++r) {
-      const float4* src = reinterpret_cast<const float4*>(part + (size_t)(item_pos[r] - it0) * det_part_len(KP));
-      const float4 a = src[sub], b = src[LPN + sub];
-      gV.x += a.x; gV.y += a.y; gV.z += a.z; gV.w += a.w;
-      gA.x += b.x; gA.y += b.y; gA.z += b.z; gA.w += b.w;
-      if (sub == 0) gph += src[2 * LPN].x;
+  auto add_item = [&](int r) {
+    const float4* src = reinterpret_cast<const float4*>(part + (size_t)(item_pos[r] - it0) * det_part_len(KP));
+    const float4 a = src[sub], b = src[LPN + sub];
+    gV.x += a.x; gV.y += a.y; gV.z += a.z; gV.w += a.w;
+    gA.x += b.x; gA.y += b.y; gA.z += b.z; gA.w += b.w;
+    if (sub == 0) gph += src[2 * LPN].x;
+  };
+  // panels in chunks of DP: the list bounds, then the first items' positions, then their slots are
+  // fetched for the whole chunk before anything is added (the ADDS stay in panel order; a panel's
+  // further segments -- lists longer than one item -- follow in its turn)
+  constexpr int DP = 8;
+  for (int p0 = 0; p0 < n_panels; p0 += DP) {
+    int r0[DP], r1[DP], jp[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+      const bool on = p0 + i < n_panels;
+      const int32_t* lf = list_first + (size_t)(on ? p0 + i : p0) * D + d;
+      r0[i] = on ? lf[0] : 0;
+      r1[i] = on ? lf[1] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < DP; ++i) jp[i] = r1[i] > r0[i] ? item_pos[r0[i]] - it0 : 0;
+    float4 a[DP], b[DP];
+    float g[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+      const float4* src = reinterpret_cast<const float4*>(part + (size_t)jp[i] * det_part_len(KP));
+      const bool on = r1[i] > r0[i];
+      a[i] = on ? src[sub] : make_float4(0.f, 0.f, 0.f, 0.f);
+      b[i] = on ? src[LPN + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
+      g[i] = (on && sub == 0) ? src[2 * LPN].x : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+      if (r1[i] > r0[i]) {            // (an empty list adds nothing: not even +0, which could turn -0 into +0)
+        gV.x += a[i].x; gV.y += a[i].y; gV.z += a[i].z; gV.w += a[i].w;
+        gA.x += b[i].x; gA.y += b[i].y; gA.z += b[i].z; gA.w += b[i].w;
+        if (sub == 0) gph += g[i];
+        for (int r = r0[i] + 1; r < r1[i]; ++r) add_item(r);
+      }
     }
   }
   reinterpret_cast<float4*>(gVp + (size_t)d * KP)[sub] = gV;
