@@ -207,7 +207,9 @@ int spmf_ctx_set_e_cap(spmf_ctx* ctx, size_t bytes);
  * through rounding order).  Costs the column pass its atomics' bandwidth twice (write + read of
  * n_items * (2*KP + 4) floats): C3 2.81 -> 2.87 ms per step.  `scratch`: caller-owned device buffer of
  * spmf_det_scratch_bytes(ctx, n_items, S) bytes for the largest batch (n_items = spmf_counts.n_items),
- * 256-byte aligned; NULL switches the mode off.  The counts must carry list_first / item_pos. */
+ * 256-byte aligned; NULL switches the mode off.  The counts must carry list_first / item_pos.
+ * (Covers the step as spmf_data_pass + spmf_finish run it; the replacement rule for non-finite cells,
+ * spmf_nonfinite_patch, adds its correction with atomics and is outside the guarantee.) */
 size_t spmf_det_scratch_bytes(const spmf_ctx* ctx, int64_t n_items, int S);
 int spmf_ctx_set_deterministic(spmf_ctx* ctx, void* scratch, size_t bytes);
 
