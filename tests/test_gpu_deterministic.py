@@ -131,3 +131,22 @@ def test_deterministic_minibatch_training_under_graph_replay_repeats_exactly():
         finals.append([p.detach().clone() for p in m.surrogate_distribution.trainable_variables])
     for a, b in zip(*finals):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,D,K,S,density,scale_rows,panel_rows", [
+    (37, 23, 3, 2, 0.3, True, 16), (300, 257, 32, 2, 0.04, False, 128), (150, 90, 50, 1, 0.1, True, 32),
+    (50, 300, 4, 1, 0.8, True, 16), (1800, 640, 32, 1, 0.03, True, 256),
+])
+def test_deterministic_mode_against_the_oracle(B, D, K, S, density, scale_rows, panel_rows):
+    """The same entry-wise bar as the default path (tests/test_gpu_parity.py): 14 parts to 1e-5, every gradient
+    entry to 1e-5 of the sum of the absolute contributions to it, against the fp64 oracle."""
+    from oracle import spmf_oracle as O
+    from test_gpu_parity import assert_close_grads, assert_close_parts, build_model, make_problem
+    cfg, x, params = make_problem(B, D, K, S, 4000 + B + D + K, density, scale_rows)
+    parts_ref, grads_ref, _ = O.energy_and_grads(cfg, x, params)
+    m = build_model(cfg, panel_rows)
+    m.deterministic = True
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    assert float(nnf.sum()) == 0
+    assert_close_parts(parts, parts_ref)
+    assert_close_grads(grads, grads_ref, O.energy_grad_scales(cfg, x, params), tag="deterministic")
