@@ -9,6 +9,7 @@ from spmf_amd import PoissonFactorization, synth  # noqa: E402
 from spmf_amd.sparse import balanced_panel_rows  # noqa: E402
 
 rows, D, K = int(sys.argv[1]) if len(sys.argv) > 1 else 250_000, 20_000, 32
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda", 0)
 sc = synth.linear_structure(rows, D, 0.005, dev, panel_rows=balanced_panel_rows(rows, K))
 models = {}
@@ -23,7 +24,7 @@ for det in (False, True):
     m.xi_u_global = float(torch.nansum(cm))
     models[det] = m
 torch.manual_seed(7)
-params = models[False].surrogate_distribution.sample(1)
+params = models[False].surrogate_distribution.sample(S)
 runs = {}
 for det in (False, True, False, True):
     for rep in range(3):
@@ -33,7 +34,7 @@ for det in (False, True):
     r = runs[det]
     eq = [all(torch.equal(r[0][1][k], x[1][k]) for k in r[0][1]) and all(torch.equal(r[0][0][k], x[0][k]) for k in r[0][0])
           for x in r[1:]]
-    print(f"deterministic={det}: {len(r)} runs, identical to the first: {eq}")
+    print(f"deterministic={det}, S={S}: {len(r)} runs, identical to the first: {eq}")
 a, b = runs[True][0][1], runs[False][0][1]
 for k in ("u", "v", "w", "s"):
     d = (a[k] - b[k]).abs()
