@@ -269,7 +269,8 @@ int spmf_counts_gvals(spmf_ctx* ctx, const spmf_counts* counts, const float* eta
  * 0 <= col_idx < n_cols, no (row, column) pair stored twice (columns need not be sorted inside
  * a row).  The first four are verified on the device (SPMF_E_ARG, nothing usable in *out).
  * panel_rows >= 1 (spmf_amd/sparse.py balanced_panel_rows chooses it from K); col_split = 0 or
- * the column split of spmf_ctx_set_column_split.  nnz < 2^31.
+ * the column split of spmf_ctx_set_column_split.  nnz < 2^31, n_rows < 2^31 and n_panels * n_cols < 2^32
+ * (SPMF_E_UNSUPPORTED otherwise: choose larger panels).
  *
  * Layout produced (what spmf_amd/sparse.py built with torch sorts until version 3 of
  * this header; the two are compared array by array in tests/test_gpu_layout.py):

@@ -71,7 +71,6 @@ struct DeviceScope {
 struct Geo {
   int64_t B, nnz, nkeys, max_items;
   int D, P, nP, seg, key_bits, item_bits;
-  bool wide;                       // 64-bit sort keys (n_panels * D does not fit 32 bits)
 };
 
 // info block on the device
@@ -94,7 +93,9 @@ int make_geo(int64_t B, int64_t nnz, int D, int P, Geo* g) {
   g->P = (int)(P < (B > 1 ? B : 1) ? P : (B > 1 ? B : 1));
   g->nP = (int)(B > 0 ? (B + g->P - 1) / g->P : 1);
   g->nkeys = (int64_t)g->nP * D;
-  if (g->nkeys + g->nP >= (int64_t(1) << 40)) return lfail(SPMF_E_UNSUPPORTED, "layout: n_panels * n_cols too large");
+  // the sort key panel * D + column is 32 bits wide (and pc_ptr would be 16 GB beyond that): larger panels
+  if (g->nkeys >= (int64_t(1) << 32)) return lfail(SPMF_E_UNSUPPORTED,
+      "layout: n_panels * n_cols must stay below 2^32 (choose larger panels)");
   // segment length: a panel should offer a few thousand items (spmf_amd/sparse.py _build_items)
   const double per_panel = (double)nnz / (double)(g->nP > 0 ? g->nP : 1);
   int seg = 16;
@@ -102,7 +103,6 @@ int make_geo(int64_t B, int64_t nnz, int D, int P, Geo* g) {
   g->seg = seg;
   const int64_t lists = nnz < g->nkeys ? nnz : g->nkeys;
   g->max_items = lists + nnz / seg + 1;
-  g->wide = (uint64_t)g->nkeys >= (uint64_t(1) << 32);
   g->key_bits = bits_for((uint64_t)(g->nkeys > 1 ? g->nkeys : 2));
   const uint64_t item_keys = (uint64_t)g->nP * 2 * (seg + 1);
   if (item_keys >= (uint64_t(1) << 32)) return lfail(SPMF_E_UNSUPPORTED, "layout: too many panels");
@@ -149,7 +149,7 @@ int carve_scratch(const Geo& g, hipStream_t st, ScratchCarve* out) {
   ScratchCarve c{};
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += up256(bytes); return at; };
-  const size_t ks = g.wide ? 8 : 4;
+  const size_t ks = 4;
   c.key_in = take(((size_t)g.nnz + 1) * ks);
   c.key_out = take(((size_t)g.nnz + 1) * ks);
   c.word_in = take(((size_t)g.nnz + 1) * 4);
@@ -162,8 +162,7 @@ int carve_scratch(const Geo& g, hipStream_t st, ScratchCarve* out) {
   c.ival_out = take((size_t)g.max_items * 4);
   c.info = take(I_LEN * 4);
   size_t t1 = 0, t2 = 0, t3 = 0;
-  hipError_t e = g.wide ? sort_temp_bytes<uint64_t>((size_t)g.nnz, g.key_bits, st, &t1)
-                        : sort_temp_bytes<uint32_t>((size_t)g.nnz, g.key_bits, st, &t1);
+  hipError_t e = sort_temp_bytes<uint32_t>((size_t)g.nnz, g.key_bits, st, &t1);
   if (e == hipSuccess) e = sort_temp_bytes<uint32_t>((size_t)g.max_items, g.item_bits, st, &t2);
   if (e == hipSuccess)
     e = rocprim::exclusive_scan(nullptr, t3, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)g.nkeys + 1,
@@ -668,10 +667,8 @@ int spmf_layout_build(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, c
     return lfail(SPMF_E_WORKSPACE, "layout_build: buffers smaller than spmf_layout_sizes reports");
   bool packed_words = false;
   int hi[I_LEN] = {0};
-  rc = g.wide ? run_build<uint64_t>(g, row_ptr, col_idx, val, col_split, (char*)layout, L, (char*)scratch, S,
-                                    &packed_words, hi, st)
-              : run_build<uint32_t>(g, row_ptr, col_idx, val, col_split, (char*)layout, L, (char*)scratch, S,
-                                    &packed_words, hi, st);
+  rc = run_build<uint32_t>(g, row_ptr, col_idx, val, col_split, (char*)layout, L, (char*)scratch, S,
+                           &packed_words, hi, st);
   if (rc) return rc;
   if (hi[I_FLAGS] & F_ROWPTR)
     return lfail(SPMF_E_ARG, "layout_build: row_ptr is not a CSR offset array of this shard (row_ptr[0] == 0, "

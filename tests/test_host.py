@@ -72,6 +72,8 @@ def test_layout_builder_argument_errors_without_gpu(lib):
     assert lib.spmf_layout_sizes(0, 10, -1, 7, 4, C.byref(lb), C.byref(sb)) == -1      # nnz < 0
     assert lib.spmf_layout_sizes(0, 10, 2 ** 31, 7, 4, C.byref(lb), C.byref(sb)) == -4  # nnz must fit int32
     assert lib.spmf_layout_sizes(0, 10, 5, 7, 0, C.byref(lb), C.byref(sb)) == -1       # panel_rows < 1
+    assert lib.spmf_layout_sizes(0, 2 ** 20, 5, 8192, 1, C.byref(lb), C.byref(sb)) == -4  # n_panels * n_cols >= 2^32
+    assert b"larger panels" in lib.spmf_layout_last_error()
     assert lib.spmf_layout_sizes(0, 10, 5, 7, 4, None, C.byref(sb)) == -1
     cs, info = _lib.CountsStruct(), _lib.LayoutInfo()
     info.struct_size = C.sizeof(_lib.LayoutInfo)
