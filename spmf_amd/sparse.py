@@ -136,6 +136,15 @@ class SparseCounts:
             return x
         device = torch.device(device if device is not None else
                               ("cuda" if torch.cuda.is_available() else "cpu"))
+        if isinstance(x, torch.Tensor) and x.layout in (torch.sparse_csr, torch.sparse_coo):
+            # a torch sparse tensor (CSR, or COO coalesced to CSR): its index / value tensors are taken where
+            # they are -- on the device: no host round trip
+            xc = x.coalesce().to_sparse_csr() if x.layout == torch.sparse_coo else x
+            if xc.dim() != 2:
+                raise ValueError("counts must be [rows, features]")
+            return cls(xc.crow_indices().to(device), xc.col_indices().to(device),
+                       xc.values().to(device=device, dtype=torch.float32), xc.shape[0], xc.shape[1],
+                       panel_rows, col_split, latent_dim)
         csr = _as_csr_arrays(x)
         if csr is not None:
             indptr, indices, data, shape = csr

@@ -318,3 +318,24 @@ def test_dense_batches_to_csr_native_equals_torch_and_numpy(shape):
         rr, cc = np.nonzero((xb != 0) | np.isnan(xb))
         assert n == len(rr) and np.array_equal(ci.cpu().numpy(), cc)
         assert np.array_equal(va.cpu().numpy(), xb[rr, cc], equal_nan=True)
+
+
+def test_torch_sparse_tensors_are_taken_where_they_are():
+    """torch.sparse_csr / sparse_coo inputs (device resident) give the layout of the same matrix from scipy."""
+    import scipy.sparse as sp
+    from spmf_amd.sparse import SparseCounts
+    rng = np.random.default_rng(3)
+    X = sp.random(700, 300, density=0.03, format="csr", random_state=rng, data_rvs=lambda n: rng.poisson(2.0, n) + 1.0)
+    X.sort_indices()
+    dev = torch.device("cuda", 0)
+    ref = SparseCounts.from_any(X, dev, 128)
+    t_csr = torch.sparse_csr_tensor(torch.as_tensor(X.indptr, dtype=torch.int64), torch.as_tensor(X.indices, dtype=torch.int64),
+                                    torch.as_tensor(X.data, dtype=torch.float32), size=X.shape).to(dev)
+    coo = X.tocoo()
+    t_coo = torch.sparse_coo_tensor(torch.as_tensor(np.stack([coo.row, coo.col])), torch.as_tensor(coo.data, dtype=torch.float32),
+                                    size=X.shape).to(dev)
+    for t in (t_csr, t_coo):
+        sc = SparseCounts.from_any(t, dev, 128)
+        for k in ("row_ptr", "col_idx", "val") + ARRAYS:
+            a, b = getattr(sc, k), getattr(ref, k)
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), k
