@@ -63,17 +63,41 @@ namespace spmf {
 template <int KP>
 __device__ __forceinline__ void pack_block(const double* __restrict__ dacc, float* __restrict__ tail,
                                            const double* __restrict__ det_slots) {
+  if (det_slots) {
+    // deterministic mode: the row pass's workgroups left their sums in their own slots (slots 3..5 -- dense
+    // sum, saturation, spare -- are not produced by this mode's linear decoder and stay 0).  A fixed
+    // association: 256 / 128 thread groups each add a contiguous eighth (quarter ... ) of the slots in
+    // workgroup order, then the partial sums are added in group order -- the same tree for the same
+    // workgroup count, 8 x shorter chains than one pass (4096 slots on the 256-thread launch shape)
+    constexpr int LEN = kDaccHead + KP;                 // 10 ... 70 values
+    constexpr int SEG = 256 / (LEN <= 32 ? 32 : (LEN <= 64 ? 64 : 128));
+    constexpr int W = 256 / SEG;
+    __shared__ double seg_sum[SEG][W];
+    const int i = threadIdx.x % W, g = threadIdx.x / W;
+    const int nb = (int)det_slots[0];
+    const int per = (nb + SEG - 1) / SEG;
+    double v = 0.0;
+    if (i < LEN) {
+      const double* sl = det_slots + kDetMeta + i;
+      const int b1 = min(nb, (g + 1) * per);
+      for (int b = g * per; b < b1; ++b) v += sl[(size_t)b * LEN];
+    }
+    seg_sum[g][i] = v;
+    __syncthreads();
+    if (threadIdx.x < LEN) {
+      double t = 0.0;
+#pragma unroll
+      for (int s = 0; s < SEG; ++s) t += seg_sum[s][threadIdx.x];
+      const float hi = (float)t;
+      tail[2 * threadIdx.x] = hi;
+      tail[2 * threadIdx.x + 1] = (float)(t - (double)hi);
+    }
+    return;
+  }
   const int i = threadIdx.x;
   if (i < kDaccHead + KP) {
     double v = 0.0;
-    if (det_slots) {
-      // deterministic mode: the row pass's workgroups left their sums in their own slots; add them in
-      // workgroup order (slots 3..5 -- dense sum, saturation, spare -- are not produced by this mode's
-      // linear decoder and stay 0)
-      const int nb = (int)det_slots[0];
-      const double* sl = det_slots + kDetMeta + i;
-      for (int b = 0; b < nb; ++b) v += sl[(size_t)b * (kDaccHead + KP)];
-    } else {
+    {
 #pragma unroll
       for (int r = 0; r < kDaccRep; ++r) v += dacc[(size_t)r * (kDaccHead + KP) + i];
     }
