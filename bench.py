@@ -531,6 +531,8 @@ def main():
         ss.compute_stats(h)
         npan_s = ss.n_panels
         sb = {"counts": ss}
+        # (first without the hipEvent taps: five event records per step are ~20 us of a 0.4 ms step)
+        extras["shard125k_ms_per_step_no_taps"] = timed(lambda: model.energy_and_grads(sb, params), 50, 5)
         lib.spmf_ctx_enable_timing(h, 1)
         sh_ms = timed(lambda: model.energy_and_grads(sb, params), 50, 5)
         ms_s = (C.c_float * 6)()
@@ -609,6 +611,8 @@ def main():
             dmax = max(float((ga[k] - gd_[k]).abs().max()) / max(float(gd_[k].abs().max()), 1e-30) for k in ga)
             extras["det_vs_default_differing_entries"] = int(sum(int((ga[k] != gd_[k]).sum()) for k in ga))
             det_ms, t6d, _, _ = _timed_steps(mdet, batch, params, max(3, min(args.steps, 10)), 2)
+            if "sb" in locals():       # the 8-GPU shard in the deterministic mode too
+                extras["shard125k_det_ms_per_step"] = timed(lambda: mdet.energy_and_grads(sb, params), 50, 5)
             extras["det_ms_per_step"] = det_ms
             extras["det_kernel_ms"] = {"prep": round(t6d[0], 4), "row_pass": round(t6d[1], 4),
                                        "col_pass_and_reduce": round(t6d[2], 4), "finish": round(t6d[3], 4)}
