@@ -302,6 +302,83 @@ def c2_extra(dev, steps=50, warmup=5):
     return out
 
 
+def c1_gpu_extra(dev, steps=200, warmup=10):
+    """BASELINE config 1 on the GPU, on the SAME seeded data as c1_dense_cpu_baseline (5000 x 200 dense
+    Poisson(1) counts, K = 2, one batch of 5000): ms per energy + gradient step, and per whole VI step
+    (what bin/factorize_csv.py runs per epoch at its defaults) replayed from its hipGraph."""
+    import contextlib
+    import numpy as np
+    import torch
+    from spmf_amd import PoissonFactorization, vi
+    rng = np.random.default_rng(20241218 + 1)
+    N, D, K = 5000, 200, 2
+    x = rng.poisson(1.0, size=(N, D)).astype(np.float64)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1.0 / (N * D) ** 0.5, device=dev)
+        model.compute_scales(lambda: [{"counts": x}])
+    batch = {"counts": x}
+    torch.manual_seed(20241218)
+    params = model.surrogate_distribution.sample(1)
+    ms, t6, parts, nnf = _timed_steps(model, batch, params, steps, warmup)
+    opt = vi.AdamHIP(model, model.surrogate_distribution.trainable_variables, 0.1)
+    opt.init_state(None)
+    run = vi.StepRunner(model, opt, N, 1, use_graph=True)
+    for _ in range(warmup):
+        run.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run.step(batch)
+    torch.cuda.synchronize()
+    vi_ms = 1e3 * (time.perf_counter() - t0) / steps
+    out = {"c1_gpu_ms_per_step": ms, "c1_gpu_steps_per_sec": 1e3 / ms, "c1_gpu_vi_step_ms": vi_ms,
+           "c1_gpu_vi_graph_replays": run.replays, "c1_nnz": int(model._batch(batch)[0].nnz),
+           "c1_gpu_elbo_x": float(parts["x"][0])}
+    del model, run, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def ref_harness_extra(dev, steps=100, warmup=10):
+    """The shape of the reference's own harness (tests/spmf_test.py:12-43): D = 350 features, P = 50
+    factors, dense Poisson(1) counts, batches of batch_size = 10 rows, sample_size = 20 draws per step.
+    ms per energy + gradient evaluation of one such batch with S = 20 (all draws in ONE launch sequence:
+    csrc/api.hip batched_draws), per whole VI step of it replayed from its hipGraph, and the same at a
+    1000-row batch for scale."""
+    import contextlib
+    import numpy as np
+    import torch
+    from spmf_amd import PoissonFactorization, vi
+    rng = np.random.default_rng(20241218 + 6)
+    N, D, P, S = 5000, 350, 50, 20
+    x = rng.poisson(1.0, size=(N, D)).astype(np.float64)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = PoissonFactorization(latent_dim=P, feature_dim=D, u_tau_scale=1.0 / (N * D) ** 0.5, device=dev)
+        model.compute_scales(lambda: [{"counts": x}])
+    out = {"ref_harness_shape": f"D={D} P={P} S={S} dense Poisson(1) (tests/spmf_test.py:12-43)"}
+    torch.manual_seed(20241218)
+    params = model.surrogate_distribution.sample(S)
+    for rows, tag in ((10, "b10"), (1000, "b1000")):
+        batch = {"counts": x[:rows]}
+        ms, _, parts, _ = _timed_steps(model, batch, params, steps, warmup)
+        out[f"ref_harness_{tag}_S20_ms"] = ms
+        opt = vi.AdamHIP(model, model.surrogate_distribution.trainable_variables, 0.01)
+        opt.init_state(None)
+        run = vi.StepRunner(model, opt, N, S, use_graph=True)
+        for _ in range(warmup):
+            run.step(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run.step(batch)
+        torch.cuda.synchronize()
+        out[f"ref_harness_{tag}_S20_vi_step_ms"] = 1e3 * (time.perf_counter() - t0) / steps
+        del run, opt
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries below this script print there too
     # (RCCL writes a version banner from C when a communicator is created), so file
@@ -670,6 +747,16 @@ def main():
             extras.update(c2_extra(dev))
         except Exception as e:
             extras["c2_error"] = str(e)[:200]
+        # the reference's own shapes: C1 on the GPU beside its CPU number, and the harness
+        # of tests/spmf_test.py (D = 350, P = 50, batches of 10 rows, sample_size = 20)
+        try:
+            extras.update(c1_gpu_extra(dev))
+        except Exception as e:
+            extras["c1_gpu_error"] = str(e)[:200]
+        try:
+            extras.update(ref_harness_extra(dev))
+        except Exception as e:
+            extras["ref_harness_error"] = str(e)[:200]
         # ... and a third (C4: seconds to generate on the device, 15 GB resident)
         if os.environ.get("SPMF_BENCH_C4_EXTRA", "1") != "0":
             try:
@@ -799,6 +886,11 @@ def main():
             "config": {"workload": desc + f", S={S}, full batch, row-sharded x{world}",
                        "rows": rows_g, "cols": D, "nnz": nnz_g, "latent_dim": K,
                        "samples": S, "parallelism": f"row-shard dp{world}", "allreduce_transport": transport,
+                       # what one timed step is: the energy step; the whole VI step is vi_step_ms
+                       "step": "energy + gradient: all 14 energy parts and d/d(12 latent variables) of one batch "
+                               "(spmf_step_begin .. [all-reduce] .. spmf_step_end); the surrogate's sampler / "
+                               "transform / chain rule / Adam around it are NOT in `value`: the whole VI step is "
+                               "vi_step_ms",
                        "panel_rows": args.panel_rows,
                        # physical entry streams (the algorithmic bytes above stay canonical: 8 B per entry and pass)
                        "entry_format": ("packed u32: col<<16|count (row pass), row-in-panel<<16|count (column pass)"

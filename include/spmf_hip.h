@@ -159,12 +159,15 @@ typedef struct spmf_counts {
   int64_t n_items;
 } spmf_counts;
 
-/* ABI version of this header: 5.  (2 -> 3: spmf_counts.struct_size replaces a reserved slot
+/* ABI version of this header: 6.  (2 -> 3: spmf_counts.struct_size replaces a reserved slot
  * and is verified; pc_pad / ent / pc_ent are validated.  3 -> 4: the device layout builder
  * spmf_layout_* added.  4 -> 5: spmf_counts grows by list_first / item_pos / n_items for the
  * deterministic mode -- a caller built against 4 is refused by the struct_size check, not
- * misread.)  A binding checks it at load time. */
-#define SPMF_ABI_VERSION 5
+ * misread.  5 -> 6: spmf_step_begin / spmf_step_end added -- the step with its outputs handed over
+ * up front -- and spmf_p2p_*, the step's collective as a hand-written kernel over peer pointers; no
+ * struct changed, every version-5 entry point keeps its meaning.)  A binding checks it
+ * at load time. */
+#define SPMF_ABI_VERSION 6
 int spmf_version(void);
 
 /* sizeof(spmf_counts) / sizeof(spmf_sur_var) / sizeof(spmf_adam_var) as this
@@ -382,6 +385,30 @@ int spmf_comm_init(spmf_ctx* ctx, const void* id128, int rank, int world);
 int spmf_allreduce(spmf_ctx* ctx, float* buf, int64_t n, void* stream);
 int spmf_comm_destroy(spmf_ctx* ctx);
 
+/* ---- the same collective as a hand-written kernel over peer pointers (ABI 6) -----
+ * SURVEY 5 (last row) / 8e ask for a direct reduce-scatter + all-gather over the xGMI mesh instead of a
+ * ring: csrc/p2p.hip.  Every rank pushes slice q of its buffer straight into rank q's inbox (N-1 links at
+ * once), rank q adds the N contributions IN RANK ORDER and pushes the reduced slice to every peer, every
+ * rank copies the N-1 reduced slices home: ONE kernel launch per rank on the caller's stream (capturable
+ * in a hipGraph: the call counter lives on the device), flags with system-scope release / acquire, and all
+ * ranks end with the SAME bits (each slice is reduced once, by its owner, in a fixed order).  The memory
+ * the peers write is a fine-grained region this library allocates and exports with hipIpcGetMemHandle; the
+ * peers may be other GPUs of the node (xGMI) or other processes on the same GPU (how the one-GPU tests run
+ * it at world 2 and 4) -- the kernel is the same.
+ *   spmf_p2p_init     allocates this rank's region for buffers of up to n_max floats and returns its 64-byte
+ *                     IPC handle; nchunk = workgroups of the kernel (0: default 32; <= 256)
+ *   [ the host exchanges the handles: the Python mirror uses a torch.distributed all_gather ]
+ *   spmf_p2p_connect  handles = world x 64 bytes in rank order; opens the peers' regions
+ *   spmf_allreduce    then runs this kernel instead of ncclAllReduce (n <= n_max, buf 16-byte aligned)
+ *   spmf_p2p_status   SYNCHRONISES; out3 = {calls completed, 0, first call in which a workgroup gave up
+ *                     waiting for a peer (0 = none)}: every spin is bounded, a lost peer cannot hang the GPU
+ *   spmf_p2p_destroy  unmaps and frees (also done by spmf_ctx_destroy)
+ * All ranks must call spmf_allreduce with the same n, the same number of times. */
+int spmf_p2p_init(spmf_ctx* ctx, int rank, int world, int64_t n_max, int nchunk, void* handle_out64);
+int spmf_p2p_connect(spmf_ctx* ctx, const void* handles);
+int spmf_p2p_status(spmf_ctx* ctx, uint64_t out3[3]);
+int spmf_p2p_destroy(spmf_ctx* ctx);
+
 /* Phase 2: chain the accumulators to d/d(u,v,w,s), add the prior's parts and
  * gradients -- the horseshoe-plus hierarchy over all 12 variables (poisson.py:228-377)
  * or, for a context created with SPMF_FLAG_ABS_HORSESHOE, the AbsHorseshoe priors on u
@@ -405,7 +432,31 @@ int spmf_finish(spmf_ctx* ctx, int S, int64_t n_rows_global,
                 double* parts, float* const grads[SPMF_NVARS],
                 double* n_nonfinite, void* stream);
 
-/* Phases 1+2 back to back (single shard). */
+/* ---- the step with its outputs known up front (ABI 6) ------------------------
+ * poisson.py:582-621 is ONE call; spmf_data_pass + spmf_finish split it in two so that the row-shard
+ * all-reduce fits between them, but handed the gradient outputs over only at the second call, which
+ * forced the prior's twelve log-densities and their gradients (poisson.py:590-591: parameters only, no
+ * accumulator) into the step's LAST launch, behind the collective.  This pair is the same step with
+ * parts / grads / n_nonfinite known from the first call on:
+ *   spmf_step_begin  = spmf_data_pass, and the prior half of the finish runs INSIDE the data pass's
+ *                      first launch, beside the A' / V' / phi tiles (O(D*K) work on the parameters, both);
+ *   [ the caller's all-reduce of spmf_acc_ptr / spmf_acc_len, row shards only ]
+ *   spmf_step_end    = the data half of spmf_finish (chain rule from the accumulators ADDED to what
+ *                      the prior half left in grads, parts 'z' and 'x', the fold of the prior half's
+ *                      per-workgroup sums) in ONE launch.
+ * Four launches per step instead of five, none of them on a side stream, and what is independent of
+ * the batch size shrinks to the prep launch + a 7 us data half (C3 sizes).  Arguments as
+ * spmf_data_pass / spmf_finish; params, eta, parts, grads, n_nonfinite must stay valid until
+ * spmf_step_end returns (the pointer ARRAYS are copied, the caller's may go).  Results are those of
+ * spmf_data_pass + spmf_finish.  When the S draws of a large batch run in turn (S > 1 beyond the
+ * batched-draw size) spmf_step_end falls back to the whole finish.  A spmf_data_pass, or anything that
+ * re-binds the workspace, between the two calls cancels the step (spmf_step_end: SPMF_E_ARG). */
+int spmf_step_begin(spmf_ctx* ctx, const spmf_counts* counts, int S, double prior_weight,
+                    const float* const params[SPMF_NVARS], const float* eta, double* parts,
+                    float* const grads[SPMF_NVARS], double* n_nonfinite, void* stream);
+int spmf_step_end(spmf_ctx* ctx, int64_t n_rows_global, double lgamma_sum_global, void* stream);
+
+/* spmf_step_begin + spmf_step_end back to back (single shard). */
 int spmf_elbo_fwd_bwd(spmf_ctx* ctx, const spmf_counts* counts, int S,
                       double prior_weight,
                       const float* const params[SPMF_NVARS], const float* eta,

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPMF_LIB_PATH") or os.path.join(_HERE, "libspmf_hip.so")
 
 NVARS = 12
-ABI_VERSION = 5          # include/spmf_hip.h SPMF_ABI_VERSION
+ABI_VERSION = 6          # include/spmf_hip.h SPMF_ABI_VERSION
 VI_STATE_LEN = 16
 NPARTS = 14
 #: variable order of the C-ABI = the reference's var_list (poisson.py:403-539,572)
@@ -122,6 +122,9 @@ SIGNATURES = {
     "spmf_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double,
                               C.c_double, PtrArray, C.c_void_p, C.c_void_p, PtrArray,
                               C.c_void_p, C.c_void_p]),
+    "spmf_step_begin": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int, C.c_double, PtrArray,
+                                  C.c_void_p, C.c_void_p, PtrArray, C.c_void_p, C.c_void_p]),
+    "spmf_step_end": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p]),
     "spmf_elbo_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int,
                                     C.c_double, PtrArray, C.c_void_p, C.c_void_p, PtrArray,
                                     C.c_void_p, C.c_void_p]),
@@ -133,6 +136,10 @@ SIGNATURES = {
     "spmf_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "spmf_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "spmf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "spmf_p2p_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
+    "spmf_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spmf_p2p_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "spmf_p2p_destroy": (C.c_int, [C.c_void_p]),
     "spmf_nonfinite_argmin": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
                                         C.c_void_p, C.c_void_p]),
     "spmf_nonfinite_lgamma": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_void_p,

@@ -75,7 +75,27 @@ struct spmf_ctx {
   double* scratch = nullptr;
   static constexpr size_t kScratchDoubles = 1u << 20;   // 8 MiB
   void* comm = nullptr;           // ncclComm_t of the row-shard collective (spmf_comm_init)
+  // spmf_step_begin .. spmf_step_end (ABI 6): the step's outputs are known from its first call on, so the
+  // prior half of the finish rides in the prep launch (fused = 1) and spmf_step_end launches the data half only
+  struct StepOut {
+    int active = 0, fused = 0, S = 0;
+    double prior_weight = 1.0;
+    const float* params[SPMF_NVARS] = {};
+    float* grads[SPMF_NVARS] = {};
+    const float* eta = nullptr;
+    double* parts = nullptr;
+    double* nnf = nullptr;
+  } step;
   int comm_rank = 0, comm_world = 1;
+  // the hand-written collective over peer pointers (spmf_p2p_*; p2p.hip): this rank's fine-grained region
+  // and the peers' regions as mapped into this process
+  struct P2P {
+    char* region = nullptr;          // own allocation: [rs | ag | flags | seq]
+    size_t bytes = 0, off_ag = 0, off_flags = 0, off_seq = 0;
+    int64_t n_max = 0, slice_cap = 0;
+    int rank = 0, world = 0, nchunk = 0, connected = 0;
+    char* peer[kP2PMaxWorld] = {};   // peer regions (own rank: own region); opened with hipIpcOpenMemHandle
+  } p2p;
   std::string err;
 };
 
@@ -153,14 +173,30 @@ struct Carve {
   size_t acc, dacc, dprep, ppart, putau, Ap, Vp, phi, dbias, Vb, bb, z, gzs, gzd, est, total;
 };
 // Small batches run all S draws in ONE launch per kernel (gridDim.y = S): the per-draw tables and
-// row outputs then exist S times.  Only for the linear Poisson decoder, only while the S table
-// pairs stay L2 sized (beyond that a draw is gather-bound, not launch-bound, and draws run in turn).
+// row outputs then exist S times.  Only for the linear Poisson decoder.  Two cases:
+//   * the S table pairs stay L2 sized (<= 3 MB): any batch up to 256 MB of row outputs -- beyond that size a
+//     draw is gather-bound, its tables want the L2 to themselves, and draws run in turn;
+//   * the batch is launch-bound whatever the tables weigh (<= kSmallBatchRows rows: the reference's own
+//     harness trains on batches of 10 rows with sample_size = 20, tests/spmf_test.py:35-43, where D = 350,
+//     K = 50 gives 3.58 MB of tables -- just over the cut above -- and 20 launch sequences per step): a
+//     draw's tables are only touched by that draw's few rows, residency is moot, and S x 4 launches
+//     become 4.  Bounded by 512 MB of tables.
+constexpr int64_t kSmallBatchRows = 2048;
 static bool batched_draws(const spmf_ctx* c, int64_t rows, int S) {
   if (S < 2 || c->Dh > 0) return false;
   if (c->flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED)) return false;
   const size_t tables = (size_t)S * 2 * c->D * c->KP * sizeof(float);
   const size_t rowbuf = (size_t)S * 2 * (size_t)rows * c->KP * sizeof(float);
+  if (rows <= kSmallBatchRows && tables <= ((size_t)512 << 20)) return true;
   return tables <= (3u << 20) && rowbuf <= (256u << 20);
+}
+
+static int fail(spmf_ctx* c, int code, const std::string& msg);
+// a bf16x3 dense launcher answered "shape not covered": the dense term of the step would be missing from
+// gzs / gV' / the softplus sum -- fail instead (the use_* predicates below are meant to make this unreachable)
+static int dense3_uncovered(spmf_ctx* c) {
+  return fail(c, SPMF_E_UNSUPPORTED, "data_pass: the bf16x3 dense kernels do not cover this launch shape "
+      "(set SPMF_DENSE_BF16X3=0 for the exact-f32 kernels)");
 }
 
 static int likelihood_code(const spmf_ctx* c) {   // common.h: lik_exp / lik_bern
@@ -261,6 +297,8 @@ size_t spmf_sizeof_counts(void) { return sizeof(spmf_counts); }
 size_t spmf_sizeof_sur_var(void) { return sizeof(spmf_sur_var); }
 size_t spmf_sizeof_adam_var(void) { return sizeof(spmf_adam_var); }
 
+static void p2p_release(spmf_ctx* c);
+
 int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   if (!out) return SPMF_E_ARG;
   *out = nullptr;
@@ -298,6 +336,7 @@ void spmf_ctx_destroy(spmf_ctx* c) {
     Rccl* r = rccl();
     if (r) (void)r->destroy(c->comm);
   }
+  p2p_release(c);
   delete c;
 }
 
@@ -346,6 +385,7 @@ static void unbind_ws(spmf_ctx* c) {
   c->fpart = nullptr;
   c->futau = nullptr;
   c->prior_pending = 0;
+  c->step.active = 0;
 }
 
 int spmf_ctx_set_e_cap(spmf_ctx* c, size_t bytes) {
@@ -357,7 +397,14 @@ int spmf_ctx_set_e_cap(spmf_ctx* c, size_t bytes) {
 
 size_t spmf_workspace_bytes(const spmf_ctx* c, int64_t max_rows, int S) {
   if (!c || max_rows < 0 || S < 1) return 0;
-  return carve(c, max_rows, S).total;
+  size_t need = carve(c, max_rows, S).total;
+  // (a batch of at most kSmallBatchRows rows keeps S table pairs: cover it too, so that every batch of up
+  //  to max_rows rows fits the workspace this sizes)
+  if (max_rows > kSmallBatchRows) {
+    const size_t small = carve(c, kSmallBatchRows, S).total;
+    if (small > need) need = small;
+  }
+  return need;
 }
 
 int spmf_ctx_set_workspace(spmf_ctx* c, void* workspace, size_t bytes) {
@@ -550,8 +597,9 @@ int spmf_ctx_set_deterministic(spmf_ctx* c, void* scratch, size_t bytes) {
 // parts: bit 0 = zero, prep, row pass and the column pass of the lower column half (all columns
 // without a split); bit 1 = column pass of the upper half and the fp64 pack
 static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float* const params[SPMF_NVARS],
-    const float* eta, int parts_mask, void* stream) {
+    const float* eta, int parts_mask, void* stream, spmf_ctx::StepOut* so = nullptr) {
   if (!c || !params || !eta || S < 1) return fail(c, SPMF_E_ARG, "data_pass: bad arguments");
+  if (!so) c->step.active = 0;   // a plain data pass ends a step begun earlier
   // likelihood / decoder code of the kernels: 0 Poisson linear, 1 Poisson log_transform, 2 Bernoulli
   const int logt = likelihood_code(c);
   int rc = check_counts(c, ct);
@@ -611,7 +659,19 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       pa.zero_p = c->acc;
       pa.zero_bytes = (size_t)((char*)c->dprep - (char*)c->acc);
     }
-    launch_prep(KP, pa, st);
+    if (so && nbat == S) {
+      // spmf_step_begin with every draw in this launch: the prior half of the finish (all twelve prior
+      // log-densities and prior_weight * d prior / d theta: parameters only) runs in the prep launch
+      const bool hsf = (c->flags & SPMF_FLAG_ABS_HORSESHOE) != 0;
+      FinishArgs fa{D, c->K, 0, 0.0, c->u_tau_scale, c->s_tau_scale, c->decay, so->prior_weight, nullptr, nullptr,
+          so->params, so->eta, so->grads, so->parts, nullptr, logt, c->ctype, c->Dh, S, 0, {}, hsf ? 1 : 0,
+          c->fpart, c->futau};
+      for (int i = 0; i < SPMF_NVARS; ++i) fa.vstride[i] = (int64_t)var_size(c, i);
+      launch_step_begin(KP, pa, fa, st);
+      so->fused = 1;
+    } else {
+      launch_prep(KP, pa, st);
+    }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], st));
     const float* rscale = (c->flags & SPMF_FLAG_SCALE_ROWS) ? ct->row_scale : nullptr;
     if (ct->n_rows > 0 && !logt) {
@@ -623,7 +683,8 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         ra.det_stride = (int64_t)(det_draw / sizeof(double));
       }
       launch_row_pass(KP, ra, st);
-    } else if (ct->n_rows > 0 && uses_sig3(c)) {
+    } else if (ct->n_rows > 0 && uses_sig3(c) && c->fuse_rows != 0) {
+      // (SPMF_FUSE_ROWS=0: the three-launch flow below, sweep 1 -> sigdot3 -> sweep 2)
       // Bernoulli / mixed columns with the linear decoder on the bf16x3 sigmoid kernels: ONE fused row
       // pass (both sweeps read the same counts; mode 3 leaves xi_b (gz_b - [veta] - z_b) in gzs), then
       // the (Z, W) launch subtracts the dense row term in its epilogue, gzs_b -= xi_b sum_d sigmoid(l_bd) V'_d,
@@ -657,9 +718,9 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       ez.e_planes = 3;              // V' rows have mixed signs under the Normal priors: third plane of E
       ez.accumulate = 1;
       ez.p_scale = rscale;
-      launch_sigdot3(KP, ez, st);   // gzs_b -= xi_b sum_d sigmoid(l_bd) V'_d ; dacc[3] = sum softplus
+      if (!launch_sigdot3(KP, ez, st)) return dense3_uncovered(c);   // gzs_b -= xi_b sum_d sigmoid(l_bd) V'_d ; dacc[3] = sum softplus
       ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 1, lbias, nullptr, gphi_acc, orows};
-      launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b sigmoid z_b ; gphi_d -= sum_b sigmoid
+      if (!launch_sigdot3(KP, ew, st)) return dense3_uncovered(c);   // gV'_d -= sum_b sigmoid z_b ; gphi_d -= sum_b sigmoid
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
     } else if (ct->n_rows > 0 && [&]() {
       // Poisson log_transform on the bf16x3 exp kernels with a packed entry stream: ONE fused row pass
@@ -678,11 +739,11 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       ExpdotArgs ez{(int)ct->n_rows, D, c->z, c->Vp, c->gzs, -1.f, dacc + 3, 1, 0, 0, nullptr, nullptr, nullptr, nullptr};
       ez.accumulate = 1;
       ez.p_scale = rscale;
-      launch_expdot3(KP, ez, st);   // gzs_b -= xi_b sum_d E_bd V'_d ; dacc[3] = sum E
+      if (!launch_expdot3(KP, ez, st)) return dense3_uncovered(c);   // gzs_b -= xi_b sum_d E_bd V'_d ; dacc[3] = sum E
       const int ch3 = pick_chunks((D + expdot3_rows_per_wg() - 1) / expdot3_rows_per_wg(),
                                   (int)((ct->n_rows + 127) / 128), 256 * expdot3_wgs_per_cu(), 64);
       ExpdotArgs ew{D, (int)ct->n_rows, c->Vp, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr, nullptr};
-      launch_expdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+      if (!launch_expdot3(KP, ew, st)) return dense3_uncovered(c);   // gV'_d -= sum_b E_bd z_b
       if (tm) HIPCHK(c, hipEventRecord(c->ev[7], st));
     } else if (ct->n_rows > 0) {
       // log_transform: z from g(x) (sweep 1), dense exp terms on the matrix
@@ -713,7 +774,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         // trip through HBM would be the bound)
         ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, 1, 0, 0, nullptr, nullptr, nullptr,
             nullptr};
-        launch_expdot3(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E
+        if (!launch_expdot3(KP, ez, st)) return dense3_uncovered(c);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E
         // Q chunks of the W-stationary launch: whole rounds of the resident workgroups (one 110 KB
         // workgroup per CU: 118 column blocks x 13 chunks = 6 rounds of 256 on C4; 5 chunks = 590
         // workgroups ran 2.3 rounds, the last one a third full)
@@ -721,7 +782,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
                                     (int)((ct->n_rows + 127) / 128), 256 * expdot3_wgs_per_cu(), 64);
         ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, ch3, 1, 0, nullptr, nullptr, nullptr,
             nullptr};
-        launch_expdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+        if (!launch_expdot3(KP, ew, st)) return dense3_uncovered(c);   // gV'_d -= sum_b E_bd z_b
       } else if (uses_exp3_32(c) && !compact) {
         // the same two launches at K padded to 32 (sigdot3 family, ACT 0); chunk counts that fill whole
         // rounds of the resident workgroups
@@ -732,9 +793,23 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         if (zc > 1) launch_zero(c->gzd, (size_t)ct->n_rows * KP * sizeof(float), st);
         ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, zc, zc > 1 ? 1 : 0, 0, nullptr, nullptr,
             nullptr, nullptr};
-        launch_sigdot3(KP, ez, st);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E ; dacc[4]: saturation
+        if (!launch_sigdot3(KP, ez, st)) return dense3_uncovered(c);   // gzd_b = sum_d E_bd V'_d ; dacc[3] = sum E ; dacc[4]: saturation
         ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 0, nullptr, nullptr, nullptr, nullptr};
-        launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b
+        if (!launch_sigdot3(KP, ew, st)) return dense3_uncovered(c);   // gV'_d -= sum_b E_bd z_b
+      } else if (uses_sig3(c)) {
+        // the sigmoid / softplus sums on the bf16x3 kernels without the fused row pass (SPMF_FUSE_ROWS=0):
+        // (Z, W) writes gzd_b = sum_d sigmoid(l_bd) V'_d for the stored-cell sweep, (W, Z) as in the fused flow
+        const int zt = (Dd + 127) / 128, wt = (int)((ct->n_rows + 127) / 128);
+        const int rpw = sigdot3_rows_per_wg(KP), slots = 256 * sigdot3_wgs_per_cu(KP);
+        const int zc = pick_chunks((int)((ct->n_rows + rpw - 1) / rpw), zt, slots, 16);
+        const int wc = pick_chunks((Dd + rpw - 1) / rpw, wt, slots, 256);
+        if (zc > 1) launch_zero(c->gzd, (size_t)ct->n_rows * KP * sizeof(float), st);
+        ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, zc, zc > 1 ? 1 : 0, 1, nullptr, lbias,
+            nullptr, nullptr};
+        ez.e_planes = 3;
+        if (!launch_sigdot3(KP, ez, st)) return dense3_uncovered(c);
+        ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 1, lbias, nullptr, gphi_acc, orows};
+        if (!launch_sigdot3(KP, ew, st)) return dense3_uncovered(c);
       } else if (uses_sigexp3(c) && !compact) {
         // Bernoulli + log_transform at K padded to 32: (Z, W) with the bias on the Q rows, the softplus sum and
         // three planes of E = sigmoid exp (V' has mixed signs), (W, Z) with the bias on the P rows and the
@@ -747,9 +822,9 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
         ExpdotArgs ez{(int)ct->n_rows, Dd, c->z, Wd, c->gzd, 1.f, dacc + 3, zc, zc > 1 ? 1 : 0, 2, nullptr, lbias,
             nullptr, nullptr};
         ez.e_planes = 3;
-        launch_sigdot3(KP, ez, st);   // gzd_b = sum_d sigmoid(l) exp(X) V'_d ; dacc[3] = sum softplus(l)
+        if (!launch_sigdot3(KP, ez, st)) return dense3_uncovered(c);   // gzd_b = sum_d sigmoid(l) exp(X) V'_d ; dacc[3] = sum softplus(l)
         ExpdotArgs ew{Dd, (int)ct->n_rows, Wd, c->z, gVp, -1.f, nullptr, wc, 1, 2, lbias, nullptr, gphi_acc, orows};
-        launch_sigdot3(KP, ew, st);   // gV'_d -= sum_b E_bd z_b ; gphi_d -= sum_b sigmoid(l)
+        if (!launch_sigdot3(KP, ew, st)) return dense3_uncovered(c);   // gV'_d -= sum_b E_bd z_b ; gphi_d -= sum_b sigmoid(l)
       } else if (c->est && act != 2) {   // (act 2: E carries exp(X) too, its row sums are not the d/dphi sums)
         // E once: per row chunk, the Z-stationary kernel keeps E (exp, or the sigmoid of the
         // Bernoulli logits) and the second contraction (gV'_d -= sum_b E_bd z_b; Bernoulli:
@@ -954,12 +1029,67 @@ int spmf_finish(spmf_ctx* c, int S, int64_t n_rows_global, double lgamma_sum_glo
   return SPMF_OK;
 }
 
+// ---- the step with its outputs known up front (ABI 6) -------------------------
+int spmf_step_begin(spmf_ctx* c, const spmf_counts* ct, int S, double prior_weight,
+    const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS],
+    double* n_nonfinite, void* stream) {
+  if (!c || !params || !grads || !eta || !parts || S < 1) return fail(c, SPMF_E_ARG, "step_begin: bad arguments");
+  const bool hsf = (c->flags & SPMF_FLAG_ABS_HORSESHOE) != 0;
+  for (int i = 0; i < SPMF_NVARS; ++i)
+    if ((!params[i] || !grads[i]) && !(hsf && i != 0 && i != 1 && i != 2 && i != 7))
+      return fail(c, SPMF_E_ARG, "step_begin: params/grads must be non-null (all 12; v,w,u,s with ABS_HORSESHOE)");
+  spmf_ctx::StepOut so;
+  so.S = S;
+  so.prior_weight = prior_weight;
+  for (int i = 0; i < SPMF_NVARS; ++i) {
+    so.params[i] = params[i];
+    so.grads[i] = grads[i];
+  }
+  so.eta = eta;
+  so.parts = parts;
+  so.nnf = n_nonfinite;
+  c->step.active = 0;
+  const int rc = data_pass_impl(c, ct, S, params, eta, 3, stream, &so);
+  if (rc) return rc;
+  so.active = 1;
+  c->step = so;
+  return SPMF_OK;
+}
+
+int spmf_step_end(spmf_ctx* c, int64_t n_rows_global, double lgamma_sum_global, void* stream) {
+  if (!c) return SPMF_E_ARG;
+  if (!c->step.active || !c->acc) return fail(c, SPMF_E_ARG, "step_end: no spmf_step_begin precedes it");
+  spmf_ctx::StepOut& so = c->step;
+  so.active = 0;
+  if (!so.fused)   // the draws ran in turn (S > 1 on a large batch): the whole finish, as spmf_finish runs it
+    return spmf_finish(c, so.S, n_rows_global, lgamma_sum_global, so.prior_weight, so.params, so.eta, so.parts,
+                       so.grads, so.nnf, stream);
+  hipStream_t st = (hipStream_t)stream;
+  const bool hsf = (c->flags & SPMF_FLAG_ABS_HORSESHOE) != 0;
+  const bool tm = c->timing;
+  FinishArgs fa{c->D, c->K, n_rows_global, lgamma_sum_global, c->u_tau_scale, c->s_tau_scale, c->decay,
+      so.prior_weight, c->acc, c->dprep, so.params, so.eta, so.grads, so.parts, so.nnf, likelihood_code(c),
+      c->ctype, c->Dh, so.S, (int64_t)acc_len(c->D, c->KP), {}, hsf ? 1 : 0, c->fpart, c->futau};
+  for (int i = 0; i < SPMF_NVARS; ++i) fa.vstride[i] = (int64_t)var_size(c, i);
+  if (tm) HIPCHK(c, hipEventRecord(c->ev[4], st));
+  launch_step_end(c->KP, fa, st);   // data half + the fold of the prior half's per-block sums
+  if (tm) {
+    HIPCHK(c, hipEventRecord(c->ev[5], st));
+    if (c->ev_valid == 1) {
+      c->ev_valid = 3;
+      c->ev_count++;
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
 int spmf_elbo_fwd_bwd(spmf_ctx* c, const spmf_counts* ct, int S, double prior_weight,
     const float* const params[SPMF_NVARS], const float* eta, double* parts, float* const grads[SPMF_NVARS],
     double* n_nonfinite, void* stream) {
-  int rc = spmf_data_pass(c, ct, S, params, eta, stream);
+  int rc = spmf_step_begin(c, ct, S, prior_weight, params, eta, parts, grads, n_nonfinite, stream);
   if (rc) return rc;
-  return spmf_finish(c, S, ct->n_rows, ct->lgamma_sum, prior_weight, params, eta, parts, grads, n_nonfinite, stream);
+  return spmf_step_end(c, ct->n_rows, ct->lgamma_sum, stream);
 }
 
 int spmf_encode(spmf_ctx* c, const spmf_counts* ct, const float* u, const float* s, const float* eta, float* z_out,
@@ -1024,6 +1154,131 @@ int spmf_nonfinite_reduce(spmf_ctx* c, int64_t n, const float* ll, int pass, dou
 }
 
 // ---- row-shard collective inside the library (spmf_allreduce) ---------
+// (1) hand-written, over peer pointers: p2p.hip.  Region layout of a rank:
+//     rs[2][kP2PMaxWorld][slice_cap] | ag[2][kP2PMaxWorld][slice_cap] | flags[2][2][kP2PMaxWorld][kP2PMaxChunks] | seq[8]
+static void p2p_release(spmf_ctx* c) {
+  spmf_ctx::P2P& p = c->p2p;
+  for (int i = 0; i < p.world; ++i)
+    if (p.peer[i] && p.peer[i] != p.region) (void)hipIpcCloseMemHandle(p.peer[i]);
+  if (p.region) (void)hipFree(p.region);
+  p = spmf_ctx::P2P();
+}
+
+static int p2p_allreduce(spmf_ctx* c, float* buf, int64_t n, hipStream_t st) {
+  spmf_ctx::P2P& p = c->p2p;
+  if (n > p.n_max) {
+    char b[160];
+    snprintf(b, sizeof b, "allreduce: %lld floats, the peer regions were sized for %lld (spmf_p2p_init n_max)",
+        (long long)n, (long long)p.n_max);
+    return fail(c, SPMF_E_WORKSPACE, b);
+  }
+  if (((uintptr_t)buf & 15) != 0) return fail(c, SPMF_E_ARG, "allreduce: buffer must be 16-byte aligned");
+  if (n == 0 || p.world == 1) return SPMF_OK;
+  P2PLaunch L{};
+  L.buf = buf;
+  L.n = n;
+  L.rank = p.rank;
+  L.world = p.world;
+  L.nchunk = p.nchunk;
+  L.slice_cap = p.slice_cap;
+  L.rs = (float*)p.region;
+  L.ag = (float*)(p.region + p.off_ag);
+  L.flags = (uint64_t*)(p.region + p.off_flags);
+  L.seq = (uint64_t*)(p.region + p.off_seq);
+  for (int i = 0; i < p.world; ++i) {
+    L.peer_rs[i] = (float*)p.peer[i];
+    L.peer_ag[i] = (float*)(p.peer[i] + p.off_ag);
+    L.peer_flags[i] = (uint64_t*)(p.peer[i] + p.off_flags);
+  }
+  launch_p2p_allreduce(L, st);
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
+int spmf_p2p_init(spmf_ctx* c, int rank, int world, int64_t n_max, int nchunk, void* handle_out64) {
+  if (!c || !handle_out64 || world < 1 || world > kP2PMaxWorld || rank < 0 || rank >= world || n_max < 1)
+    return fail(c, SPMF_E_ARG, "p2p_init: bad arguments (world <= 16)");
+  if (nchunk <= 0) nchunk = 32;
+  if (nchunk > kP2PMaxChunks) nchunk = kP2PMaxChunks;
+  HIPCHK(c, hipSetDevice(c->device));
+  p2p_release(c);
+  spmf_ctx::P2P& p = c->p2p;
+  p.rank = rank;
+  p.world = world;
+  p.nchunk = nchunk;
+  p.n_max = n_max;
+  const int64_t per = ((n_max + world - 1) / world + 3) & ~(int64_t)3;
+  p.slice_cap = (per + 63) & ~(int64_t)63;                       // 256-byte slots
+  const size_t box = (size_t)2 * kP2PMaxWorld * p.slice_cap * sizeof(float);
+  p.off_ag = box;
+  p.off_flags = 2 * box;
+  p.off_seq = p.off_flags + (size_t)2 * 2 * kP2PMaxWorld * kP2PMaxChunks * sizeof(uint64_t);
+  p.bytes = p.off_seq + 64;
+  // fine-grained: coherent across agents INSIDE a kernel (a coarse-grained allocation is only
+  // coherent at kernel boundaries); what RCCL allocates for its own buffers
+  void* reg = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&reg, p.bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(c, SPMF_E_HIP, std::string("p2p_init: hipExtMallocWithFlags(fine-grained): ") + hipGetErrorString(e));
+  }
+  p.region = (char*)reg;
+  HIPCHK(c, hipMemset(p.region + p.off_flags, 0, p.bytes - p.off_flags));
+  HIPCHK(c, hipDeviceSynchronize());
+  hipIpcMemHandle_t hnd;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "spmf_p2p_init hands out 64-byte handles");
+  e = hipIpcGetMemHandle(&hnd, p.region);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    p2p_release(c);
+    return fail(c, SPMF_E_HIP, std::string("p2p_init: hipIpcGetMemHandle: ") + hipGetErrorString(e));
+  }
+  memcpy(handle_out64, &hnd, 64);
+  return SPMF_OK;
+}
+
+int spmf_p2p_connect(spmf_ctx* c, const void* handles) {
+  if (!c || !handles) return fail(c, SPMF_E_ARG, "p2p_connect: bad arguments");
+  spmf_ctx::P2P& p = c->p2p;
+  if (!p.region) return fail(c, SPMF_E_ARG, "p2p_connect: spmf_p2p_init was not called");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int i = 0; i < p.world; ++i) {
+    if (i == p.rank) {
+      p.peer[i] = p.region;
+      continue;
+    }
+    hipIpcMemHandle_t hnd;
+    memcpy(&hnd, (const char*)handles + (size_t)i * 64, 64);
+    void* ptr = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&ptr, hnd, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      char b[200];
+      snprintf(b, sizeof b, "p2p_connect: hipIpcOpenMemHandle(rank %d): %s", i, hipGetErrorString(e));
+      return fail(c, SPMF_E_HIP, b);
+    }
+    p.peer[i] = (char*)ptr;
+  }
+  p.connected = 1;
+  return SPMF_OK;
+}
+
+int spmf_p2p_status(spmf_ctx* c, uint64_t out3[3]) {
+  if (!c || !out3) return SPMF_E_ARG;
+  if (!c->p2p.region) return fail(c, SPMF_E_ARG, "p2p_status: spmf_p2p_init was not called");
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(out3, c->p2p.region + c->p2p.off_seq, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return SPMF_OK;
+}
+
+int spmf_p2p_destroy(spmf_ctx* c) {
+  if (!c) return SPMF_E_ARG;
+  (void)hipDeviceSynchronize();
+  p2p_release(c);
+  return SPMF_OK;
+}
+
+// (2) RCCL, bound at run time
 int spmf_comm_unique_id(void* out128) {
   if (!out128) return SPMF_E_ARG;
   Rccl* r = rccl();
@@ -1057,7 +1312,8 @@ int spmf_comm_init(spmf_ctx* c, const void* id128, int rank, int world) {
 
 int spmf_allreduce(spmf_ctx* c, float* buf, int64_t n, void* stream) {
   if (!c || !buf || n < 0) return fail(c, SPMF_E_ARG, "allreduce: bad arguments");
-  if (!c->comm) return fail(c, SPMF_E_ARG, "allreduce: spmf_comm_init was not called");
+  if (c->p2p.connected) return p2p_allreduce(c, buf, n, (hipStream_t)stream);
+  if (!c->comm) return fail(c, SPMF_E_ARG, "allreduce: neither spmf_comm_init nor spmf_p2p_connect was called");
   if (n == 0) return SPMF_OK;
   Rccl* r = rccl();
   const int rc = r->allreduce(buf, buf, (size_t)n, kNcclFloat, kNcclSum, c->comm, (hipStream_t)stream);

@@ -74,7 +74,7 @@ __device__ __forceinline__ void pack_block(const double* __restrict__ dacc, floa
     constexpr int W = 256 / SEG;
     __shared__ double seg_sum[SEG][W];
     const int i = threadIdx.x % W, g = threadIdx.x / W;
-    const int nb = (int)det_slots[0];
+    const int nb = min(max((int)det_slots[0], 0), kDetMaxBlocks);   // (never past the slot area, whatever the word says)
     const int per = (nb + SEG - 1) / SEG;
     double v = 0.0;
     if (i < LEN) {

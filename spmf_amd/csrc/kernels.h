@@ -207,6 +207,11 @@ struct FinishArgs {
   float* putau;          // [S][ceil(D/32)][KP] per-block u_tau gradient sums (workspace)
 };
 void launch_finish(int KP, const FinishArgs& a, int phase, hipStream_t st);
+// The step as spmf_step_begin / spmf_step_end run it (ABI 6): the prior half of the finish inside the prep
+// launch (prep.hip begin_kernel; f.acc / f.dprep / f.n_nonfinite unused, f.S == a.S), and the data half with
+// the fold of the prior half's per-block sums as the step's last launch (finish.hip end_kernel).
+void launch_step_begin(int KP, const PrepArgs& a, const FinishArgs& f, hipStream_t st);
+void launch_step_end(int KP, const FinishArgs& a, hipStream_t st);
 
 // ---- surrogate posterior / optimiser (surrogate.hip) ----------------------
 struct SurVar {
@@ -242,6 +247,22 @@ void launch_surrogate_bwd_adam(const SurTable& T, const AdamTable& A, int nvars,
 void launch_vi_gate(const double* parts, const double* logq, const double* nnf, int S, double c, double rows, double* state, hipStream_t st);
 void launch_adam_dev(const AdamTable& T, int ntensors, int max_n, const double* state, hipStream_t st);
 void launch_adam(const AdamTable& T, int ntensors, int max_n, float lr, float b1, float b2, float eps, float c1, float c2, float clip, hipStream_t st);
+
+// ---- the step's collective over peer pointers (p2p.hip) ---------------------------------
+constexpr int kP2PMaxWorld = 16;    // ranks of one node
+constexpr int kP2PMaxChunks = 256;  // workgroups of the collective's kernel
+struct P2PLaunch {
+  float* buf;
+  int64_t n;
+  int rank, world, nchunk;
+  int64_t slice_cap;
+  float *rs, *ag;
+  uint64_t *flags, *seq;
+  float* peer_rs[kP2PMaxWorld];
+  float* peer_ag[kP2PMaxWorld];
+  uint64_t* peer_flags[kP2PMaxWorld];
+};
+void launch_p2p_allreduce(const P2PLaunch& L, hipStream_t st);
 
 struct StatsArgs {
   int64_t B;

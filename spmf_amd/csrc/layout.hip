@@ -285,11 +285,17 @@ __global__ __launch_bounds__(256) void layout_unpack_kernel(int64_t nnz, int D, 
   }
 }
 
+// (an input the key pass rejected -- a row_ptr that is no CSR, a column out of range -- can give
+//  neighbouring panels overlapping or reversed entry ranges, hence list "lengths" below zero or of up to nnz per
+//  panel: such an input gets NO work items at all, so nothing below writes outside the scratch carve; the
+//  key pass ran earlier on this stream, its flags are complete)
 __global__ __launch_bounds__(256) void layout_nseg_kernel(int64_t nkeys, int seg, const int32_t* __restrict__ excl,
-                                                          int32_t* __restrict__ nseg) {
+                                                          int32_t* __restrict__ nseg, const int* __restrict__ info) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k > nkeys) return;
-  nseg[k] = k < nkeys ? (excl[k + 1] - excl[k] + seg - 1) / seg : 0;
+  const bool rejected = (info[I_FLAGS] & (F_ROWPTR | F_COLUMN)) != 0;
+  const int len = k < nkeys ? excl[k + 1] - excl[k] : 0;
+  nseg[k] = (rejected || len <= 0) ? 0 : (len + seg - 1) / seg;
 }
 
 __global__ __launch_bounds__(256) void layout_fill_kernel(int64_t n, uint32_t v, uint32_t* __restrict__ p) {
@@ -302,10 +308,15 @@ __global__ __launch_bounds__(256) void layout_items_kernel(int64_t nkeys, int D,
                                                            const int32_t* __restrict__ excl,
                                                            const int32_t* __restrict__ first,
                                                            int4* __restrict__ raw, uint32_t* __restrict__ ikey,
-                                                           uint32_t* __restrict__ ival, int* __restrict__ info) {
+                                                           uint32_t* __restrict__ ival, int* __restrict__ info,
+                                                           int64_t max_items) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k == 0) info[I_NITEMS] = first[nkeys];
-  if (k >= nkeys) return;
+  const bool rejected = (info[I_FLAGS] & (F_ROWPTR | F_COLUMN)) != 0;
+  if (k == 0) {
+    const int64_t n = rejected ? 0 : first[nkeys];
+    info[I_NITEMS] = (int)(n < 0 ? 0 : (n > max_items ? max_items : n));
+  }
+  if (k >= nkeys || rejected) return;
   const int start = excl[k], len = excl[k + 1] - start;
   if (len <= 0) return;
   const int64_t p = k / D;
@@ -314,6 +325,7 @@ __global__ __launch_bounds__(256) void layout_items_kernel(int64_t nkeys, int D,
   const uint32_t kb = ((uint32_t)p * 2u + half) * (uint32_t)(seg + 1);
   const int f = first[k];
   for (int s = 0, off = 0; off < len; ++s, off += seg) {
+    if (f < 0 || (int64_t)f + s >= max_items) return;      // (cannot happen on an accepted input: max_items bounds it)
     const int l = len - off < seg ? len - off : seg;
     raw[f + s] = make_int4(start + off, l, d, 0);
     ikey[f + s] = kb + (uint32_t)(seg - l);
@@ -531,7 +543,7 @@ int run_build(const Geo& g, const int32_t* row_ptr, const int32_t* col, const fl
       // work items: they depend on the list lengths only
       int32_t* nseg = (int32_t*)(scratch + S.nseg);
       hipLaunchKernelGGL(layout_nseg_kernel, dim3(blocks_for(g.nkeys + 1)), dim3(256), 0, st, g.nkeys, g.seg, excl,
-                         nseg);
+                         nseg, info);
       LCHK(rocprim::exclusive_scan(temp, tb, nseg, first, 0, (size_t)g.nkeys + 1, rocprim::plus<int32_t>(), st));
       uint32_t* ikey_in = (uint32_t*)(scratch + S.ikey_in);
       uint32_t* ikey_out = (uint32_t*)(scratch + S.ikey_out);
@@ -542,7 +554,8 @@ int run_build(const Geo& g, const int32_t* row_ptr, const int32_t* col, const fl
       hipLaunchKernelGGL(layout_fill_kernel, dim3(blocks_for(g.max_items)), dim3(256), 0, st, g.max_items, 0u,
                          ival_in);
       hipLaunchKernelGGL(layout_items_kernel, dim3(blocks_for(g.nkeys + 1)), dim3(256), 0, st, g.nkeys, g.D, g.seg,
-                         col_split, excl, first, (int4*)(scratch + S.raw), ikey_in, ival_in, info);
+                         col_split, excl, first, (int4*)(scratch + S.raw), ikey_in, ival_in, info,
+                         (int64_t)g.max_items);
       LCHK(rocprim::radix_sort_pairs(temp, tb, ikey_in, ikey_out, ival_in, ival_out, (size_t)g.max_items, 0u,
                                      (unsigned)g.item_bits, st));
       hipLaunchKernelGGL(layout_gather_items_kernel, dim3(blocks_for(g.max_items)), dim3(256), 0, st, info,

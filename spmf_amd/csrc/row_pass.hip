@@ -36,6 +36,8 @@ namespace spmf {
 #ifndef ROW_MAX_BLOCKS
 #define ROW_MAX_BLOCKS 4096
 #endif
+static_assert(ROW_MAX_BLOCKS <= spmf::kDetMaxBlocks,
+              "the deterministic mode's per-workgroup slots (common.h kDetMaxBlocks) are sized for at most that many row-pass workgroups");
 #ifndef ROW_GRP
 #define ROW_GRP 4
 #endif

@@ -96,6 +96,72 @@ class LibraryComm:
         _lib.check(h, lib.spmf_allreduce(h, t.data_ptr(), t.numel(), stream), "spmf_allreduce")
 
 
+class PeerComm:
+    """The step's collective as the library's own kernel over peer pointers
+    (include/spmf_hip.h spmf_p2p_*; csrc/p2p.hip): a direct reduce-scatter + all-gather in
+    which every rank pushes its slices straight into the owners' inboxes -- over xGMI when the
+    ranks are GPUs of one node, through same-device IPC mappings when they are processes on
+    one GPU (how the one-GPU tests run it at world 2 and 4).  One kernel launch per rank on
+    the caller's stream: stream-ordered, capturable in a hipGraph (the call counter is on the
+    device), and every rank ends with the same bits (each slice is reduced once, by its owner,
+    in rank order).  torch.distributed (any backend) only carries the 64-byte IPC handles at
+    construction.  ``n_max``: the longest buffer that will be reduced (default: the packed
+    accumulators of ``max_draws`` draws)."""
+
+    def __init__(self, model, n_max=None, max_draws=1, nchunk=0, rank=None, world=None, group=None):
+        import ctypes as C
+        from . import _lib
+        self.model = model
+        lib, h = _lib.load(), model._handle()
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if n_max is None:
+            n_max = int(lib.spmf_acc_len(h, int(max_draws)))
+        n_max = max(int(n_max), 4 * int(world))
+        hnd = (C.c_char * 64)()
+        _lib.check(h, lib.spmf_p2p_init(h, int(rank), int(world), n_max, int(nchunk), hnd), "spmf_p2p_init")
+        mine = torch.frombuffer(bytearray(hnd.raw), dtype=torch.uint8).clone()
+        if world > 1:
+            if dist.get_backend(group) == "nccl":
+                mine = mine.to(model.device)
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=group)
+            blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in every)
+        else:
+            blob = bytes(mine.numpy().tobytes())
+        raw = (C.c_char * (64 * world)).from_buffer_copy(blob)
+        _lib.check(h, lib.spmf_p2p_connect(h, raw), "spmf_p2p_connect")
+        if world > 1:
+            dist.barrier(group=group)      # every rank has mapped every region before the first push
+        self.rank, self.world, self.n_max = int(rank), int(world), n_max
+        self.kind = "p2p"
+
+    def all_reduce_(self, t):
+        from . import _lib
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("PeerComm reduces contiguous fp32 device tensors (the packed accumulators)")
+        lib, h = _lib.load(), self.model._handle()
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        _lib.check(h, lib.spmf_allreduce(h, t.data_ptr(), t.numel(), stream), "spmf_allreduce")
+
+    def status(self):
+        """(calls completed, first call in which a workgroup gave up waiting for a peer or 0).
+        Synchronises the device."""
+        import ctypes as C
+        from . import _lib
+        lib, h = _lib.load(), self.model._handle()
+        out = (C.c_uint64 * 3)()
+        _lib.check(h, lib.spmf_p2p_status(h, out), "spmf_p2p_status")
+        return int(out[0]), int(out[2])
+
+    def close(self):
+        from . import _lib
+        lib, h = _lib.load(), self.model._handle()
+        _lib.check(h, lib.spmf_p2p_destroy(h), "spmf_p2p_destroy")
+
+
 class ShardReducer:
     """Holds the global batch constants and performs the per-step all-reduce.
     ``comm``: a LibraryComm moves the packed fp32 accumulators with the library's
@@ -130,6 +196,8 @@ class ShardReducer:
         (profiles/r04_graph_threshold_sweep.txt)."""
         if self.capture is not None:
             return bool(self.capture) and (self.comm is not None or not self.active)
+        if getattr(self.comm, "kind", None) == "p2p":
+            return True    # a kernel launch whose call counter lives on the device (tests: world 2 and 4 replayed)
         return (self.comm is not None and self.world == 1) or not self.active
 
     def sum_(self, acc):
@@ -141,11 +209,17 @@ class ShardReducer:
         """Global (rows, lgamma) of the batch this rank's struct `cs` belongs to, reduced ONCE
         per batch object and remembered: the device-resident training loop (vi.vi_step_dev)
         asks every step and must not read anything back.  Valid while rank r's i-th batch
-        always meets the same batches of the other ranks (a fixed data factory)."""
+        always meets the same batches of the other ranks (a fixed data factory, the same
+        number of batches per epoch on every rank: a rank that misses where the others hit
+        would enter the collective alone).  A miss inside a hipGraph capture raises."""
         if self.rows_global is not None:
             return self.rows_global, self.lgamma_global
         hit = self._totals_cache.get(id(cs))
         if hit is None or hit[0] is not cs:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ShardReducer.batch_totals: the totals of this batch are not known yet and a "
+                                   "hipGraph capture is in progress (their reduction is a collective and a host "
+                                   "read): run the step eagerly once before capturing it")
             if len(self._totals_cache) > 4096:
                 self._totals_cache.clear()
             hit = (cs, self.totals(cs.n_rows, cs.lgamma_sum))

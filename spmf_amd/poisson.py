@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict
 
 import numpy as np
@@ -42,6 +43,7 @@ class PoissonFactorization:
     bijectors = None
     var_list = []
     s_tau_scale = 1
+    _dtype_notice_given = False   # the float64 notice is printed once per process
     _likelihood_flag = 0          # extra ctx flag of a subclass (BernoulliFactorization)
     _identity_vars = ()           # variables with an Identity bijector in the surrogate
 
@@ -53,7 +55,7 @@ class PoissonFactorization:
             scale_columns=True, scale_rows=True, log_transform=False,
             horshoe_plus=True, column_norms=None, count_key='counts',
             initialize_distributions=True,
-            dtype=torch.float64, device=None, panel_rows=None,
+            dtype=None, device=None, panel_rows=None,
             **kwargs):
         # poisson.py:94-97 lets callers swap g / f.  The kernels know the two built-in
         # pairs only; with a callable the energy takes the dense torch-on-device route of
@@ -77,7 +79,15 @@ class PoissonFactorization:
         if column_norms is not None:
             self.eta_i = column_norms
         self.count_key = count_key
-        self.dtype = dtype
+        # the reference's default is float64 (poisson.py:64) and its CLI passes it (bin/factorize_csv.py:119);
+        # a caller who ASKS for it is told once what runs instead
+        self.dtype = torch.float64 if dtype is None else dtype
+        if dtype is not None and "64" in str(dtype) and not PoissonFactorization._dtype_notice_given:
+            PoissonFactorization._dtype_notice_given = True
+            print("dtype=float64 requested: the device arithmetic of this build is float32 storage and FMA "
+                  "with float64 accumulation of every scalar sum (energy parts to 1e-5 relative of the "
+                  "float64 reference); the log_transform decoder evaluates exp(min(y, 70)) - 1 where "
+                  "float64 is finite up to y = 709 (reported as 'Decoder saturated' while it happens)")
         self.symmetry_breaking_decay = symmetry_breaking_decay
         self.log_transform = log_transform
         self.feature_dim = feature_dim
@@ -405,6 +415,9 @@ class PoissonFactorization:
         nnf2 = torch.empty(2 * S, dtype=torch.float64, device=self.device)
         nnf = nnf2[:S]
         rows_g, lg_g = cs.n_rows, cs.lgamma_sum
+        # SPMF_LEGACY_STEP=1: the version-5 call sequence (spmf_data_pass [+ spmf_prior_async] + spmf_finish),
+        # kept for A/B timing and for callers built against it; the results are the same
+        legacy = os.environ.get("SPMF_LEGACY_STEP", "0") == "1"
         split = (all_reduce is not None and S == 1 and getattr(self, "column_split", 0) > 0
                  and sc.col_split == self.column_split and hasattr(all_reduce, "start"))
         if split:
@@ -427,16 +440,19 @@ class PoissonFactorization:
             r = all_reduce.totals(cs.n_rows, cs.lgamma_sum)
             if r is not None:
                 rows_g, lg_g = r
-        else:
+        elif legacy:
             _lib.check(h, lib.spmf_data_pass(h, C.byref(cs), S, pin, eta.data_ptr(), stream),
                        "spmf_data_pass")
+        else:
+            # ABI 6: the outputs go in with the step's first call, so the prior half of the finish
+            # (parameters only) runs inside the data pass's first launch
+            _lib.check(h, lib.spmf_step_begin(h, C.byref(cs), S, float(prior_weight), pin, eta.data_ptr(),
+                                              parts.data_ptr(), gout, nnf.data_ptr(), stream),
+                       "spmf_step_begin")
         if all_reduce is not None and not split:
-            # the prior half of the finish reads no accumulator: it runs on the
-            # library's side stream while the collective has the GPU mostly idle
-            # (beside the sparse passes it costs them more than it hides: measured).
-            # The reducer decides (ShardReducer.overlap_prior: on with more than one rank;
-            # with one rank the fork/join costs what the prior half would save)
-            if getattr(all_reduce, "overlap_prior", True):
+            # (version-5 flow only: the prior half of the finish on the library's side stream
+            # while the collective has the GPU mostly idle; ShardReducer.overlap_prior)
+            if legacy and getattr(all_reduce, "overlap_prior", True):
                 _lib.check(h, lib.spmf_prior_async(h, S, float(prior_weight), pin, eta.data_ptr(),
                                                    parts.data_ptr(), gout, stream), "spmf_prior_async")
             n = lib.spmf_acc_len(h, S)
@@ -444,9 +460,12 @@ class PoissonFactorization:
             r = all_reduce(acc, cs.n_rows, cs.lgamma_sum)
             if r is not None:
                 rows_g, lg_g = r
-        _lib.check(h, lib.spmf_finish(h, S, int(rows_g), float(lg_g), float(prior_weight), pin, eta.data_ptr(),
-                                      parts.data_ptr(), gout, nnf.data_ptr(), stream),
-                   "spmf_finish")
+        if split or legacy:
+            _lib.check(h, lib.spmf_finish(h, S, int(rows_g), float(lg_g), float(prior_weight), pin,
+                                          eta.data_ptr(), parts.data_ptr(), gout, nnf.data_ptr(), stream),
+                       "spmf_finish")
+        else:
+            _lib.check(h, lib.spmf_step_end(h, int(rows_g), float(lg_g), stream), "spmf_step_end")
         if nonfinite == "rule" and float(nnf.sum()) > 0.0:
             io, nlg = self._nonfinite_scan(sc, cs, data, S, P)
             if all_reduce is not None:

@@ -495,6 +495,10 @@ class StepRunner:
             return
         if len(self.graphs) >= self.max_graphs:
             self.graphs.pop(next(iter(self.graphs)))
+        if self.all_reduce is not None and hasattr(self.all_reduce, "batch_totals"):
+            # the batch's global totals must already be known: reducing them is a collective plus a host
+            # read, neither of which may happen inside the capture (ShardReducer.batch_totals refuses it)
+            self.all_reduce.batch_totals(cs)
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
         graph = torch.cuda.CUDAGraph()
@@ -591,8 +595,12 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
     #  a foreign all_reduce hook, which only knows how to sum the accumulators)
     device_loop = getattr(model, "_custom_codec", None) is None and (
         all_reduce is None or hasattr(all_reduce, "batch_totals"))
-    # (a deterministic model's replicas apply bit-identical updates: the guard re-broadcast is not needed)
-    sync_every = 0 if getattr(model, "deterministic", False) else int(kwargs.get("sync_every", 200))
+    # (a deterministic model's replicas apply bit-identical updates on the device loop: the guard
+    #  re-broadcast is not needed THERE; the eager loop a skipped batch falls back to runs the
+    #  non-finite rule, whose accumulator patch uses atomics and is outside that guarantee, so the
+    #  guard comes back with it -- see the fallback below)
+    sync_default = int(kwargs.get("sync_every", 200))
+    sync_every = 0 if getattr(model, "deterministic", False) else sync_default
     since_sync = 0
     if device_loop:
         opt.init_state(clip_value)
@@ -622,6 +630,7 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
                 # host decision); from here on run the eager loop, which trains THROUGH
                 # non-finite cells like the reference (poisson.py:606-616)
                 device_loop = False
+                sync_every = sync_default         # (deterministic models: the eager / rule path is not bit-reproducible)
                 opt.t = int(st[7])
                 if nb == 0:
                     continue                      # nothing applied yet: next epoch, eagerly

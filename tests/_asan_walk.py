@@ -15,7 +15,7 @@ for name, (res, args) in _lib.SIGNATURES.items():
     fn = getattr(lib, name)
     fn.restype, fn.argtypes = res, args
 
-assert lib.spmf_version() == 5 and lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct)
+assert lib.spmf_version() == 6 and lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct)
 h = C.c_void_p()
 assert lib.spmf_ctx_create(0, 100, 10, 0, C.byref(h)) == -1
 assert lib.spmf_ctx_create(0, 0, 10, 0, C.byref(h)) == -1

@@ -171,6 +171,16 @@ def test_builder_rejects_what_would_make_the_kernels_read_out_of_bounds():
     if p2[10] != p2[11]:
         with pytest.raises(_lib.SpmfError, match="row_ptr"):
             _build(p2, col, val, rows, D, 64, 0, native=True)
+    # offsets that zig-zag AT the panel edges (panels of 64 rows: edges at rows 64 and 128): neighbouring
+    # panels get overlapping / reversed entry ranges, list "lengths" below zero or of a whole panel -- the
+    # item stage must not be driven by them (it wrote outside its scratch)
+    for edit in ({64: ptr[128], 128: ptr[64]}, {64: ptr[192], 128: ptr[1]}, {64: 0, 128: ptr[-1], 192: 0}):
+        p4 = ptr.copy()
+        for i, v in edit.items():
+            p4[i] = v
+        with pytest.raises(_lib.SpmfError, match="row_ptr"):
+            _build(p4, col, val, rows, D, 64, 0, native=True)
+    _build(ptr, col, val, rows, D, 64, 0, native=True)      # and the builder still works afterwards
     p3 = ptr.copy()
     p3[-1] += 4                                  # row_ptr[n_rows] != nnz
     with pytest.raises(_lib.SpmfError, match="row_ptr"):

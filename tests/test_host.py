@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.spmf_version() == 5 and 'define SPMF_ABI_VERSION 5' in hdr
+    assert lib.spmf_version() == 6 and 'define SPMF_ABI_VERSION 6' in hdr
 
 
 def test_library_exports_only_the_c_abi(lib):
@@ -336,3 +336,19 @@ def test_packed_entries_only_for_integer_counts_in_16_bits():
     top = sp.csr_matrix((np.ones(1, np.float32), (np.array([0]), np.array([65535]))), shape=(1, 65536))
     t = SparseCounts.from_any(top, "cpu", 1)
     assert (int(t.ent[0]) & 0xffffffff) == (65535 << 16) | 1
+
+
+def test_float64_request_is_answered_once(capsys):
+    """poisson.py:64 / bin/factorize_csv.py:119: the reference computes in float64 and its callers say so.  This
+    build accepts the keyword and computes in float32 with float64 accumulation: a caller who asks for float64 is
+    told so, once per process (VERDICT r4 #6); the default construction says nothing extra."""
+    import numpy as np
+    from spmf_amd import PoissonFactorization
+    PoissonFactorization._dtype_notice_given = False
+    m = PoissonFactorization(latent_dim=2, feature_dim=5, device="cpu", initialize_distributions=False)
+    assert "float64" not in capsys.readouterr().out and m.dtype is not None
+    PoissonFactorization(latent_dim=2, feature_dim=5, dtype=np.float64, device="cpu", initialize_distributions=False)
+    out = capsys.readouterr().out
+    assert "float32 storage" in out and "float64 accumulation" in out and "min(y, 70)" in out
+    PoissonFactorization(latent_dim=2, feature_dim=5, dtype="float64", device="cpu", initialize_distributions=False)
+    assert "float32 storage" not in capsys.readouterr().out
