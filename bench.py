@@ -652,7 +652,12 @@ def main():
             saved = [p_.detach().clone() for p_ in sur.trainable_variables]
             for key, force_graph, red in (("shard125k_vi_1rank_rccl_ms", False, red1),
                                           ("shard125k_vi_1rank_rccl_graph_ms", True, red1),
-                                          ("shard125k_vi_no_comm_ms", False, None)):
+                                          ("shard125k_vi_no_comm_ms", False, None),
+                                          # the order of round 4: every surrogate kernel in front of the data pass,
+                                          # one stream (SPMF_VI_OVERLAP=0); the default runs the scale hierarchy's
+                                          # draws / transform / prior half beside the column pass (vi.vi_step_dev)
+                                          ("shard125k_vi_single_stream_ms", False, None)):
+                os.environ["SPMF_VI_OVERLAP"] = "0" if "single_stream" in key else "1"
                 o_ = _vi.AdamHIP(model, sur.trainable_variables, 1e-3)
                 o_.init_state(3.0)
                 # default: what fit() runs (StepRunner replays a hipGraph for launch-bound batches and
@@ -667,6 +672,7 @@ def main():
                     for p_, q_ in zip(sur.trainable_variables, saved):
                         p_.copy_(q_)
             del saved
+            os.environ.pop("SPMF_VI_OVERLAP", None)
             _lib.check(h, lib.spmf_comm_destroy(h), "spmf_comm_destroy")
         except Exception as e:                      # no librccl on the box: report, do not fail
             extras["allreduce_1rank_us"] = None

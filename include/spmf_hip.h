@@ -352,6 +352,15 @@ int spmf_prior_async(spmf_ctx* ctx, int S, double prior_weight,
                      const float* const params[SPMF_NVARS], const float* eta, double* parts,
                      float* const grads[SPMF_NVARS], void* stream);
 
+/* Optional marker inside the data pass (ABI 6): `event` (a hipEvent_t of the caller, NULL = none) is recorded
+ * on the pass's stream right behind its row stage -- after the row pass of the last draw has been issued,
+ * before the column pass.  Work of the caller that does not feed the data pass (the VI step's draws and
+ * transform of the scale hierarchy, the prior half of the finish: spmf_amd/vi.py) waits for it on another
+ * stream and so runs beside the column pass -- many short workgroups that share the chip gracefully -- and
+ * not beside the row pass, whose launch is exactly the resident set and is delayed as a whole by any
+ * workgroup that holds a slot when it starts. */
+int spmf_ctx_set_rows_event(spmf_ctx* ctx, void* event);
+
 /* Column split of the packed accumulators (multi-GPU: all-reduce one half while
  * the column pass still produces the other).  With Dh set (a multiple of 32 in
  * (0, D); 0 or D = none; linear Poisson decoder only) the accumulators of a
@@ -547,6 +556,9 @@ typedef struct spmf_sur_var {
   int64_t noise_ld;
 } spmf_sur_var;
 
+/* (spmf_sample_noise and spmf_surrogate_fwd skip a variable whose n is 0: nothing is read or written for it,
+ * the other variables keep their indices -- the Philox counter of a draw and the order of the log q sum do
+ * not depend on which variables a call covers, so a caller may draw / transform the variables in two calls.) */
 /* Base noise for every variable, drawn on the device into the caller's noise
  * (and, kind 2, dgda) buffers: eps ~ N(0,1), or g ~ Gamma(softplus(t0), 1) with
  * its implicit-reparameterisation derivative d g / d concentration.  Counter-based

@@ -153,6 +153,7 @@ SIGNATURES = {
     "spmf_surrogate_bwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_void_p]),
     "spmf_ctx_set_column_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "spmf_ctx_set_rows_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spmf_acc_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "spmf_data_pass_split": (C.c_int, [C.c_void_p, C.POINTER(CountsStruct), C.c_int, PtrArray,
                                        C.c_void_p, C.c_int, C.c_void_p]),

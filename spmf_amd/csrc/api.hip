@@ -75,6 +75,7 @@ struct spmf_ctx {
   double* scratch = nullptr;
   static constexpr size_t kScratchDoubles = 1u << 20;   // 8 MiB
   void* comm = nullptr;           // ncclComm_t of the row-shard collective (spmf_comm_init)
+  hipEvent_t rows_event = nullptr; // caller's event recorded behind the row stage of a data pass (spmf_ctx_set_rows_event)
   // spmf_step_begin .. spmf_step_end (ABI 6): the step's outputs are known from its first call on, so the
   // prior half of the finish rides in the prep launch (fused = 1) and spmf_step_end launches the data half only
   struct StepOut {
@@ -867,6 +868,9 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       launch_row_pass(KP, r2, st);
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    // the caller's marker "the row stage of the last draw has been issued": what it makes wait for this event
+    // runs beside the column pass instead of beside the resident-set row launch (spmf_ctx_set_rows_event)
+    if (c->rows_event && s + nbat == S) HIPCHK(c, hipEventRecord(c->rows_event, st));
     }   // first
     if (ct->n_rows > 0 && ct->nnz > 0) {
       for (int hf = 0; hf < 2; ++hf) {
@@ -927,6 +931,12 @@ int spmf_data_pass_split(spmf_ctx* c, const spmf_counts* ct, int S, const float*
     const float* eta, int part, void* stream) {
   if (part != 0 && part != 1) return fail(c, SPMF_E_ARG, "data_pass_split: part must be 0 or 1");
   return data_pass_impl(c, ct, S, params, eta, part == 0 ? 1 : 2, stream);
+}
+
+int spmf_ctx_set_rows_event(spmf_ctx* c, void* event) {
+  if (!c) return SPMF_E_ARG;
+  c->rows_event = (hipEvent_t)event;
+  return SPMF_OK;
 }
 
 int spmf_ctx_set_column_split(spmf_ctx* c, int Dh) {
@@ -1379,6 +1389,10 @@ int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
   int max_n = 0;
   for (int i = 0; i < nvars; ++i) {
     const spmf_sur_var& v = vars[i];
+    if (v.n == 0) {                 // skipped variable (its slot keeps its index: the RNG counter, the logq slots)
+      T.v[i] = SurVar{};
+      continue;
+    }
     if (!v.t0 || !v.t1 || !v.noise || !v.theta || v.n < 1 || v.kind < 0 || v.kind > 2) return fail(c, SPMF_E_ARG,
         "surrogate_fwd: bad variable");
     if (v.noise_ld != 0 && v.noise_ld < v.n) return fail(c, SPMF_E_ARG, "surrogate: noise_ld < n");
@@ -1386,6 +1400,7 @@ int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
         v.noise_ld ? v.noise_ld : (int64_t)v.n};
     if (v.n > max_n) max_n = v.n;
   }
+  if (max_n < 1) return fail(c, SPMF_E_ARG, "surrogate_fwd: every variable is skipped (n = 0)");
   hipStream_t st = (hipStream_t)stream;
   if (!c->scratch) {
     // first use (never inside a stream capture: a step is run eagerly before it is captured);
@@ -1411,6 +1426,10 @@ int spmf_sample_noise(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, u
   int max_n = 0;
   for (int i = 0; i < nvars; ++i) {
     const spmf_sur_var& v = vars[i];
+    if (v.n == 0) {                 // skipped variable: nothing is drawn for it, the others keep their indices
+      T.v[i] = SurVar{};
+      continue;
+    }
     if (!v.t0 || !v.noise || v.n < 1 || v.kind < 0 || v.kind > 2 || (v.kind == 2 && !v.dgda)) return fail(c,
         SPMF_E_ARG, "sample_noise: bad variable (t0 / noise / dgda buffers)");
     if (v.noise_ld != 0 && v.noise_ld < v.n) return fail(c, SPMF_E_ARG, "surrogate: noise_ld < n");
@@ -1418,6 +1437,7 @@ int spmf_sample_noise(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, u
         v.noise_ld ? v.noise_ld : (int64_t)v.n};
     if (v.n > max_n) max_n = v.n;
   }
+  if (max_n < 1) return fail(c, SPMF_E_ARG, "sample_noise: every variable is skipped (n = 0)");
   launch_sample_noise(T, nvars, max_n, S, seed, counter, state, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;

@@ -372,7 +372,7 @@ class PoissonFactorization:
     # the hot path
     # ------------------------------------------------------------------
     def energy_and_grads(self, data, params, all_reduce=None, prior_weight=1.0,
-                         nonfinite="count"):
+                         nonfinite="count", beside_columns=None):
         """All 14 energy parts (poisson.py:582-621) and d(sum of parts)/d(param)
         for every one of the 12 variables, for S draws, on the GPU.
 
@@ -383,6 +383,12 @@ class PoissonFactorization:
         the data pass and the finish kernel -- the single collective of the
         row-sharded multi-GPU path; it must also return the global
         (rows, lgamma_sum) via its return value or None for single shard.
+
+        ``beside_columns`` (the VI step, spmf_amd/vi.py): ``((side_stream, rows_event), fn)`` -- the data
+        pass reads v, w, u, s only, so the caller may hand over the OTHER parameter tensors unfilled: ``fn``
+        fills them on ``side_stream`` once the row pass is done (the library records ``rows_event`` there:
+        spmf_ctx_set_rows_event), the prior half of the finish follows it on that stream, and the finish
+        joins -- all of it beside the column pass and the collective.
 
         ``nonfinite``: what happens when stored cells have a non-finite
         log-pmf (rate 0 under a positive count).  "count" (default, no host
@@ -440,6 +446,21 @@ class PoissonFactorization:
             r = all_reduce.totals(cs.n_rows, cs.lgamma_sum)
             if r is not None:
                 rows_g, lg_g = r
+        elif beside_columns is not None:
+            (side, ev_rows), fill = beside_columns
+            legacy = True                    # data pass, prior half on the side stream, finish joins it
+            _lib.check(h, lib.spmf_ctx_set_rows_event(h, ev_rows.cuda_event), "spmf_ctx_set_rows_event")
+            try:
+                _lib.check(h, lib.spmf_data_pass(h, C.byref(cs), S, pin, eta.data_ptr(), stream),
+                           "spmf_data_pass")
+            finally:
+                lib.spmf_ctx_set_rows_event(h, None)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_rows)
+                fill()
+                _lib.check(h, lib.spmf_prior_async(h, S, float(prior_weight), pin, eta.data_ptr(),
+                                                   parts.data_ptr(), gout, side.cuda_stream),
+                           "spmf_prior_async")
         elif legacy:
             _lib.check(h, lib.spmf_data_pass(h, C.byref(cs), S, pin, eta.data_ptr(), stream),
                        "spmf_data_pass")
@@ -452,7 +473,7 @@ class PoissonFactorization:
         if all_reduce is not None and not split:
             # (version-5 flow only: the prior half of the finish on the library's side stream
             # while the collective has the GPU mostly idle; ShardReducer.overlap_prior)
-            if legacy and getattr(all_reduce, "overlap_prior", True):
+            if legacy and beside_columns is None and getattr(all_reduce, "overlap_prior", True):
                 _lib.check(h, lib.spmf_prior_async(h, S, float(prior_weight), pin, eta.data_ptr(),
                                                    parts.data_ptr(), gout, stream), "spmf_prior_async")
             n = lib.spmf_acc_len(h, S)

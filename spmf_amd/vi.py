@@ -126,22 +126,9 @@ class Surrogate:
     # ---- HIP path -------------------------------------------------------
     _KIND = {"normal": 0, "normal_identity": 1, "invgamma": 2}
 
-    @torch.no_grad()
-    def draw_noise(self, S, seed=None, state=None):
-        """Base noise per variable, drawn by the HIP sampler (spmf_sample_noise:
-        Philox4x32-10; eps ~ N(0,1), or for the InverseGamma kinds g ~
-        Gamma(softplus(t0), 1) and d g/d concentration by implicit
-        reparameterisation).  One launch for ALL variables: a variable's noise is a
-        column slice of an [S, total] buffer (row stride = total, passed as noise_ld).
-        ``seed``: 64-bit key; None draws one from torch's CPU generator, so
-        ``torch.manual_seed`` still makes a run reproducible and ranks that share a
-        seed (dist.sync_seed) draw identical noise.  ``state``: the optimiser's
-        device state; its step counter (advanced by spmf_vi_gate) is added to the
-        Philox counter, which is what gives a hipGraph replay fresh noise."""
-        model = self._model()
-        lib, h = _lib.load(), model._handle()
-        if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+    def alloc_noise(self, S):
+        """Buffers of the base noise of all variables (name -> (noise, dgda or None)): a variable's noise is
+        a column slice of an [S, total] buffer (row stride = total, passed as noise_ld)."""
         out = {}
         nor = [n for n in self.var_order if self.kinds[n] != "invgamma"]
         if nor:
@@ -156,16 +143,40 @@ class Surrogate:
             for n, gp, dp in zip(self._gam_names, g.split(sizes, dim=1), dg.split(sizes, dim=1)):
                 shape = (S,) + tuple(self.params_of(n)[0].shape)
                 out[n] = (gp.view(shape), dp.view(shape))
-        arr = self._table(S, out)
+        return out
+
+    @torch.no_grad()
+    def draw_noise(self, S, seed=None, state=None, only=None, out=None):
+        """Base noise per variable, drawn by the HIP sampler (spmf_sample_noise:
+        Philox4x32-10; eps ~ N(0,1), or for the InverseGamma kinds g ~
+        Gamma(softplus(t0), 1) and d g/d concentration by implicit
+        reparameterisation).  One launch for ALL variables (or for the names in ``only``:
+        the others are skipped, the draws do not depend on which call covers a variable).
+        ``seed``: 64-bit key; None draws one from torch's CPU generator, so
+        ``torch.manual_seed`` still makes a run reproducible and ranks that share a
+        seed (dist.sync_seed) draw identical noise.  ``state``: the optimiser's
+        device state; its step counter (advanced by spmf_vi_gate) is added to the
+        Philox counter, which is what gives a hipGraph replay fresh noise.
+        ``out``: buffers from alloc_noise (allocated here when None)."""
+        model = self._model()
+        lib, h = _lib.load(), model._handle()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+        if out is None:
+            out = self.alloc_noise(S)
+        arr = self._table(S, out, only=only)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(h, lib.spmf_sample_noise(h, arr, len(self.var_order), S, seed, 0,
                                             state.data_ptr() if state is not None else None,
                                             stream), "spmf_sample_noise")
         return out
 
-    def _table(self, S, noise, theta=None, gtheta=None, grads=None):
+    def _table(self, S, noise, theta=None, gtheta=None, grads=None, only=None):
         arr = (_lib.SurVar * len(self.var_order))()
         for i, n in enumerate(self.var_order):
+            if only is not None and n not in only:
+                arr[i].n = 0                    # skipped by spmf_sample_noise / spmf_surrogate_fwd
+                continue
             t0, t1 = self.params_of(n)
             nz, dg = noise[n]
             v = arr[i]
@@ -183,14 +194,18 @@ class Surrogate:
         return arr
 
     @torch.no_grad()
-    def forward_hip(self, model, S, noise):
-        """theta (dict name -> [S,*shape]) and logq [S] (float64) by the HIP kernel."""
+    def forward_hip(self, model, S, noise, only=None, theta=None, logq=None):
+        """theta (dict name -> [S,*shape]) and logq [S] (float64) by the HIP kernel; ``only``: the
+        variables to transform (logq is then THEIR share of log q); ``theta`` / ``logq``: outputs
+        to fill (allocated here when None)."""
         lib, h = _lib.load(), model._handle()
-        theta = {n: torch.empty(noise[n][0].shape, dtype=torch.float32, device=self.device)
-                 for n in self.var_order}
-        logq = torch.empty(S, dtype=torch.float64, device=self.device)
+        if theta is None:
+            theta = {n: torch.empty(noise[n][0].shape, dtype=torch.float32, device=self.device)
+                     for n in self.var_order}
+        if logq is None:
+            logq = torch.empty(S, dtype=torch.float64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        arr = self._table(S, noise, theta=theta)
+        arr = self._table(S, noise, theta=theta, only=only)
         _lib.check(h, lib.spmf_surrogate_fwd(h, arr, len(self.var_order), S, logq.data_ptr(), stream),
                    "spmf_surrogate_fwd")
         return theta, logq
@@ -372,6 +387,24 @@ class _StepReducer:
         return self._tot
 
 
+def _hierarchy_beside_the_column_pass(model, sur):
+    """The side stream + the "rows done" event of the model when the VI step may split its surrogate work
+    (vi_step_dev), else None: models with the scale hierarchy (horshoe_plus=True) on the HIP energy path;
+    SPMF_VI_OVERLAP=0 switches it off (one stream, the order of round 4)."""
+    import os
+    if os.environ.get("SPMF_VI_OVERLAP", "1") == "0" or getattr(model, "_custom_codec", None) is not None:
+        return None
+    if not any(sur.kinds[n] == "invgamma" for n in sur.var_order) or getattr(model, "column_split", 0):
+        return None
+    st = getattr(model, "_vi_side", None)
+    if st is None:
+        stream = torch.cuda.Stream(device=sur.device)
+        ev_rows = torch.cuda.Event(enable_timing=False)
+        ev_rows.record()                     # (creates the underlying hipEvent_t: its handle goes to the library)
+        st = model._vi_side = (stream, ev_rows)
+    return st
+
+
 @torch.no_grad()
 def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=None,
                 all_reduce=None):
@@ -391,10 +424,6 @@ def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=No
     lib, h = _lib.load(), model._handle()
     sur = model.surrogate_distribution
     S = int(sample_size)
-    # seed given (StepRunner): a fixed key + the device step counter, so the launch
-    # sequence is replayable; else a fresh key from torch's generator per call
-    noise = sur.draw_noise(S, seed=seed, state=opt.state if seed is not None else None)
-    theta, logq = sur.forward_hip(model, S, noise)
     sc, cs = model._batch(batch)
     hook = None
     B = cs.n_rows
@@ -406,7 +435,40 @@ def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=No
         B = int(tot[0])
         hook = _StepReducer(all_reduce, (B, float(tot[1])))
     c = float(B) / float(dataset_rows)
-    parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=hook, prior_weight=c)
+    # seed given (StepRunner): a fixed key + the device step counter, so the launch
+    # sequence is replayable; else a fresh key from torch's generator per call
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+        state = None
+    else:
+        state = opt.state
+    side = _hierarchy_beside_the_column_pass(model, sur)
+    if side is None:
+        noise = sur.draw_noise(S, seed=seed, state=state)
+        theta, logq = sur.forward_hip(model, S, noise)
+        parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=hook, prior_weight=c)
+    else:
+        # The data pass reads v, w, u, s only; the eight variables of the scale hierarchy (the gamma draws
+        # with their implicit gradient, half of the transform) enter the prior alone.  So: draw + transform
+        # the four, issue the data pass, and draw + transform the hierarchy and run the prior half of the
+        # finish on a side stream that starts when the row pass is done -- beside the column pass (and the
+        # all-reduce), which is bound by gathers while this work is arithmetic.  Same draws, same numbers:
+        # the sampler's counter and the log q slots do not depend on which call covers a variable.
+        names_d = frozenset(n for n in sur.var_order if sur.kinds[n] != "invgamma")
+        names_h = frozenset(sur.var_order) - names_d
+        noise = sur.alloc_noise(S)
+        theta = {n: torch.empty(noise[n][0].shape, dtype=torch.float32, device=sur.device) for n in sur.var_order}
+        logq_d = torch.empty(S, dtype=torch.float64, device=sur.device)
+        logq_h = torch.empty(S, dtype=torch.float64, device=sur.device)
+        sur.draw_noise(S, seed=seed, state=state, only=names_d, out=noise)
+        sur.forward_hip(model, S, noise, only=names_d, theta=theta, logq=logq_d)
+
+        def hierarchy():
+            sur.draw_noise(S, seed=seed, state=state, only=names_h, out=noise)
+            sur.forward_hip(model, S, noise, only=names_h, theta=theta, logq=logq_h)
+        parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=hook, prior_weight=c,
+                                               beside_columns=(side, hierarchy))
+        logq = logq_d + logq_h
     stream = torch.cuda.current_stream(sur.device).cuda_stream
     _lib.check(h, lib.spmf_vi_gate(h, model._last_parts.data_ptr(), logq.data_ptr(),
                                    nnf.data_ptr(), S, c, float(B), opt.state.data_ptr(), stream),

@@ -66,6 +66,19 @@ for flags in (0, 1, 2 | 1, 4, 4 | 2, 8, 16 | 1):
         assert lib.spmf_vi_gate(h, None, None, None, 1, 1.0, 1.0, None, None) == -1
         assert lib.spmf_allreduce(h, 4096, 8, None) == -1 and b"comm_init" in lib.spmf_last_error(h)
         assert lib.spmf_comm_init(h, None, 0, 1) == -1
+        # ABI 6: the step with its outputs up front, the peer-pointer collective, the rows event
+        assert lib.spmf_step_end(h, 10, 0.0, None) == -1 and b"step_begin" in lib.spmf_last_error(h)
+        assert lib.spmf_step_begin(h, C.byref(cs), 1, 1.0, P, None, 4096, P, None, None) == -1
+        assert lib.spmf_step_begin(h, C.byref(cs), 1, 1.0, P, 4096, None, P, None, None) == -1
+        assert lib.spmf_p2p_connect(h, None) == -1
+        hb = (C.c_char * 64)()
+        assert lib.spmf_p2p_connect(h, hb) == -1 and b"p2p_init" in lib.spmf_last_error(h)
+        assert lib.spmf_p2p_init(h, 0, 17, 1024, 0, hb) == -1          # more than 16 ranks
+        assert lib.spmf_p2p_init(h, 3, 2, 1024, 0, hb) == -1           # rank outside the world
+        assert lib.spmf_p2p_init(h, 0, 2, 0, 0, hb) == -1              # nothing to reduce
+        assert lib.spmf_p2p_status(h, None) == -1
+        assert lib.spmf_p2p_destroy(h) == 0
+        assert lib.spmf_ctx_set_rows_event(h, None) == 0
         assert lib.spmf_comm_destroy(h) == 0
         # deterministic mode: scratch arithmetic, the contexts it is refused for
         n0, n1 = lib.spmf_det_scratch_bytes(h, 0, 1), lib.spmf_det_scratch_bytes(h, 1000, 1)

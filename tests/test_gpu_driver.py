@@ -608,3 +608,43 @@ def test_hip_sampler_statistics_and_implicit_gradient():
     st[13] = 5.0
     a2 = sur.draw_noise(2, seed=77, state=st)["v"][0].clone()
     assert torch.equal(a0, a1) and not torch.equal(a0, a2)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_vi_step_with_the_hierarchy_beside_the_column_pass_equals_the_single_stream_step(monkeypatch, use_graph):
+    """vi.vi_step_dev draws + transforms v, w, u, s, issues the data pass, and draws + transforms the eight
+    variables of the scale hierarchy and runs the prior half of the finish on a side stream that starts when
+    the row pass is done (spmf_ctx_set_rows_event).  Same draws (the sampler's counter does not depend on which
+    call covers a variable), same kernels: in the deterministic mode the trainables after a few steps are the
+    same BITS as with SPMF_VI_OVERLAP=0 (one stream, the order of round 4), eager and replayed from a hipGraph
+    that holds the fork and the join; the loss agrees to the last digits (log q is added up in two pieces)."""
+    from spmf_amd import PoissonFactorization, SparseCounts
+    from spmf_amd.vi import AdamHIP, StepRunner
+    X = _data()
+    N, D = X.shape
+    sc = SparseCounts.from_any(X, "cuda", 100)
+    batches = [{"counts": sc, "panels": (p, p + 2)} for p in range(0, sc.n_panels, 2)]
+    finals, losses = [], []
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("SPMF_VI_OVERLAP", overlap)
+        torch.manual_seed(3)
+        m = PoissonFactorization(latent_dim=3, feature_dim=D, u_tau_scale=1 / math.sqrt(N * D), device="cuda",
+                                 panel_rows=100, deterministic=True)
+        m.compute_scales(lambda: [{"counts": X}])
+        opt = AdamHIP(m, m.surrogate_distribution.trainable_variables, 0.05)
+        opt.init_state(10.0)
+        run = StepRunner(m, opt, N, 2, use_graph=use_graph, seed=99)
+        for ep in range(3):
+            for b in batches:
+                run.step(b)
+        torch.cuda.synchronize()
+        st = opt.read_state()
+        assert st[11] == 3 * len(batches) and st[12] == 0
+        if use_graph:
+            assert run.replays == 2 * len(batches)
+        assert (getattr(m, "_vi_side", None) is not None) == (overlap == "1")
+        finals.append([t.detach().clone() for t in m.surrogate_distribution.trainable_variables])
+        losses.append(st[10])
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)
+    assert abs(losses[0] - losses[1]) <= 1e-12 * abs(losses[1])
