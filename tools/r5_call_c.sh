@@ -14,6 +14,7 @@ for l in open('$o/fixed_new.jsonl'):
     d=json.loads(l); r=d['runs'][-1]; print('  ', d['shape'], r)
 "
 python bench.py > $o/bench.json 2> $o/bench.err || { tail -5 $o/bench.err; exit 1; }
+python tools/row_order_probe.py 1000000 > $o/row_order.json 2> $o/row_order.err || tail -5 $o/row_order.err
 tools/pmc_r05.sh $o/pmc > $o/pmc.log 2>&1
 python3 tools/pmc_r05_summary.py $o/pmc $o/pmc_summary.json > $o/pmc_summary.txt
 tail -5 $o/pmc.log
