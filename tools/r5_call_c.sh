@@ -4,9 +4,10 @@
 export TMPDIR=/tmp
 o=gpurun_out/r5d
 mkdir -p $o
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > $o/tests.log 2>&1
+timeout -k 10 1000 python -m pytest tests -q -m gpu > $o/tests.log 2>&1
 rc=$?; echo "tests rc=$rc" > $o/tests.rc; tail -3 $o/tests.log
-[ $rc -eq 0 ] || exit 1
+[ $rc -lt 2 ] || exit 1          # (failed assertions: go on; an abort, a timeout or a collection error: stop)
+grep -E "^(FAILED|ERROR)" $o/tests.log
 python tools/fixed_cost_probe.py 3 > $o/fixed_new.jsonl 2> $o/fixed_new.err || { tail -5 $o/fixed_new.err; exit 1; }
 python3 -c "
 import json
