@@ -316,7 +316,8 @@ def c1_gpu_extra(dev, steps=200, warmup=10):
     with contextlib.redirect_stdout(sys.stderr):
         model = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1.0 / (N * D) ** 0.5, device=dev)
         model.compute_scales(lambda: [{"counts": x}])
-    batch = {"counts": x}
+    from spmf_amd.sparse import SparseCounts, balanced_panel_rows
+    batch = {"counts": SparseCounts.from_any(x, dev, balanced_panel_rows(N, K))}     # resident, as every workload here
     torch.manual_seed(20241218)
     params = model.surrogate_distribution.sample(1)
     ms, t6, parts, nnf = _timed_steps(model, batch, params, steps, warmup)
@@ -358,8 +359,9 @@ def ref_harness_extra(dev, steps=100, warmup=10):
     out = {"ref_harness_shape": f"D={D} P={P} S={S} dense Poisson(1) (tests/spmf_test.py:12-43)"}
     torch.manual_seed(20241218)
     params = model.surrogate_distribution.sample(S)
+    from spmf_amd.sparse import SparseCounts, balanced_panel_rows
     for rows, tag in ((10, "b10"), (1000, "b1000")):
-        batch = {"counts": x[:rows]}
+        batch = {"counts": SparseCounts.from_any(x[:rows], dev, balanced_panel_rows(rows, P))}
         ms, _, parts, _ = _timed_steps(model, batch, params, steps, warmup)
         out[f"ref_harness_{tag}_S20_ms"] = ms
         opt = vi.AdamHIP(model, model.surrogate_distribution.trainable_variables, 0.01)
@@ -653,11 +655,10 @@ def main():
             for key, force_graph, red in (("shard125k_vi_1rank_rccl_ms", False, red1),
                                           ("shard125k_vi_1rank_rccl_graph_ms", True, red1),
                                           ("shard125k_vi_no_comm_ms", False, None),
-                                          # the order of round 4: every surrogate kernel in front of the data pass,
-                                          # one stream (SPMF_VI_OVERLAP=0); the default runs the scale hierarchy's
-                                          # draws / transform / prior half beside the column pass (vi.vi_step_dev)
-                                          ("shard125k_vi_single_stream_ms", False, None)):
-                os.environ["SPMF_VI_OVERLAP"] = "0" if "single_stream" in key else "1"
+                                          # SPMF_VI_OVERLAP=1 (off by default): the scale hierarchy's draws / transform /
+                                          # prior half on a side stream behind the row pass (vi.vi_step_dev)
+                                          ("shard125k_vi_hierarchy_on_side_stream_ms", False, None)):
+                os.environ["SPMF_VI_OVERLAP"] = "1" if "side_stream" in key else "0"
                 o_ = _vi.AdamHIP(model, sur.trainable_variables, 1e-3)
                 o_.init_state(3.0)
                 # default: what fit() runs (StepRunner replays a hipGraph for launch-bound batches and

@@ -68,6 +68,8 @@ struct spmf_ctx {
                                   // decoder at KP = 64, where the two-stream fused kernel (20 spilled registers
                                   // at four waves per SIMD) ran 13.9 ms against 12.8 for the two launches on C4
                                   // (profiles/r04_fused_rows_c4.txt).  SPMF_FUSE_ROWS=1 / 0 forces it on / off.
+  int dyn_rows = 1;               // the row pass hands the last eighth of its rows out dynamically (row_pass.hip);
+                                  // SPMF_ROW_DYNAMIC=0: the fixed stride everywhere
   int dense3 = 1;                 // exp sums on the bf16 matrix cores with three-way split operands
                                   // (dense3.hip; Poisson log_transform at KP = 64 only);
                                   // SPMF_DENSE_BF16X3=0 selects the exact-f32 MFMA kernels (dense.hip)
@@ -320,6 +322,7 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   if (const char* e = getenv("SPMF_DENSE_E_ONCE")) c->e_once = e[0] != '0';
   if (const char* e = getenv("SPMF_DENSE_BF16X3")) c->dense3 = e[0] != '0';
   if (const char* e = getenv("SPMF_FUSE_ROWS")) c->fuse_rows = e[0] != '0' ? 1 : 0;
+  if (const char* e = getenv("SPMF_ROW_DYNAMIC")) c->dyn_rows = e[0] != '0' ? 1 : 0;
   *out = c;
   return SPMF_OK;
 }
@@ -679,6 +682,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       RowArgs ra{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
           dacc, 0, 0, nullptr, nullptr, nbat, D, dacc_stride};
       ra.ent = ct->ent;
+      ra.dyn_tail = c->dyn_rows;
       if (det) {
         ra.det_slots = (double*)(c->det_buf + (size_t)s * det_draw);
         ra.det_stride = (int64_t)(det_draw / sizeof(double));
@@ -694,6 +698,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       RowArgs rf{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
           dacc, 3, logt, nullptr, c->ctype, 1, D, dacc_stride};
       rf.ent = ct->ent;
+      rf.dyn_tail = c->dyn_rows;
       launch_row_pass(KP, rf, st);
       if (tm) HIPCHK(c, hipEventRecord(c->ev[6], st));
       const float* lbias = logt == 3 ? c->dbias : c->phi;   // mixed: -1e30 masks the Poisson columns

@@ -50,6 +50,10 @@ struct RowArgs {
   // (kDaccHead + KP) doubles per draw, stride det_stride) instead of the fp64 atomics on dacc
   double* det_slots = nullptr;
   int64_t det_stride = 0;
+  // 1: the last eighth of every wave's rows is handed out by counters (the spare slot [5] of the kDaccRep replicas
+  // of `dacc`, zeroed by the caller with the rest of it) instead of by the fixed stride; only for the ONE
+  // full row launch of a step (modes 0 and 3), ignored in the deterministic mode
+  int dyn_tail = 0;
 };
 bool launch_row_pass(int KP, const RowArgs& a, hipStream_t st);   // false: a.dual asked for a form this shape lacks (nothing launched)
 

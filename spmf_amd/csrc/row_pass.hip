@@ -224,7 +224,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     const double* __restrict__ dprep, float* __restrict__ z, float* __restrict__ gzs,
     double* __restrict__ dacc, int mode, const float* __restrict__ gzd,
     const uint8_t* __restrict__ ctype, int Dcols, int64_t dacc_stride,
-    const uint32_t* __restrict__ ent, double* __restrict__ det_slots, int64_t det_stride) {
+    const uint32_t* __restrict__ ent, double* __restrict__ det_slots, int64_t det_stride, int dyn_tail) {
   if (gridDim.y > 1) {   // S draws per launch: tables, outputs and accumulators of draw blockIdx.y
     const size_t sd = blockIdx.y;
     Ap += sd * (size_t)Dcols * KP;
@@ -262,41 +262,90 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
   double ll_acc = 0.0, zsq_acc = 0.0, nnf_acc = 0.0;
   float4 zsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // Software pipeline across rows: the pointers of row b+2*nwaves and the first
-  // two 64-entry chunks of row b+nwaves are in flight while row b is processed,
+  // Which rows a wave takes.  Rows [0, B_static) are dealt out with a fixed stride (row w, w + nwaves, ...:
+  // every wave the same count); the LAST eighth of a wave's share is not fixed: rows [B_static, B) are handed
+  // out one at a time from sixteen counters (wave w draws from counter w % 16, which owns a sixteenth of that
+  // range), so a wave that fell behind -- longer rows, a slower corner of the chip -- takes fewer of them and
+  // the launch no longer ends with most waves waiting for the unluckiest one (the stored entries of a wave's
+  // fixed share scatter by sqrt(rows per wave): +6.7 % at the largest of 4096 waves on the 8-GPU shard of
+  // C3, +2.4 % on the whole matrix).  The counters are the spare fp64 slot [5] of the sixteen replicas of the
+  // scalar block (common.h: zeroed by the prep launch with everything else in it, never read as a sum).
+  // Off (B_static = B) in the deterministic mode -- which workgroup sums which rows must not depend on timing
+  // there -- and for launches that share a step's scalar block with another row launch (dyn_tail = 0).
+  int64_t B_static = B;
+  int64_t dyn_lo = B, dyn_hi = B;
+  unsigned int* dyn_ctr = nullptr;
+  if (dyn_tail && !det_slots && !encode_only) {
+    const int64_t per_wave = B / nwaves;
+    if (per_wave >= 8) {
+      B_static = (per_wave - per_wave / 8) * nwaves;
+      const int r = (int)(wave & (kDaccRep - 1));
+      const int64_t each = (B - B_static + kDaccRep - 1) / kDaccRep;
+      dyn_lo = B_static + r * each;
+      dyn_hi = dyn_lo + each < B ? dyn_lo + each : B;
+      if (dyn_lo > B) dyn_lo = B;
+      dyn_ctr = reinterpret_cast<unsigned int*>(dacc + (size_t)r * (kDaccHead + KP) + 5);
+    }
+  }
+  // the row after `cur` in this wave's sequence when it is a fixed one, else -1 (ask the counter)
+  auto fixed_next = [&](int64_t cur) -> int64_t {
+    if (cur >= B) return B;
+    if (cur + nwaves < B_static) return cur + nwaves;
+    return dyn_ctr ? (int64_t)-1 : B;
+  };
+  auto take_dynamic = [&]() -> int64_t {          // (wave-uniform; the wait for the atomic is here)
+    unsigned int k = 0;
+    if (lane == 0) k = atomicAdd(dyn_ctr, 1u);
+    k = (unsigned int)__builtin_amdgcn_readfirstlane((int)k);
+    const int64_t row = dyn_lo + (int64_t)k;
+    return row < dyn_hi ? row : B;
+  };
+
+  // Software pipeline across rows: the pointers of the row after next and the first
+  // two 64-entry chunks of the next row are in flight while a row is processed,
   // so the row_ptr -> col/val dependent latency is off the per-row critical path.
   int start = 0, end = 0, pc0 = 0, pc1 = 0, nstart = 0, nend = 0;
   float xi = 1.f, px0 = 0.f, px1 = 0.f, nxi = 1.f;
-  if (wave < B) {
-    start = row_ptr[wave];
-    end = row_ptr[wave + 1];
-    xi = row_scale ? row_scale[wave] : 1.f;
+  int64_t b = wave < B_static ? wave : B;
+  int64_t bn = fixed_next(b);
+  if (bn < 0) bn = take_dynamic();
+  int64_t bnn = fixed_next(bn);
+  if (bnn < 0) bnn = take_dynamic();
+  if (b < B) {
+    start = row_ptr[b];
+    end = row_ptr[b + 1];
+    xi = row_scale ? row_scale[b] : 1.f;
     const int f0 = min(end - start, 64);
     const int i0 = start + lane, i1 = start + f0 + lane;
     load_entry<PACKED, true>(col, val, ent, i0, lane < f0, pc0, px0);
     load_entry<PACKED, true>(col, val, ent, i1, i1 < end, pc1, px1);
   }
-  if (wave + nwaves < B) {
-    nstart = row_ptr[wave + nwaves];
-    nend = row_ptr[wave + nwaves + 1];
-    nxi = row_scale ? row_scale[wave + nwaves] : 1.f;
+  if (bn < B) {
+    nstart = row_ptr[bn];
+    nend = row_ptr[bn + 1];
+    nxi = row_scale ? row_scale[bn] : 1.f;
   }
-  for (int64_t b = wave; b < B; b += nwaves) {
+  while (b < B) {
     const int n = end - start;
     // prefetch: chunks of the next row, pointers of the one after
     int qc0 = 0, qc1 = 0, nnstart = 0, nnend = 0;
     float qx0 = 0.f, qx1 = 0.f, nnxi = 1.f;
-    if (b + nwaves < B) {
+    if (bn < B) {
       const int f0 = min(nend - nstart, 64);
       const int j0 = nstart + lane, j1 = nstart + f0 + lane;
       load_entry<PACKED, true>(col, val, ent, j0, lane < f0, qc0, qx0);
       load_entry<PACKED, true>(col, val, ent, j1, j1 < nend, qc1, qx1);
     }
-    if (b + 2 * nwaves < B) {
-      nnstart = row_ptr[b + 2 * nwaves];
-      nnend = row_ptr[b + 2 * nwaves + 1];
-      nnxi = row_scale ? row_scale[b + 2 * nwaves] : 1.f;
+    if (bnn < B) {
+      nnstart = row_ptr[bnn];
+      nnend = row_ptr[bnn + 1];
+      nnxi = row_scale ? row_scale[bnn] : 1.f;
     }
+    // the row three ahead: a fixed one, or a counter's next (asked for now, looked at when this row is done)
+    int64_t bnnn = fixed_next(bnn);
+    unsigned int dyn_k = 0;
+    const bool dyn_ask = bnnn < 0;                  // wave-uniform
+    if (dyn_ask && lane == 0) dyn_k = atomicAdd(dyn_ctr, 1u);
     float4 zacc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 gz = make_float4(0.f, 0.f, 0.f, 0.f);
     float llrow = 0.f;
@@ -367,9 +416,15 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     }
     // rotate the pipeline registers
     const float xi_cur = xi;
+    const int64_t b_cur = b;
     start = nstart; end = nend; xi = nxi;
     pc0 = qc0; px0 = qx0; pc1 = qc1; px1 = qx1;
     nstart = nnstart; nend = nnend; nxi = nnxi;
+    if (dyn_ask) {
+      const int64_t row = dyn_lo + (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)dyn_k);
+      bnnn = row < dyn_hi ? row : B;
+    }
+    b = bn; bn = bnn; bnn = bnnn;
     if (encode_only) continue;
     gz = across_groups_sum4<LPN>(gz);
     if (grp == 0) {
@@ -378,7 +433,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       // minus the derivative of sum_d r_bd over ALL columns: closed form veta
       // (linear decoder) or the dense exp term of this row (log_transform)
       // (mixed: closed-form Poisson-column part veta PLUS the dense Bernoulli-column term)
-      float4 dn = (mode == 2 && gzd) ? gather4<LPN>(gzd, (int)b, sub) : veta4;
+      float4 dn = (mode == 2 && gzd) ? gather4<LPN>(gzd, (int)b_cur, sub) : veta4;
       if (LIK == 3 && mode == 2 && gzd) dn = add4(dn, veta4);
       // mode 3 (both sweeps, dense row term subtracted LATER by the dense kernel's epilogue,
       // gzs_b -= xi_b * sum_d E_bd V'_d): only the closed-form Poisson-column part is known here
@@ -388,7 +443,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       o.y = xi_cur * (gz.y - dn.y - zacc.y);
       o.z = xi_cur * (gz.z - dn.z - zacc.z);
       o.w = xi_cur * (gz.w - dn.w - zacc.w);
-      reinterpret_cast<float4*>(gzs)[(size_t)b * LPN + sub] = o;
+      reinterpret_cast<float4*>(gzs)[(size_t)b_cur * LPN + sub] = o;
     }
     ll_acc += (double)llrow;
   }
@@ -484,7 +539,7 @@ static bool launch_row_lds_t(const RowArgs& a, hipStream_t st) {
   const int nb = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   hipLaunchKernelGGL((row_pass_kernel<KP, LIK, BT, PACKED>), dim3(nb, a.S > 1 ? a.S : 1), dim3(BT), lds, st,
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z,
-                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent, a.det_slots, a.det_stride);
+                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent, a.det_slots, a.det_stride, a.dyn_tail);
   return true;
 }
 
@@ -538,7 +593,7 @@ static bool launch_row_t(const RowArgs& a, hipStream_t st) {
 #define SPMF_ROW_LAUNCH(L_)                                                                    \
   hipLaunchKernelGGL((row_pass_kernel<KP, L_>), dim3(nb, a.S > 1 ? a.S : 1), dim3(256), 0, st, \
                      a.B, a.row_ptr, a.col, a.val, a.row_scale, a.Ap, a.Vp, a.phi, a.dprep, a.z, \
-                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent, a.det_slots, a.det_stride)
+                     a.gzs, a.dacc, a.mode, a.gzd, a.ctype, a.D, a.dacc_stride, a.ent, a.det_slots, a.det_stride, a.dyn_tail)
   if (a.logt == 4) SPMF_ROW_LAUNCH(4);
   else if (a.logt == 3) SPMF_ROW_LAUNCH(3);
   else if (a.logt == 2) SPMF_ROW_LAUNCH(2);

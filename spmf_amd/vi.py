@@ -388,11 +388,14 @@ class _StepReducer:
 
 
 def _hierarchy_beside_the_column_pass(model, sur):
-    """The side stream + the "rows done" event of the model when the VI step may split its surrogate work
-    (vi_step_dev), else None: models with the scale hierarchy (horshoe_plus=True) on the HIP energy path;
-    SPMF_VI_OVERLAP=0 switches it off (one stream, the order of round 4)."""
+    """The side stream + the "rows done" event of the model when the VI step is asked to split its surrogate
+    work (vi_step_dev), else None: models with the scale hierarchy (horshoe_plus=True) on the HIP energy path,
+    and only with SPMF_VI_OVERLAP=1.  OFF by default: on ONE GPU the split measured 2 % SLOWER than the
+    single-stream order (the 122 880-row shard of C3: 0.509 against 0.499 ms per VI step, round 5 -- the
+    side stream's kernels did not run beside the column pass, they took turns with it); what it is for is the
+    row-sharded step, where the collective leaves the chip idle, and that has never been timed."""
     import os
-    if os.environ.get("SPMF_VI_OVERLAP", "1") == "0" or getattr(model, "_custom_codec", None) is not None:
+    if os.environ.get("SPMF_VI_OVERLAP", "0") != "1" or getattr(model, "_custom_codec", None) is not None:
         return None
     if not any(sur.kinds[n] == "invgamma" for n in sur.var_order) or getattr(model, "column_split", 0):
         return None

@@ -616,7 +616,7 @@ def test_vi_step_with_the_hierarchy_beside_the_column_pass_equals_the_single_str
     variables of the scale hierarchy and runs the prior half of the finish on a side stream that starts when
     the row pass is done (spmf_ctx_set_rows_event).  Same draws (the sampler's counter does not depend on which
     call covers a variable), same kernels: in the deterministic mode the trainables after a few steps are the
-    same BITS as with SPMF_VI_OVERLAP=0 (one stream, the order of round 4), eager and replayed from a hipGraph
+    same BITS as without the split (the default: one stream), eager and replayed from a hipGraph
     that holds the fork and the join; the loss agrees to the last digits (log q is added up in two pieces)."""
     from spmf_amd import PoissonFactorization, SparseCounts
     from spmf_amd.vi import AdamHIP, StepRunner
