@@ -36,6 +36,11 @@ namespace spmf {
 #ifndef ROW_MAX_BLOCKS
 #define ROW_MAX_BLOCKS 4096
 #endif
+// share of a wave's rows that the counters hand out (the dynamic tail of the row loop, below)
+#ifndef ROW_DYN_NUM
+#define ROW_DYN_NUM 1
+#define ROW_DYN_DEN 8
+#endif
 static_assert(ROW_MAX_BLOCKS <= spmf::kDetMaxBlocks,
               "the deterministic mode's per-workgroup slots (common.h kDetMaxBlocks) are sized for at most that many row-pass workgroups");
 #ifndef ROW_GRP
@@ -278,7 +283,9 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
   if (dyn_tail && !det_slots && !encode_only) {
     const int64_t per_wave = B / nwaves;
     if (per_wave >= 8) {
-      B_static = (per_wave - per_wave / 8) * nwaves;
+      int64_t fixed = per_wave - (per_wave * ROW_DYN_NUM) / ROW_DYN_DEN;
+      if (fixed < 2) fixed = 2;
+      B_static = fixed * nwaves;
       const int r = (int)(wave & (kDaccRep - 1));
       const int64_t each = (B - B_static + kDaccRep - 1) / kDaccRep;
       dyn_lo = B_static + r * each;
