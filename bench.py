@@ -381,6 +381,74 @@ def ref_harness_extra(dev, steps=100, warmup=10):
     return out
 
 
+def _pick_collective(model, lib_comm, dev, world, rank, S, want, all_reduce_):
+    """-> (comm, transport string, record).  See the call site.  all_reduce_(tensor, op): torch.distributed's
+    all-reduce of a device tensor (host-staged under gloo: the one-GPU rehearsal)."""
+    import torch
+    import torch.distributed as dist
+    from spmf_amd import _lib
+    from spmf_amd.dist import PeerComm
+    lib, h = _lib.load(), model._handle()
+    n = int(lib.spmf_acc_len(h, S))
+    rec = {}
+    transport_lib = "library RCCL communicator (spmf_allreduce on the step's stream)"
+
+    def all_ok(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        all_reduce_(t, dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def check_and_time(comm, reps=20):
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        x = torch.randn(n, device=dev, generator=g)
+        ref = x.clone()
+        all_reduce_(ref, dist.ReduceOp.SUM)
+        y = x.clone()
+        comm.all_reduce_(y)
+        torch.cuda.synchronize()
+        good = bool(torch.isfinite(y).all()) and float((y - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        if not all_ok(good):
+            return False, None
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            comm.all_reduce_(y)
+        torch.cuda.synchronize()
+        us = torch.tensor([1e6 * (time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        all_reduce_(us, dist.ReduceOp.MAX)
+        return True, float(us.item())
+
+    peer = None
+    try:
+        peer = PeerComm(model, max_draws=S)              # (collective inside; a local failure is agreed on)
+    except Exception as e:
+        rec["allreduce_p2p_error"] = str(e)[:160]
+    if not all_ok(peer is not None):
+        if peer is not None:
+            peer.close()
+        rec.setdefault("allreduce_p2p_error", "unavailable on another rank")
+        return lib_comm, transport_lib if lib_comm is not None else "torch.distributed", rec
+    ok_p, us_p = check_and_time(peer)
+    done, gave_up = peer.status()
+    ok_p = all_ok(ok_p and gave_up == 0)
+    rec["allreduce_p2p_ok"], rec["allreduce_p2p_us"] = ok_p, us_p
+    us_l = None
+    if lib_comm is not None:
+        peer.enable(False)
+        ok_l, us_l = check_and_time(lib_comm)
+        rec["allreduce_rccl_ok"], rec["allreduce_rccl_us"] = ok_l, us_l
+        peer.enable(True)
+    use_p2p = ok_p and (want == "p2p" or us_l is None or us_p <= us_l)
+    rec["allreduce_floats"] = n
+    if use_p2p:
+        return peer, ("library peer-pointer kernel (csrc/p2p.hip: direct reduce-scatter + all-gather over xGMI, "
+                      "spmf_allreduce on the step's stream)"), rec
+    peer.enable(False)
+    return lib_comm, (transport_lib if lib_comm is not None else "torch.distributed"), rec
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries below this script print there too
     # (RCCL writes a version banner from C when a communicator is created), so file
@@ -525,6 +593,7 @@ def main():
 
     hook = None
     transport = None
+    comm_pick = {}
     if distributed:
         from spmf_amd.dist import LibraryComm, ShardReducer
         # transport of the step's one collective: the library's own RCCL communicator
@@ -533,13 +602,22 @@ def main():
         # SPMF_BENCH_COMM=torch selects torch.distributed's; the gloo rehearsal always uses it.
         comm = None
         transport = f"torch.distributed ({backend})"
-        if os.environ.get("SPMF_BENCH_COMM", "lib") != "torch" and backend == "nccl":
+        comm_pick = {}
+        want = os.environ.get("SPMF_BENCH_COMM", "auto")       # auto | p2p | lib | torch
+        if want != "torch" and backend == "nccl":
             try:
                 comm = LibraryComm(model)
                 transport = "library RCCL communicator (spmf_allreduce on the step's stream)"
             except Exception as e:        # librccl not loadable from the library: every rank lands here alike
                 print(f"LibraryComm unavailable ({e}); torch.distributed moves the accumulators", file=sys.stderr)
                 comm = None
+        # The library's own kernel over peer pointers (csrc/p2p.hip: direct reduce-scatter + all-gather,
+        # every pair of ranks on its own xGMI link) against RCCL, ON THIS NODE: both are checked against
+        # torch.distributed's all-reduce of the same buffer and timed back to back on the real payload; the
+        # faster one that passed carries the step.  Every decision is agreed over all ranks first.
+        # (gloo rehearsal on one GPU: only with SPMF_BENCH_COMM=p2p -- the ranks are processes on one card)
+        if world > 1 and ((want in ("auto", "p2p") and backend == "nccl") or want == "p2p"):
+            comm, transport, comm_pick = _pick_collective(model, comm, dev, world, rank, S, want, all_reduce_)
         hook = ShardReducer(comm=comm)
         hook.set_batch_totals(rows_g, lgam_g)
 
@@ -915,6 +993,7 @@ def main():
                                  "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic},
             "roofline_l2": roof_l2,
             "vi_step_ms": vi_ms,
+            "collective": (comm_pick if distributed else None),
             "also": extras,
             "n_nonfinite": float(nnf.sum()),
             "saturated": sat0,

@@ -409,12 +409,15 @@ int spmf_comm_destroy(spmf_ctx* ctx);
  *   [ the host exchanges the handles: the Python mirror uses a torch.distributed all_gather ]
  *   spmf_p2p_connect  handles = world x 64 bytes in rank order; opens the peers' regions
  *   spmf_allreduce    then runs this kernel instead of ncclAllReduce (n <= n_max, buf 16-byte aligned)
+ *   spmf_p2p_enable   a context may hold both transports (bench.py times them against each other): which one
+ *                     spmf_allreduce uses; spmf_p2p_connect leaves the kernel selected
  *   spmf_p2p_status   SYNCHRONISES; out3 = {calls completed, 0, first call in which a workgroup gave up
  *                     waiting for a peer (0 = none)}: every spin is bounded, a lost peer cannot hang the GPU
  *   spmf_p2p_destroy  unmaps and frees (also done by spmf_ctx_destroy)
  * All ranks must call spmf_allreduce with the same n, the same number of times. */
 int spmf_p2p_init(spmf_ctx* ctx, int rank, int world, int64_t n_max, int nchunk, void* handle_out64);
 int spmf_p2p_connect(spmf_ctx* ctx, const void* handles);
+int spmf_p2p_enable(spmf_ctx* ctx, int on);   /* 0: spmf_allreduce goes back to RCCL (if spmf_comm_init was called); 1: the kernel again */
 int spmf_p2p_status(spmf_ctx* ctx, uint64_t out3[3]);
 int spmf_p2p_destroy(spmf_ctx* ctx);
 

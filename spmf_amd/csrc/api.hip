@@ -1278,6 +1278,14 @@ int spmf_p2p_connect(spmf_ctx* c, const void* handles) {
   return SPMF_OK;
 }
 
+int spmf_p2p_enable(spmf_ctx* c, int on) {
+  if (!c) return SPMF_E_ARG;
+  if (on && (!c->p2p.region || !c->p2p.peer[c->p2p.world > 0 ? c->p2p.world - 1 : 0]))
+    return fail(c, SPMF_E_ARG, "p2p_enable: spmf_p2p_connect has not connected the peers");
+  c->p2p.connected = on ? 1 : 0;
+  return SPMF_OK;
+}
+
 int spmf_p2p_status(spmf_ctx* c, uint64_t out3[3]) {
   if (!c || !out3) return SPMF_E_ARG;
   if (!c->p2p.region) return fail(c, SPMF_E_ARG, "p2p_status: spmf_p2p_init was not called");

@@ -121,7 +121,25 @@ class PeerComm:
             n_max = int(lib.spmf_acc_len(h, int(max_draws)))
         n_max = max(int(n_max), 4 * int(world))
         hnd = (C.c_char * 64)()
-        _lib.check(h, lib.spmf_p2p_init(h, int(rank), int(world), n_max, int(nchunk), hnd), "spmf_p2p_init")
+
+        def agree(rc, what):
+            """Every rank learns whether ANY rank failed a local step, before the next collective: a rank
+            that raised alone would leave the others waiting in it."""
+            bad = 1 if rc != 0 else 0
+            msg = lib.spmf_last_error(h).decode() if rc != 0 else ""
+            if world > 1:
+                t = torch.tensor([bad], dtype=torch.int32)
+                if dist.get_backend(group) == "nccl":
+                    t = t.to(model.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                bad_any = int(t.item())
+            else:
+                bad_any = bad
+            if bad_any:
+                lib.spmf_p2p_destroy(h)
+                raise _lib.SpmfError(f"PeerComm: {what} failed on " +
+                                     (f"this rank (rc={rc}): {msg}" if bad else "another rank"))
+        agree(lib.spmf_p2p_init(h, int(rank), int(world), n_max, int(nchunk), hnd), "spmf_p2p_init")
         mine = torch.frombuffer(bytearray(hnd.raw), dtype=torch.uint8).clone()
         if world > 1:
             if dist.get_backend(group) == "nccl":
@@ -132,7 +150,7 @@ class PeerComm:
         else:
             blob = bytes(mine.numpy().tobytes())
         raw = (C.c_char * (64 * world)).from_buffer_copy(blob)
-        _lib.check(h, lib.spmf_p2p_connect(h, raw), "spmf_p2p_connect")
+        agree(lib.spmf_p2p_connect(h, raw), "spmf_p2p_connect")
         if world > 1:
             dist.barrier(group=group)      # every rank has mapped every region before the first push
         self.rank, self.world, self.n_max = int(rank), int(world), n_max
@@ -145,6 +163,13 @@ class PeerComm:
         lib, h = _lib.load(), self.model._handle()
         stream = torch.cuda.current_stream(t.device).cuda_stream
         _lib.check(h, lib.spmf_allreduce(h, t.data_ptr(), t.numel(), stream), "spmf_allreduce")
+
+    def enable(self, on=True):
+        """Which transport spmf_allreduce uses on this model's context when it also holds an RCCL
+        communicator (LibraryComm): this kernel (True) or RCCL (False)."""
+        from . import _lib
+        lib, h = _lib.load(), self.model._handle()
+        _lib.check(h, lib.spmf_p2p_enable(h, 1 if on else 0), "spmf_p2p_enable")
 
     def status(self):
         """(calls completed, first call in which a workgroup gave up waiting for a peer or 0).
