@@ -317,7 +317,7 @@ def c1_gpu_extra(dev, steps=200, warmup=10):
         model = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1.0 / (N * D) ** 0.5, device=dev)
         model.compute_scales(lambda: [{"counts": x}])
     from spmf_amd.sparse import SparseCounts, balanced_panel_rows
-    batch = {"counts": SparseCounts.from_any(x, dev, balanced_panel_rows(N, K))}     # resident, as every workload here
+    batch = {"counts": SparseCounts.from_any(x, dev, balanced_panel_rows(N, K), latent_dim=K)}   # resident, as every workload here
     torch.manual_seed(20241218)
     params = model.surrogate_distribution.sample(1)
     ms, t6, parts, nnf = _timed_steps(model, batch, params, steps, warmup)

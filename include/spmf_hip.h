@@ -303,6 +303,18 @@ int spmf_layout_build(int device, int64_t n_rows, int64_t nnz, int32_t n_cols,
                       int32_t panel_rows, int32_t col_split, void* layout, size_t layout_bytes,
                       void* scratch, size_t scratch_bytes, spmf_counts* out,
                       spmf_layout_info* info, void* stream);
+/* The same with the model's latent dimension as a hint (ABI 6; 0 = unknown = the two calls above): a work item
+ * is one lane group of the column pass, K padded / 4 lanes, so at K <= 8 a wave carries 32 or 64 items and the
+ * lists are cut into proportionally more, shorter items (16 384 / 32 768 per panel instead of 4096) -- the
+ * reference CLI's default K = 2 ran its column pass on a few dozen waves otherwise.  Sizes and build must get
+ * the same hint. */
+int spmf_layout_sizes_k(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, int32_t panel_rows,
+                        int32_t latent_dim, size_t* layout_bytes, size_t* scratch_bytes);
+int spmf_layout_build_k(int device, int64_t n_rows, int64_t nnz, int32_t n_cols,
+                        const int32_t* row_ptr, const int32_t* col_idx, const float* val,
+                        int32_t panel_rows, int32_t col_split, int32_t latent_dim, void* layout,
+                        size_t layout_bytes, void* scratch, size_t scratch_bytes, spmf_counts* out,
+                        spmf_layout_info* info, void* stream);
 /* Message of the last failed spmf_layout_* call of the calling thread (host string). */
 const char* spmf_layout_last_error(void);
 

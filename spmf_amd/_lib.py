@@ -109,6 +109,12 @@ SIGNATURES = {
                                     C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_size_t, C.POINTER(CountsStruct),
                                     C.POINTER(LayoutInfo), C.c_void_p]),
+    "spmf_layout_sizes_k": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "spmf_layout_build_k": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_size_t, C.POINTER(CountsStruct),
+                                      C.POINTER(LayoutInfo), C.c_void_p]),
     "spmf_layout_last_error": (C.c_char_p, []),
     "spmf_dense_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "spmf_dense_row_ptr": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,

@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256, EPL == 4 ? COL_WIDE_WAVES : 1) void col_pass_k
   }
   constexpr int LPN = KP / 4;
   constexpr int NG = 64 / LPN;                        // items per wave
-  constexpr int GRP = LPN < COL_GRP ? LPN : COL_GRP;  // entries gathered back to back
+  // entries gathered back to back: COL_GRP of the 4 * LPN a wide fetch holds (also at K <= 8, where a lane group
+  // is one or two lanes and used to keep ONE or two entries in flight); the narrow fetch holds LPN
+  constexpr int GRP = EPL == 4 ? COL_GRP : (LPN < COL_GRP ? LPN : COL_GRP);
+  static_assert((EPL * LPN) % GRP == 0, "a fetch is a whole number of gather groups");
   __shared__ __attribute__((aligned(16))) float stage[4][NG][2 * KP];
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPN, grp = lane / LPN;

@@ -83,7 +83,11 @@ int bits_for(uint64_t n) {         // bits needed for keys in [0, n)
   return b;
 }
 
-int make_geo(int64_t B, int64_t nnz, int D, int P, Geo* g) {
+// khint: the latent dimension of the model the layout is for (0 = unknown).  A work item is one lane GROUP of the
+// column pass, KP / 4 lanes (KP = K padded to 4, 8, ...): at K <= 8 a wave carries 64 or 32 items, so "a few
+// thousand items per panel" is a few dozen waves -- C1 (5000 x 200 dense, K = 2) ran its column pass on 39
+// waves with one gather in flight per lane.  Small K asks for proportionally more, shorter items.
+int make_geo(int64_t B, int64_t nnz, int D, int P, int khint, Geo* g) {
   if (B < 0 || nnz < 0 || D < 1 || P < 1) return lfail(SPMF_E_ARG, "layout: n_rows, nnz >= 0, n_cols, panel_rows >= 1");
   if (nnz >= (int64_t(1) << 31)) return lfail(SPMF_E_UNSUPPORTED, "layout: nnz per shard must fit int32");
   if (B >= (int64_t(1) << 31)) return lfail(SPMF_E_UNSUPPORTED, "layout: n_rows per shard must fit int32");
@@ -98,8 +102,9 @@ int make_geo(int64_t B, int64_t nnz, int D, int P, Geo* g) {
       "layout: n_panels * n_cols must stay below 2^32 (choose larger panels)");
   // segment length: a panel should offer a few thousand items (spmf_amd/sparse.py _build_items)
   const double per_panel = (double)nnz / (double)(g->nP > 0 ? g->nP : 1);
+  const double want_items = khint >= 1 && khint <= 4 ? 32768.0 : (khint >= 5 && khint <= 8 ? 16384.0 : 4096.0);
   int seg = 16;
-  while (seg < kSegMax && per_panel / seg > 4096.0) seg *= 2;
+  while (seg < kSegMax && per_panel / seg > want_items) seg *= 2;
   g->seg = seg;
   const int64_t lists = nnz < g->nkeys ? nnz : g->nkeys;
   g->max_items = lists + nnz / seg + 1;
@@ -641,9 +646,15 @@ const char* spmf_layout_last_error(void) { return layout_last_error(); }
 
 int spmf_layout_sizes(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, int32_t panel_rows,
                       size_t* layout_bytes, size_t* scratch_bytes) {
+  return spmf_layout_sizes_k(device, n_rows, nnz, n_cols, panel_rows, 0, layout_bytes, scratch_bytes);
+}
+
+int spmf_layout_sizes_k(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, int32_t panel_rows,
+                        int32_t latent_dim, size_t* layout_bytes, size_t* scratch_bytes) {
   if (!layout_bytes || !scratch_bytes) return lfail(SPMF_E_ARG, "layout_sizes: null output");
+  if (latent_dim < 0) return lfail(SPMF_E_ARG, "layout_sizes: latent_dim >= 0 (0 = unknown)");
   Geo g;
-  int rc = make_geo(n_rows, nnz, n_cols, panel_rows, &g);
+  int rc = make_geo(n_rows, nnz, n_cols, panel_rows, latent_dim, &g);
   if (rc) return rc;
   *layout_bytes = carve_layout(g).total;
   DeviceScope dev_scope(device);
@@ -659,7 +670,16 @@ int spmf_layout_build(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, c
                       const int32_t* col_idx, const float* val, int32_t panel_rows, int32_t col_split,
                       void* layout, size_t layout_bytes, void* scratch, size_t scratch_bytes, spmf_counts* out,
                       spmf_layout_info* info, void* stream) {
+  return spmf_layout_build_k(device, n_rows, nnz, n_cols, row_ptr, col_idx, val, panel_rows, col_split, 0, layout,
+                             layout_bytes, scratch, scratch_bytes, out, info, stream);
+}
+
+int spmf_layout_build_k(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, const int32_t* row_ptr,
+                        const int32_t* col_idx, const float* val, int32_t panel_rows, int32_t col_split,
+                        int32_t latent_dim, void* layout, size_t layout_bytes, void* scratch, size_t scratch_bytes,
+                        spmf_counts* out, spmf_layout_info* info, void* stream) {
   if (!out || !info || !layout || !scratch || !row_ptr) return lfail(SPMF_E_ARG, "layout_build: null argument");
+  if (latent_dim < 0) return lfail(SPMF_E_ARG, "layout_build: latent_dim >= 0 (0 = unknown)");
   if (info->struct_size != (int32_t)sizeof(spmf_layout_info))
     return lfail(SPMF_E_ARG, "layout_build: spmf_layout_info.struct_size differs: built against another spmf_hip.h");
   if (nnz > 0 && (!col_idx || !val)) return lfail(SPMF_E_ARG, "layout_build: col_idx / val missing");
@@ -667,7 +687,7 @@ int spmf_layout_build(int device, int64_t n_rows, int64_t nnz, int32_t n_cols, c
   if (((uintptr_t)layout | (uintptr_t)scratch) & 255)
     return lfail(SPMF_E_ARG, "layout_build: buffers must be 256-byte aligned");
   Geo g;
-  int rc = make_geo(n_rows, nnz, n_cols, panel_rows, &g);
+  int rc = make_geo(n_rows, nnz, n_cols, panel_rows, latent_dim, &g);
   if (rc) return rc;
   DeviceScope dev_scope(device);
   LCHK(dev_scope.err);

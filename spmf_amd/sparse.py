@@ -111,6 +111,9 @@ class SparseCounts:
         # multi-GPU overlap: work items of a panel sorted by column half first
         # (columns < col_split, then the rest); 0 = no split
         self.col_split = int(col_split)
+        # the model's latent dimension when the caller knows it: small K asks for more, shorter work items
+        # (include/spmf_hip.h spmf_layout_build_k); 0 = unknown
+        self.latent_dim_hint = int(latent_dim) if latent_dim else 0
         # the lists, the work items and the packed streams: the library's builder on the HIP
         # device (csrc/layout.hip), the torch operators below for host-side tensors (CPU tests)
         # or when SPMF_NATIVE_LAYOUT=0 asks for them (tests/test_gpu_layout.py compares the two)
@@ -212,18 +215,18 @@ class SparseCounts:
         def ok(rc, what):
             _layout_check(lib, rc, what)
 
-        ok(lib.spmf_layout_sizes(idx, self.n_rows, self.nnz, self.n_cols, self.panel_rows,
-                                 C.byref(lb), C.byref(sb)), "spmf_layout_sizes")
+        ok(lib.spmf_layout_sizes_k(idx, self.n_rows, self.nnz, self.n_cols, self.panel_rows, self.latent_dim_hint,
+                                   C.byref(lb), C.byref(sb)), "spmf_layout_sizes_k")
         with torch.cuda.device(idx):
             layout = torch.empty(max(lb.value, 256), dtype=torch.uint8, device=dev)
             scratch = torch.empty(max(sb.value, 256), dtype=torch.uint8, device=dev)
             cs, info = _lib.CountsStruct(), _lib.LayoutInfo()
             info.struct_size = C.sizeof(_lib.LayoutInfo)
-            ok(lib.spmf_layout_build(idx, self.n_rows, self.nnz, self.n_cols, self.row_ptr.data_ptr(),
-                                     self.col_idx.data_ptr(), self.val.data_ptr(), self.panel_rows,
-                                     self.col_split, layout.data_ptr(), layout.numel(),
-                                     scratch.data_ptr(), scratch.numel(), C.byref(cs), C.byref(info),
-                                     torch.cuda.current_stream(dev).cuda_stream), "spmf_layout_build")
+            ok(lib.spmf_layout_build_k(idx, self.n_rows, self.nnz, self.n_cols, self.row_ptr.data_ptr(),
+                                       self.col_idx.data_ptr(), self.val.data_ptr(), self.panel_rows,
+                                       self.col_split, self.latent_dim_hint, layout.data_ptr(), layout.numel(),
+                                       scratch.data_ptr(), scratch.numel(), C.byref(cs), C.byref(info),
+                                       torch.cuda.current_stream(dev).cuda_stream), "spmf_layout_build_k")
         del scratch
         base = layout.data_ptr()
 
@@ -306,7 +309,9 @@ class SparseCounts:
             # batches (few, long column lists) are otherwise a handful of serial
             # 256-entry walks -- 128 us of latency for a 1000 x 30 batch
             seg, per_panel = 16, self.nnz / max(1, nP)
-            while seg < SEGMENT_ENTRIES and per_panel / seg > 4096:
+            k = getattr(self, "latent_dim_hint", 0)        # csrc/layout.hip make_geo: the same rule
+            want = 32768 if 1 <= k <= 4 else (16384 if 5 <= k <= 8 else 4096)
+            while seg < SEGMENT_ENTRIES and per_panel / seg > want:
                 seg *= 2
             seg = min(seg, SEGMENT_ENTRIES)
         seg = int(seg)

@@ -113,6 +113,9 @@ for args in ((10, 5, 0, 4), (10, -1, 7, 4), (-1, 5, 7, 4), (10, 5, 7, 0)):
 assert lib.spmf_layout_sizes(0, 10, 2 ** 31, 7, 4, C.byref(lb), C.byref(sb)) == -4
 assert lib.spmf_layout_sizes(0, 2 ** 31, 5, 7, 4, C.byref(lb), C.byref(sb)) == -4
 assert lib.spmf_layout_sizes(0, 10, 5, 7, 4, None, None) == -1
+assert lib.spmf_layout_sizes_k(0, 10, 5, 7, 4, -1, C.byref(lb), C.byref(sb)) == -1            # negative latent_dim hint
+assert lib.spmf_layout_build_k(0, 10, 5, 7, 4096, 4096, 4096, 4, 0, -3, 4096, 1 << 20, 4096, 1 << 20,
+                               C.byref(_lib.CountsStruct()), C.byref(_lib.LayoutInfo()), None) == -1
 cs0, info = _lib.CountsStruct(), _lib.LayoutInfo()
 assert lib.spmf_layout_build(0, 10, 5, 7, 4096, 4096, 4096, 4, 0, 4096, 1 << 20, 4096, 1 << 20,
                              C.byref(cs0), C.byref(info), None) == -1 and b"struct_size" in lib.spmf_layout_last_error()

@@ -41,14 +41,14 @@ def _csr(rows, D, density, seed, values="counts", unsorted=False, empty_rows=Fal
     return np.asarray(ptr, np.int64), col, val.astype(np.float32)
 
 
-def _build(ptr, col, val, rows, D, P, split, native):
+def _build(ptr, col, val, rows, D, P, split, native, latent_dim=None):
     from spmf_amd.sparse import SparseCounts
     dev = torch.device("cuda", 0)
     old = os.environ.get("SPMF_NATIVE_LAYOUT")
     os.environ["SPMF_NATIVE_LAYOUT"] = "1" if native else "0"
     try:
         return SparseCounts(torch.as_tensor(ptr).to(dev), torch.as_tensor(col).to(dev),
-                            torch.as_tensor(val).to(dev), rows, D, P, col_split=split)
+                            torch.as_tensor(val).to(dev), rows, D, P, col_split=split, latent_dim=latent_dim)
     finally:
         if old is None:
             del os.environ["SPMF_NATIVE_LAYOUT"]
@@ -105,6 +105,37 @@ def test_native_layout_equals_the_torch_construction(case):
     a = _build(ptr, col, val, rows, D, P, split, native=True)
     b = _build(ptr, col, val, rows, D, P, split, native=False)
     _same(a, b, what)
+
+
+@pytest.mark.parametrize("K,finer", [(2, True), (7, True), (16, False)])
+def test_latent_dim_hint_cuts_finer_items_for_small_k_and_both_builders_agree(K, finer):
+    """spmf_layout_build_k: a work item is one lane group of the column pass (K padded / 4 lanes), so at K <= 8 the
+    lists are cut for 16 384 / 32 768 items per panel instead of 4096 (the reference CLI's default K = 2 on a dense
+    5000 x 200 batch had 2.5k one-lane items = 39 waves).  Native == torch with the hint; the energy does not
+    depend on the cut (a C1-shaped batch against the unhinted layout)."""
+    rows, D = 5000, 200
+    rng = np.random.default_rng(5)
+    X = rng.poisson(1.0, size=(rows, D)).astype(np.float32)
+    mask = X != 0
+    ptr = np.concatenate([[0], np.cumsum(mask.sum(1))]).astype(np.int64)
+    col = np.nonzero(mask)[1].astype(np.int64)
+    val = X[mask]
+    a = _build(ptr, col, val, rows, D, rows, 0, native=True, latent_dim=K)
+    b = _build(ptr, col, val, rows, D, rows, 0, native=False, latent_dim=K)
+    _same(a, b, f"hint K={K}")
+    plain = _build(ptr, col, val, rows, D, rows, 0, native=True)
+    assert (a.segment < plain.segment) == finer and (a.items.shape[0] > plain.items.shape[0]) == finer
+    if K == 2:
+        from spmf_amd import PoissonFactorization
+        m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1e-3, device="cuda")
+        torch.manual_seed(1)
+        params = m.surrogate_distribution.sample(1)
+        pa, ga, _ = m.energy_and_grads({"counts": a}, params)
+        pb, gb, _ = m.energy_and_grads({"counts": plain}, params)
+        for k in pa:
+            assert abs(float(pa[k][0]) - float(pb[k][0])) <= 1e-9 * max(1.0, abs(float(pb[k][0]))), k
+        for k in ga:
+            assert float((ga[k] - gb[k]).abs().max()) <= 1e-5 * float(gb[k].abs().max()), k
 
 
 def test_panels_of_more_than_65536_rows_and_an_empty_shard():
