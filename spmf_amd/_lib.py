@@ -157,6 +157,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "spmf_sample_noise": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int, C.c_uint64,
                                     C.c_uint64, C.c_void_p, C.c_void_p]),
+    "spmf_sample_transform": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int, C.c_uint64,
+                                        C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spmf_surrogate_bwd": (C.c_int, [C.c_void_p, C.POINTER(SurVar), C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_void_p]),
     "spmf_ctx_set_column_split": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1395,6 +1395,54 @@ int spmf_nonfinite_patch(spmf_ctx* c, const spmf_counts* ct, int S, const float*
   return SPMF_OK;
 }
 
+// the library's one device allocation, at its first use (never inside a stream capture: a step is run eagerly
+// before it is captured); zero-filled: its last word is the arrival ticket of sample_fwd_kernel.  Without it the
+// surrogate kernels fall back (atomics / two launches).
+static void ensure_scratch(spmf_ctx* c, hipStream_t st) {
+  if (c->scratch) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  if (cap != hipStreamCaptureStatusNone) return;
+  if (hipMalloc((void**)&c->scratch, spmf_ctx::kScratchDoubles * sizeof(double)) != hipSuccess ||
+      hipMemset(c->scratch, 0, spmf_ctx::kScratchDoubles * sizeof(double)) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {
+    if (c->scratch) (void)hipFree(c->scratch);
+    c->scratch = nullptr;
+    (void)hipGetLastError();
+  }
+}
+
+int spmf_sample_transform(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, uint64_t seed, uint64_t counter,
+    const double* state, double* logq, void* stream) {
+  if (!c || !vars || nvars < 1 || nvars > 12 || S < 1 || S > 65535 || !logq) return fail(c, SPMF_E_ARG,
+      "sample_transform: bad arguments");
+  SurTable T;
+  int max_n = 0;
+  for (int i = 0; i < nvars; ++i) {
+    const spmf_sur_var& v = vars[i];
+    if (v.n == 0) {
+      T.v[i] = SurVar{};
+      continue;
+    }
+    if (!v.t0 || !v.t1 || !v.noise || !v.theta || v.n < 1 || v.kind < 0 || v.kind > 2 || (v.kind == 2 && !v.dgda))
+      return fail(c, SPMF_E_ARG, "sample_transform: bad variable (t0 / t1 / noise / dgda / theta buffers)");
+    if (v.noise_ld != 0 && v.noise_ld < v.n) return fail(c, SPMF_E_ARG, "surrogate: noise_ld < n");
+    T.v[i] = SurVar{v.t0, v.t1, v.noise, v.dgda, v.theta, v.gtheta, v.g0, v.g1, v.n, v.kind, v.ident,
+        v.noise_ld ? v.noise_ld : (int64_t)v.n};
+    if (v.n > max_n) max_n = v.n;
+  }
+  if (max_n < 1) return fail(c, SPMF_E_ARG, "sample_transform: every variable is skipped (n = 0)");
+  hipStream_t st = (hipStream_t)stream;
+  ensure_scratch(c, st);
+  if (!launch_sample_fwd(T, nvars, max_n, S, seed, counter, state, logq, c->scratch, spmf_ctx::kScratchDoubles, st)) {
+    // no scratch for the per-block sums: the two separate launches (same numbers)
+    launch_sample_noise(T, nvars, max_n, S, seed, counter, state, st);
+    launch_surrogate_fwd(T, nvars, max_n, S, logq, c->scratch, spmf_ctx::kScratchDoubles, st);
+  }
+  HIPCHK(c, hipGetLastError());
+  return SPMF_OK;
+}
+
 int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, double* logq, void* stream) {
   if (!c || !vars || nvars < 1 || nvars > 12 || S < 1 || !logq) return fail(c, SPMF_E_ARG,
       "surrogate_fwd: bad arguments");
@@ -1415,17 +1463,7 @@ int spmf_surrogate_fwd(spmf_ctx* c, const spmf_sur_var* vars, int nvars, int S, 
   }
   if (max_n < 1) return fail(c, SPMF_E_ARG, "surrogate_fwd: every variable is skipped (n = 0)");
   hipStream_t st = (hipStream_t)stream;
-  if (!c->scratch) {
-    // first use (never inside a stream capture: a step is run eagerly before it is captured);
-    // without it the kernel falls back to atomics
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cap);
-    if (cap == hipStreamCaptureStatusNone &&
-        hipMalloc((void**)&c->scratch, spmf_ctx::kScratchDoubles * sizeof(double)) != hipSuccess) {
-      c->scratch = nullptr;
-      (void)hipGetLastError();
-    }
-  }
+  ensure_scratch(c, st);
   launch_surrogate_fwd(T, nvars, max_n, S, logq, c->scratch, spmf_ctx::kScratchDoubles, st);
   HIPCHK(c, hipGetLastError());
   return SPMF_OK;

@@ -383,24 +383,17 @@ __device__ __forceinline__ float gamma_dgda(double a, double x) {
   return (float)(-acc);
 }
 
-__global__ __launch_bounds__(256) void sample_noise_kernel(SurTable T, int S, uint32_t seed_lo,
-                                                           uint32_t seed_hi, uint64_t counter,
-                                                           const double* __restrict__ state) {
-  const int var = blockIdx.y, s = blockIdx.z;
-  const SurVar v = T.v[var];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= v.n) return;
-  if (state) counter += (uint64_t)state[13];           // steps taken so far (device-resident)
-  const uint2 key = make_uint2(seed_lo, seed_hi);
+// One element's base noise for draw s of variable `var` (index in the caller's table): eps ~ N(0,1), or
+// g ~ Gamma(a, 1) with dgda its implicit-reparameterisation derivative (a = softplus(t0), given).
+__device__ __forceinline__ void draw_elem(int kind, float a, int var, int s, int i, uint2 key, uint32_t clo,
+                                          uint32_t chi, float& nz_out, float& dgda_out) {
   const uint32_t c1 = (uint32_t)s | ((uint32_t)var << 16);
-  const uint32_t clo = (uint32_t)counter, chi = (uint32_t)(counter >> 32);
-  float* nz = const_cast<float*>(v.noise) + (size_t)s * v.ld + i;
-  if (v.kind != 2) {
+  dgda_out = 0.f;
+  if (kind != 2) {
     const uint4 r = philox4x32_10(make_uint4((uint32_t)i, c1, clo, chi), key);
-    *nz = normal_bm(r.x, r.y);
+    nz_out = normal_bm(r.x, r.y);
     return;
   }
-  const float a = softplusf(v.t0[i]);
   const float ab = a < 1.f ? a + 1.f : a;              // boost: Gamma(a) = Gamma(a+1) U^(1/a)
   const float d = ab - (1.f / 3.f), cc = rsqrtf(9.f * d);
   float g = d;                                          // (fallback after 16 rejected blocks: the mode)
@@ -431,8 +424,137 @@ __global__ __launch_bounds__(256) void sample_noise_kernel(SurTable T, int S, ui
   }
   if (a < 1.f) g *= powf(ub, 1.f / a);
   g = fmaxf(g, 1e-30f);
-  *nz = g;
-  const_cast<float*>(v.dgda)[(size_t)s * v.ld + i] = gamma_dgda((double)a, (double)g);
+  nz_out = g;
+  dgda_out = gamma_dgda((double)a, (double)g);
+}
+
+__global__ __launch_bounds__(256) void sample_noise_kernel(SurTable T, int S, uint32_t seed_lo,
+                                                           uint32_t seed_hi, uint64_t counter,
+                                                           const double* __restrict__ state) {
+  const int var = blockIdx.y, s = blockIdx.z;
+  const SurVar v = T.v[var];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= v.n) return;
+  if (state) counter += (uint64_t)state[13];           // steps taken so far (device-resident)
+  const uint2 key = make_uint2(seed_lo, seed_hi);
+  float nz, dg;
+  draw_elem(v.kind, v.kind == 2 ? softplusf(v.t0[i]) : 0.f, var, s, i, key, (uint32_t)counter,
+            (uint32_t)(counter >> 32), nz, dg);
+  const_cast<float*>(v.noise)[(size_t)s * v.ld + i] = nz;
+  if (v.kind == 2) const_cast<float*>(v.dgda)[(size_t)s * v.ld + i] = dg;
+}
+
+// spmf_sample_noise + spmf_surrogate_fwd in ONE launch (the VI step's path): a thread draws its elements' noise,
+// keeps it in registers for the transform, and writes noise / dgda (the chain rule needs them) and theta; the
+// block sums of log q go to per-block slots as in surrogate_fwd_kernel, and the LAST workgroup to arrive adds
+// the slots up in block order (the order logq_reduce_kernel uses: the same bits) -- one launch instead of three.
+// Hand-off to the last workgroup: every storing wave's vmcnt(0), the workgroup barrier, an agent-scope release,
+// the ticket; the workgroup that draws the last ticket runs an agent-scope acquire, then the barrier, then
+// plain loads (MI355X_MICROARCH.md, correctness boundaries).
+__global__ __launch_bounds__(256) void sample_fwd_kernel(SurTable T, int S, uint32_t seed_lo, uint32_t seed_hi,
+                                                         uint64_t counter, const double* __restrict__ state,
+                                                         double* __restrict__ logq, double* __restrict__ lqpart,
+                                                         unsigned int* __restrict__ ticket) {
+  __shared__ double red[16];
+  __shared__ int last_s;
+  const int var = blockIdx.y;
+  const SurVar v = T.v[var];
+  const int base = blockIdx.x * (256 * kEPTF);
+  const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (state) counter += (uint64_t)state[13];
+  const uint2 key = make_uint2(seed_lo, seed_hi);
+  const uint32_t clo = (uint32_t)counter, chi = (uint32_t)(counter >> 32);
+  if (base >= v.n) {          // block-uniform (also a skipped variable: n = 0)
+    if (threadIdx.x == 0)
+      for (int s = 0; s < S; ++s) lqpart[(size_t)s * nblk + blk] = 0.0;
+  } else {
+    float c0[kEPTF], c1[kEPTF], c2[kEPTF];
+    bool soft[kEPTF];
+#pragma unroll
+    for (int e = 0; e < kEPTF; ++e) {
+      const int i = base + e * 256 + threadIdx.x;
+      c0[e] = c1[e] = c2[e] = 0.f;
+      soft[e] = false;
+      if (i < v.n) {
+        const float t0 = v.t0[i], t1 = v.t1[i];
+        if (v.kind == 2) {
+          const float a = softplusf(t0), b = softplusf(t1);
+          c0[e] = a;
+          c1[e] = b;
+          c2[e] = a * logf(b) - lgamma_pos_(a);
+        } else {
+          const float sg = softplusf(t1);
+          c0[e] = t0;
+          c1[e] = sg;
+          c2[e] = -logf(sg) - 0.91893853320467274178f;
+        }
+        soft[e] = v.kind != 1 && !(v.ident && v.ident[i]);
+      }
+    }
+    for (int s = 0; s < S; ++s) {
+      double lq = 0.0;
+      float* __restrict__ nzp = const_cast<float*>(v.noise) + (size_t)s * v.ld;
+      float* __restrict__ thp = v.theta + (size_t)s * v.n;
+#pragma unroll
+      for (int e = 0; e < kEPTF; ++e) {
+        const int i = base + e * 256 + threadIdx.x;
+        if (i < v.n) {
+          float nz, dg;
+          draw_elem(v.kind, c0[e], var, s, i, key, clo, chi, nz, dg);
+          nzp[i] = nz;
+          if (v.kind == 2) const_cast<float*>(v.dgda)[(size_t)s * v.ld + i] = dg;
+          float y, l;
+          if (v.kind == 2) {
+            y = c1[e] / nz;
+            l = c2[e] - (c0[e] + 1.f) * logf(y) - c1[e] / y;
+          } else {
+            y = c0[e] + c1[e] * nz;
+            l = -0.5f * nz * nz + c2[e];
+          }
+          float th = y;
+          if (soft[e]) {
+            th = softplusf(y);
+            l -= logsigmoidf_(y);
+          }
+          thp[i] = th;
+          lq += (double)l;
+        }
+      }
+      const double tot = block_sum(lq, red);
+      if (threadIdx.x == 0) lqpart[(size_t)s * nblk + blk] = tot;
+    }
+  }
+  // ---- the last workgroup to arrive folds the slots -----------------------------------------------
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned int k = atomicAdd(ticket, 1u);
+    last_s = k == (unsigned int)nblk - 1u ? 1 : 0;
+    if (last_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  __syncthreads();
+  if (!last_s) return;
+  for (int s = 0; s < S; ++s) {
+    const double* p = lqpart + (size_t)s * nblk;
+    double acc = 0.0;
+    for (size_t b = threadIdx.x; b < nblk; b += 256) acc += p[b];
+    const double tot = block_sum(acc, red);
+    if (threadIdx.x == 0) logq[s] = tot;
+  }
+  if (threadIdx.x == 0) *ticket = 0u;                 // ready for the next launch (stream order)
+}
+
+bool launch_sample_fwd(const SurTable& T, int nvars, int max_n, int S, uint64_t seed, uint64_t counter,
+                       const double* state, double* logq, double* scratch, size_t scratch_doubles, hipStream_t st) {
+  dim3 grid((max_n + 256 * kEPTF - 1) / (256 * kEPTF), nvars);
+  const size_t nblk = (size_t)grid.x * grid.y;
+  if (!scratch || nblk * (size_t)S + 8 > scratch_doubles) return false;   // (the caller runs the two separate kernels)
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(scratch + scratch_doubles - 1);
+  hipLaunchKernelGGL(sample_fwd_kernel, grid, dim3(256), 0, st, T, S, (uint32_t)seed, (uint32_t)(seed >> 32), counter,
+                     state, logq, scratch, ticket);
+  return true;
 }
 
 void launch_sample_noise(const SurTable& T, int nvars, int max_n, int S, uint64_t seed, uint64_t counter,

@@ -211,6 +211,24 @@ class Surrogate:
         return theta, logq
 
     @torch.no_grad()
+    def draw_and_forward(self, model, S, seed=None, state=None, only=None):
+        """draw_noise + forward_hip in ONE launch (spmf_sample_transform): -> (noise, theta, logq), the
+        same draws, theta and logq bits as the two calls."""
+        lib, h = _lib.load(), model._handle()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+        noise = self.alloc_noise(S)
+        theta = {n: torch.empty(noise[n][0].shape, dtype=torch.float32, device=self.device)
+                 for n in self.var_order}
+        logq = torch.empty(S, dtype=torch.float64, device=self.device)
+        arr = self._table(S, noise, theta=theta, only=only)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(h, lib.spmf_sample_transform(h, arr, len(self.var_order), S, seed, 0,
+                                                state.data_ptr() if state is not None else None,
+                                                logq.data_ptr(), stream), "spmf_sample_transform")
+        return noise, theta, logq
+
+    @torch.no_grad()
     def backward_hip(self, model, S, noise, gtheta, inv_sb, c):
         """d loss / d trainables (list in trainable order) given dE/dtheta."""
         lib, h = _lib.load(), model._handle()
@@ -447,8 +465,7 @@ def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=No
         state = opt.state
     side = _hierarchy_beside_the_column_pass(model, sur)
     if side is None:
-        noise = sur.draw_noise(S, seed=seed, state=state)
-        theta, logq = sur.forward_hip(model, S, noise)
+        noise, theta, logq = sur.draw_and_forward(model, S, seed=seed, state=state)     # one launch
         parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=hook, prior_weight=c)
     else:
         # The data pass reads v, w, u, s only; the eight variables of the scale hierarchy (the gamma draws

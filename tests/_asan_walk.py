@@ -60,6 +60,8 @@ for flags in (0, 1, 2 | 1, 4, 4 | 2, 8, 16 | 1):
         assert lib.spmf_surrogate_fwd(h, sv, 12, 1, 4096, None) == -1
         assert lib.spmf_surrogate_bwd(h, sv, 13, 1, 1.0, 1.0, None) == -1
         assert lib.spmf_sample_noise(h, sv, 12, 1, 1, 0, None, None) == -1
+        assert lib.spmf_sample_transform(h, sv, 12, 1, 1, 0, None, 4096, None) == -1     # every variable skipped
+        assert lib.spmf_sample_transform(h, sv, 12, 1, 1, 0, None, None, None) == -1
         av = (_lib.AdamVar * 24)()
         assert lib.spmf_adam_step(h, av, 24, 1e-3, 0.9, 0.999, 1e-7, 1, 0.0, None) == -1
         assert lib.spmf_adam_step_dev(h, av, 25, 4096, None) == -1

@@ -648,3 +648,35 @@ def test_vi_step_with_the_hierarchy_beside_the_column_pass_equals_the_single_str
     for a, b in zip(*finals):
         assert torch.equal(a, b)
     assert abs(losses[0] - losses[1]) <= 1e-12 * abs(losses[1])
+
+
+@pytest.mark.parametrize("D,K,S", [(24, 2, 3), (700, 32, 2), (5000, 16, 1)])
+def test_sample_transform_in_one_launch_equals_the_two_calls(D, K, S):
+    """spmf_sample_transform (the VI step's path since round 5): base noise, theta and log q in ONE launch --
+    the per-workgroup log-q sums folded by the last workgroup to arrive -- give the same draws, the same theta
+    and the same log q BITS as spmf_sample_noise + spmf_surrogate_fwd; repeated (the arrival ticket resets),
+    with the device step counter, and for a subset of the variables."""
+    from spmf_amd import PoissonFactorization
+    from spmf_amd import vi
+    torch.manual_seed(4)
+    m = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1e-3, device="cuda")
+    sur = m.surrogate_distribution
+    with torch.no_grad():
+        for p in sur.trainable_variables:
+            p.add_(0.05 * torch.randn_like(p))
+    opt = vi.AdamHIP(m, sur.trainable_variables, 1e-3)
+    opt.init_state(None)
+    opt.state[13] = 7.0                                  # seven steps gated so far
+    for rep, (seed, state, only) in enumerate(((11, None, None), (11, None, None), (12, opt.state, None),
+                                               (13, None, frozenset(("u", "u_eta", "s_tau_a"))))):
+        n1 = sur.draw_noise(S, seed=seed, state=state, only=only)
+        th1 = {n: torch.zeros(n1[n][0].shape, dtype=torch.float32, device="cuda") for n in sur.var_order}
+        _, lq1 = sur.forward_hip(m, S, n1, only=only, theta=th1)
+        n2, th2, lq2 = sur.draw_and_forward(m, S, seed=seed, state=state, only=only)
+        torch.cuda.synchronize()
+        assert torch.equal(lq1, lq2), (rep, lq1, lq2)
+        for n in (only or sur.var_order):
+            assert torch.equal(n1[n][0], n2[n][0]), (rep, n)
+            if n1[n][1] is not None:
+                assert torch.equal(n1[n][1], n2[n][1]), (rep, n, "dgda")
+            assert torch.equal(th1[n], th2[n]), (rep, n, "theta")
