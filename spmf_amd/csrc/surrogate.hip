@@ -444,10 +444,14 @@ __global__ __launch_bounds__(256) void sample_noise_kernel(SurTable T, int S, ui
   if (v.kind == 2) const_cast<float*>(v.dgda)[(size_t)s * v.ld + i] = dg;
 }
 
-// spmf_sample_noise + spmf_surrogate_fwd in ONE launch (the VI step's path): a thread draws its elements' noise,
-// keeps it in registers for the transform, and writes noise / dgda (the chain rule needs them) and theta; the
-// block sums of log q go to per-block slots as in surrogate_fwd_kernel, and the LAST workgroup to arrive adds
-// the slots up in block order (the order logq_reduce_kernel uses: the same bits) -- one launch instead of three.
+// spmf_sample_noise + spmf_surrogate_fwd in ONE launch (the VI step's path): the sampler's decomposition -- one
+// element and one draw per thread, grid (elements / 256, variables, draws): the gamma draws' series is what the
+// launch's time is, and it wants every lane it can get (a first form with the transform's four elements x all
+// draws per thread was 86 us SLOWER on the 8-GPU shard) -- and each thread transforms what it drew while it is
+// in registers; noise / dgda (the chain rule needs them) and theta are written, the block sums of log q go to
+// per-block slots, and the LAST workgroup to arrive adds the slots up in block order, draw by draw -- one launch
+// instead of three, a fixed association (log q equals the two-call form to rounding, not bit for bit: the
+// partial sums group 256 elements here, 1024 there).
 // Hand-off to the last workgroup: every storing wave's vmcnt(0), the workgroup barrier, an agent-scope release,
 // the ticket; the workgroup that draws the last ticket runs an agent-scope acquire, then the barrier, then
 // plain loads (MI355X_MICROARCH.md, correctness boundaries).
@@ -457,100 +461,76 @@ __global__ __launch_bounds__(256) void sample_fwd_kernel(SurTable T, int S, uint
                                                          unsigned int* __restrict__ ticket) {
   __shared__ double red[16];
   __shared__ int last_s;
-  const int var = blockIdx.y;
+  const int var = blockIdx.y, s = blockIdx.z;
   const SurVar v = T.v[var];
-  const int base = blockIdx.x * (256 * kEPTF);
-  const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const size_t nb2 = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (state) counter += (uint64_t)state[13];
-  const uint2 key = make_uint2(seed_lo, seed_hi);
-  const uint32_t clo = (uint32_t)counter, chi = (uint32_t)(counter >> 32);
-  if (base >= v.n) {          // block-uniform (also a skipped variable: n = 0)
-    if (threadIdx.x == 0)
-      for (int s = 0; s < S; ++s) lqpart[(size_t)s * nblk + blk] = 0.0;
-  } else {
-    float c0[kEPTF], c1[kEPTF], c2[kEPTF];
-    bool soft[kEPTF];
-#pragma unroll
-    for (int e = 0; e < kEPTF; ++e) {
-      const int i = base + e * 256 + threadIdx.x;
-      c0[e] = c1[e] = c2[e] = 0.f;
-      soft[e] = false;
-      if (i < v.n) {
-        const float t0 = v.t0[i], t1 = v.t1[i];
-        if (v.kind == 2) {
-          const float a = softplusf(t0), b = softplusf(t1);
-          c0[e] = a;
-          c1[e] = b;
-          c2[e] = a * logf(b) - lgamma_pos_(a);
-        } else {
-          const float sg = softplusf(t1);
-          c0[e] = t0;
-          c1[e] = sg;
-          c2[e] = -logf(sg) - 0.91893853320467274178f;
-        }
-        soft[e] = v.kind != 1 && !(v.ident && v.ident[i]);
-      }
+  double lq = 0.0;
+  if (i < v.n) {
+    const float t0 = v.t0[i], t1 = v.t1[i];
+    float c0, c1, c2;
+    if (v.kind == 2) {
+      const float a = softplusf(t0), b = softplusf(t1);
+      c0 = a;
+      c1 = b;
+      c2 = a * logf(b) - lgamma_pos_(a);
+    } else {
+      const float sg = softplusf(t1);
+      c0 = t0;
+      c1 = sg;
+      c2 = -logf(sg) - 0.91893853320467274178f;
     }
-    for (int s = 0; s < S; ++s) {
-      double lq = 0.0;
-      float* __restrict__ nzp = const_cast<float*>(v.noise) + (size_t)s * v.ld;
-      float* __restrict__ thp = v.theta + (size_t)s * v.n;
-#pragma unroll
-      for (int e = 0; e < kEPTF; ++e) {
-        const int i = base + e * 256 + threadIdx.x;
-        if (i < v.n) {
-          float nz, dg;
-          draw_elem(v.kind, c0[e], var, s, i, key, clo, chi, nz, dg);
-          nzp[i] = nz;
-          if (v.kind == 2) const_cast<float*>(v.dgda)[(size_t)s * v.ld + i] = dg;
-          float y, l;
-          if (v.kind == 2) {
-            y = c1[e] / nz;
-            l = c2[e] - (c0[e] + 1.f) * logf(y) - c1[e] / y;
-          } else {
-            y = c0[e] + c1[e] * nz;
-            l = -0.5f * nz * nz + c2[e];
-          }
-          float th = y;
-          if (soft[e]) {
-            th = softplusf(y);
-            l -= logsigmoidf_(y);
-          }
-          thp[i] = th;
-          lq += (double)l;
-        }
-      }
-      const double tot = block_sum(lq, red);
-      if (threadIdx.x == 0) lqpart[(size_t)s * nblk + blk] = tot;
+    const bool soft = v.kind != 1 && !(v.ident && v.ident[i]);
+    float nz, dg;
+    draw_elem(v.kind, c0, var, s, i, make_uint2(seed_lo, seed_hi), (uint32_t)counter, (uint32_t)(counter >> 32), nz, dg);
+    const_cast<float*>(v.noise)[(size_t)s * v.ld + i] = nz;
+    if (v.kind == 2) const_cast<float*>(v.dgda)[(size_t)s * v.ld + i] = dg;
+    float y, l;
+    if (v.kind == 2) {
+      y = c1 / nz;
+      l = c2 - (c0 + 1.f) * logf(y) - c1 / y;
+    } else {
+      y = c0 + c1 * nz;
+      l = -0.5f * nz * nz + c2;
     }
+    float th = y;
+    if (soft) {
+      th = softplusf(y);
+      l -= logsigmoidf_(y);
+    }
+    v.theta[(size_t)s * v.n + i] = th;
+    lq = (double)l;
   }
+  const double tot = block_sum(lq, red);               // (every thread of the block: a block past the variable's end adds 0)
+  if (threadIdx.x == 0) lqpart[(size_t)s * nb2 + blk] = tot;
   // ---- the last workgroup to arrive folds the slots -----------------------------------------------
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned int k = atomicAdd(ticket, 1u);
-    last_s = k == (unsigned int)nblk - 1u ? 1 : 0;
+    last_s = k == (unsigned int)(nb2 * gridDim.z) - 1u ? 1 : 0;
     if (last_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __builtin_amdgcn_s_waitcnt(0);
   }
   __syncthreads();
   if (!last_s) return;
-  for (int s = 0; s < S; ++s) {
-    const double* p = lqpart + (size_t)s * nblk;
+  for (int q = 0; q < S; ++q) {
+    const double* p = lqpart + (size_t)q * nb2;
     double acc = 0.0;
-    for (size_t b = threadIdx.x; b < nblk; b += 256) acc += p[b];
-    const double tot = block_sum(acc, red);
-    if (threadIdx.x == 0) logq[s] = tot;
+    for (size_t b = threadIdx.x; b < nb2; b += 256) acc += p[b];
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) logq[q] = t;
   }
   if (threadIdx.x == 0) *ticket = 0u;                 // ready for the next launch (stream order)
 }
 
 bool launch_sample_fwd(const SurTable& T, int nvars, int max_n, int S, uint64_t seed, uint64_t counter,
                        const double* state, double* logq, double* scratch, size_t scratch_doubles, hipStream_t st) {
-  dim3 grid((max_n + 256 * kEPTF - 1) / (256 * kEPTF), nvars);
-  const size_t nblk = (size_t)grid.x * grid.y;
-  if (!scratch || nblk * (size_t)S + 8 > scratch_doubles) return false;   // (the caller runs the two separate kernels)
+  dim3 grid((max_n + 255) / 256, nvars, S);
+  const size_t nb2 = (size_t)grid.x * grid.y;
+  if (!scratch || nb2 * (size_t)S + 8 > scratch_doubles) return false;   // (the caller runs the two separate kernels)
   unsigned int* ticket = reinterpret_cast<unsigned int*>(scratch + scratch_doubles - 1);
   hipLaunchKernelGGL(sample_fwd_kernel, grid, dim3(256), 0, st, T, S, (uint32_t)seed, (uint32_t)(seed >> 32), counter,
                      state, logq, scratch, ticket);

@@ -24,6 +24,7 @@ against lives in tests/_vi_reference.py, not in the product.)
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List
 
 import numpy as np
@@ -213,7 +214,7 @@ class Surrogate:
     @torch.no_grad()
     def draw_and_forward(self, model, S, seed=None, state=None, only=None):
         """draw_noise + forward_hip in ONE launch (spmf_sample_transform): -> (noise, theta, logq), the
-        same draws, theta and logq bits as the two calls."""
+        same draws and theta bits as the two calls, logq to fp64 rounding."""
         lib, h = _lib.load(), model._handle()
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
@@ -464,8 +465,12 @@ def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=No
     else:
         state = opt.state
     side = _hierarchy_beside_the_column_pass(model, sur)
-    if side is None:
+    if side is None and os.environ.get("SPMF_VI_FUSED_SAMPLER", "1") != "0":
         noise, theta, logq = sur.draw_and_forward(model, S, seed=seed, state=state)     # one launch
+        parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=hook, prior_weight=c)
+    elif side is None:
+        noise = sur.draw_noise(S, seed=seed, state=state)                               # (A/B: the three launches)
+        theta, logq = sur.forward_hip(model, S, noise)
         parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=hook, prior_weight=c)
     else:
         # The data pass reads v, w, u, s only; the eight variables of the scale hierarchy (the gamma draws
@@ -699,6 +704,15 @@ def fit(model, batched_data_factory, dataset_size, batch_size=None, sample_size=
             st = opt.read_state()
             tot, nb, skipped = st[10], int(st[11]), int(st[12])
             ep_sat = st[14]
+            # the peer-pointer collective bounds every wait for a peer (20 s) and then goes on with whatever it
+            # has: an epoch in which that happened must not pass for a trained one
+            peer = getattr(all_reduce, "comm", None)
+            if peer is not None and hasattr(peer, "status"):
+                _, gave_up = peer.status()
+                if gave_up:
+                    raise RuntimeError(f"the step's collective gave up waiting for a peer in its call {gave_up} "
+                                       "(spmf_p2p_status): a rank is gone or far behind; the replicas are no "
+                                       "longer in step")
             if verbose and skipped:
                 print(f"Batch loss NaN, skipping ({skipped} batches)")
             # row shards: the replicas took the same decisions on the same all-reduced
