@@ -585,10 +585,11 @@ typedef struct spmf_sur_var {
 int spmf_sample_noise(spmf_ctx* ctx, const spmf_sur_var* vars, int nvars, int S, uint64_t seed,
                       uint64_t counter, const double* state, void* stream);
 
-/* spmf_sample_noise + spmf_surrogate_fwd in ONE launch (ABI 6; the VI step's path): a thread draws its elements'
- * base noise, transforms it while it is in registers, writes noise / dgda (spmf_surrogate_bwd needs them), theta and
- * its share of log q; the last workgroup to arrive adds the per-workgroup sums up in a fixed order.  Same draws and
- * same theta bits as the two calls, logq equal to fp64 rounding (other partial-sum groups); three launches become one. */
+/* spmf_sample_noise + spmf_surrogate_fwd with the draw and the transform in ONE launch (ABI 6; the VI step's path): a
+ * thread draws its element's base noise, transforms it while it is in registers, writes noise / dgda
+ * (spmf_surrogate_bwd needs them), theta and its share of log q; a second small launch adds the per-workgroup sums up
+ * in a fixed order.  Same draws and same theta bits as the two calls, logq equal to fp64 rounding (other partial-sum
+ * groups); three launches become two. */
 int spmf_sample_transform(spmf_ctx* ctx, const spmf_sur_var* vars, int nvars, int S, uint64_t seed,
                           uint64_t counter, const double* state, double* logq, void* stream);
 

@@ -245,8 +245,8 @@ void launch_surrogate_fwd(const SurTable& T, int nvars, int max_n, int S, double
                           size_t scratch_doubles, hipStream_t st);
 void launch_sample_noise(const SurTable& T, int nvars, int max_n, int S, uint64_t seed, uint64_t counter,
                          const double* state, hipStream_t st);
-// sample + transform + log q in one launch; the last word of `scratch` is the arrival ticket (zero between launches);
-// false: scratch too small for S * blocks partial sums (nothing launched)
+// sample + transform in one launch + the fold of the log q block sums; false: scratch too small for S * blocks
+// partial sums (nothing launched)
 bool launch_sample_fwd(const SurTable& T, int nvars, int max_n, int S, uint64_t seed, uint64_t counter,
                        const double* state, double* logq, double* scratch, size_t scratch_doubles, hipStream_t st);
 void launch_surrogate_bwd(const SurTable& T, int nvars, int max_n, int S, float inv_sb, float c, hipStream_t st);

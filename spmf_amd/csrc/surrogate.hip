@@ -449,22 +449,23 @@ __global__ __launch_bounds__(256) void sample_noise_kernel(SurTable T, int S, ui
 // launch's time is, and it wants every lane it can get (a first form with the transform's four elements x all
 // draws per thread was 86 us SLOWER on the 8-GPU shard) -- and each thread transforms what it drew while it is
 // in registers; noise / dgda (the chain rule needs them) and theta are written, the block sums of log q go to
-// per-block slots, and the LAST workgroup to arrive adds the slots up in block order, draw by draw -- one launch
-// instead of three, a fixed association (log q equals the two-call form to rounding, not bit for bit: the
-// partial sums group 256 elements here, 1024 there).
-// Hand-off to the last workgroup: every storing wave's vmcnt(0), the workgroup barrier, an agent-scope release,
-// the ticket; the workgroup that draws the last ticket runs an agent-scope acquire, then the barrier, then
-// plain loads (MI355X_MICROARCH.md, correctness boundaries).
+// per-block slots that logq_reduce_kernel adds up in block order -- two launches instead of three, a fixed
+// association (log q equals the two-call form to rounding, not bit for bit: the partial sums group 256 elements
+// here, 1024 there).  (The fold by the LAST workgroup to arrive, in the same launch, was built and measured: 30 000
+// workgroups taking a ticket at ONE address serialise at ~13 ns each -- 0.85 against 0.49 ms per VI step on the
+// 8-GPU shard -- and every one of them pays an agent-scope release first.)
 __global__ __launch_bounds__(256) void sample_fwd_kernel(SurTable T, int S, uint32_t seed_lo, uint32_t seed_hi,
                                                          uint64_t counter, const double* __restrict__ state,
-                                                         double* __restrict__ logq, double* __restrict__ lqpart,
-                                                         unsigned int* __restrict__ ticket) {
+                                                         double* __restrict__ lqpart) {
   __shared__ double red[16];
-  __shared__ int last_s;
   const int var = blockIdx.y, s = blockIdx.z;
   const SurVar v = T.v[var];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const size_t nb2 = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (blockIdx.x * 256 >= v.n) {                       // block-uniform: past this variable's end (or a skipped one)
+    if (threadIdx.x == 0) lqpart[(size_t)s * nb2 + blk] = 0.0;
+    return;
+  }
   if (state) counter += (uint64_t)state[13];
   double lq = 0.0;
   if (i < v.n) {
@@ -504,36 +505,16 @@ __global__ __launch_bounds__(256) void sample_fwd_kernel(SurTable T, int S, uint
   }
   const double tot = block_sum(lq, red);               // (every thread of the block: a block past the variable's end adds 0)
   if (threadIdx.x == 0) lqpart[(size_t)s * nb2 + blk] = tot;
-  // ---- the last workgroup to arrive folds the slots -----------------------------------------------
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const unsigned int k = atomicAdd(ticket, 1u);
-    last_s = k == (unsigned int)(nb2 * gridDim.z) - 1u ? 1 : 0;
-    if (last_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __builtin_amdgcn_s_waitcnt(0);
-  }
-  __syncthreads();
-  if (!last_s) return;
-  for (int q = 0; q < S; ++q) {
-    const double* p = lqpart + (size_t)q * nb2;
-    double acc = 0.0;
-    for (size_t b = threadIdx.x; b < nb2; b += 256) acc += p[b];
-    const double t = block_sum(acc, red);
-    if (threadIdx.x == 0) logq[q] = t;
-  }
-  if (threadIdx.x == 0) *ticket = 0u;                 // ready for the next launch (stream order)
 }
 
 bool launch_sample_fwd(const SurTable& T, int nvars, int max_n, int S, uint64_t seed, uint64_t counter,
                        const double* state, double* logq, double* scratch, size_t scratch_doubles, hipStream_t st) {
   dim3 grid((max_n + 255) / 256, nvars, S);
   const size_t nb2 = (size_t)grid.x * grid.y;
-  if (!scratch || nb2 * (size_t)S + 8 > scratch_doubles) return false;   // (the caller runs the two separate kernels)
-  unsigned int* ticket = reinterpret_cast<unsigned int*>(scratch + scratch_doubles - 1);
+  if (!scratch || nb2 * (size_t)S > scratch_doubles) return false;   // (the caller runs the separate kernels)
   hipLaunchKernelGGL(sample_fwd_kernel, grid, dim3(256), 0, st, T, S, (uint32_t)seed, (uint32_t)(seed >> 32), counter,
-                     state, logq, scratch, ticket);
+                     state, scratch);
+  hipLaunchKernelGGL(logq_reduce_kernel, dim3(S), dim3(256), 0, st, (int)nb2, scratch, logq);
   return true;
 }
 
