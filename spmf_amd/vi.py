@@ -465,7 +465,14 @@ def vi_step_dev(model, opt, batch, dataset_rows, sample_size, keep=None, seed=No
     else:
         state = opt.state
     side = _hierarchy_beside_the_column_pass(model, sur)
-    if side is None and os.environ.get("SPMF_VI_FUSED_SAMPLER", "1") != "0":
+    # draw + transform in one launch where the step is launch-bound (a model of up to ~1e6 surrogate elements:
+    # the reference harness' shape 0.20 -> 0.15 ms per VI step, S = 20; C1 0.099 -> 0.095); the big models keep
+    # the separate sampler, whose waves retire without a workgroup barrier behind the gamma draws' series
+    # (the 8-GPU shard of C3, 2.7e6 elements: 0.488 against 0.498 ms; tools/vi_fused_ab.py)
+    fused_env = os.environ.get("SPMF_VI_FUSED_SAMPLER")
+    n_elem = sum(p.numel() for p in sur.trainable_variables) // 2
+    fused = (n_elem <= 1_000_000) if fused_env is None else (fused_env != "0")
+    if side is None and fused:
         noise, theta, logq = sur.draw_and_forward(model, S, seed=seed, state=state)     # one launch
         parts, g, nnf = model.energy_and_grads(batch, theta, all_reduce=hook, prior_weight=c)
     elif side is None:
