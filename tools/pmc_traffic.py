@@ -37,7 +37,7 @@ def kernels_sha():
 
 SHORT = {"row_pass_kernel": "row_pass", "col_pass_kernel": "col_pass", "col_pass_wide_kernel": "col_pass", "sigdot3_kernel": "dense_expdot",
          "expdot_kernel": "dense_expdot", "expdot3_kernel": "dense_expdot", "finish_kernel": "finish",
-         "prep_kernel": "prep"}
+         "prep_kernel": "prep", "begin_kernel": "prep", "end_kernel": "finish"}
 
 
 def main():
