@@ -257,7 +257,11 @@ def c4_extra(dev, steps=4, warmup=2):
     batch = {"counts": sc}
     ms, t6, parts, nnf = _timed_steps(model, batch, params, steps, warmup)
     tf = 6.0 * rows * D * K / (t6[5] * 1e-3) / 1e12
+    # what the bf16 pipe itself issues: two launches x 88 MFMAs of 32x32x16 (6 + 5 partial products of
+    # the three-way split operands) per 64 x 32 cells, against the dense bf16 datasheet peak
+    tf_exec = 2.0 * 88 * 32768 / (64 * 32) * rows * D / (t6[5] * 1e-3) / 1e12
     out = {"c4_ms_per_step": ms, "c4_steps_per_sec": 1e3 / ms, "c4_nnz": int(sc.nnz),
+           "c4_dense_executed_bf16_tflops": tf_exec, "c4_dense_executed_bf16_frac": tf_exec / MFMA_BF16_PEAK_TFLOPS,
            "c4_kernel_ms": {"prep": round(t6[0], 4), "row_pass": round(t6[1], 4), "col_pass": round(t6[2], 4),
                             "finish": round(t6[3], 4), "dense": round(t6[5], 4)},
            "c4_dense_tflops_algorithmic": tf, "c4_dense_frac": tf / MFMA_F32_PEAK_TFLOPS,

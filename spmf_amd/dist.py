@@ -393,6 +393,33 @@ class ShardReducer:
         return self.rows_global, self.lgamma_global
 
 
+def make_reducer(model, prefer="auto", group=None, max_draws=1):
+    """A ShardReducer over the best transport this job has: the library's peer-pointer kernel (PeerComm:
+    stream-ordered, hipGraph-capturable at any world size, the same bits on every rank), else its RCCL
+    communicator (LibraryComm; torch.distributed backend "nccl" only), else torch.distributed itself.
+    ``prefer``: "auto" | "p2p" | "rccl" | "torch".  Every rank must call it (the set-up is collective and a
+    failure on one rank is agreed on by all).  bench.py additionally TIMES the first two against each other."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or model.device.type != "cuda" \
+            or prefer == "torch":
+        return ShardReducer(group=group)
+    comm = None
+    if prefer in ("auto", "p2p"):
+        try:
+            comm = PeerComm(model, max_draws=max_draws, group=group)
+        except Exception as e:              # (agreed on by every rank inside PeerComm)
+            if prefer == "p2p":
+                raise
+            print(f"make_reducer: peer-pointer collective unavailable ({e}); trying RCCL")
+    if comm is None and dist.get_backend(group) == "nccl":
+        try:
+            comm = LibraryComm(model, group=group)
+        except Exception as e:
+            if prefer == "rccl":
+                raise
+            print(f"make_reducer: library RCCL communicator unavailable ({e}); torch.distributed carries the step")
+    return ShardReducer(group=group, comm=comm)
+
+
 def sync_seed(seed=None, group=None):
     """Every rank must draw the SAME base noise for the replicated surrogate
     (parameters, and hence theta, are replicated; only the rows are sharded).

@@ -147,7 +147,7 @@ def _step_worker(rank, world, port, q):
     _init(rank, world, port)
     from spmf_amd import PoissonFactorization, SparseCounts
     from spmf_amd import vi
-    from spmf_amd.dist import PeerComm, ShardReducer, shard_bounds, sync_seed
+    from spmf_amd.dist import PeerComm, ShardReducer, make_reducer, shard_bounds, sync_seed
     X = _data()
     N, D = X.shape
     r0, r1 = shard_bounds(N, world, rank, granule=64)
@@ -158,8 +158,10 @@ def _step_worker(rank, world, port, q):
         m = PoissonFactorization(latent_dim=3, feature_dim=D, u_tau_scale=1 / math.sqrt(N * D), device="cuda",
                                  panel_rows=64, deterministic=True)
         sc = SparseCounts.from_any(X[r0:r1], "cuda", 64)
-        comm = PeerComm(m) if name == "p2p" else None
-        red = ShardReducer(comm=comm)
+        # (make_reducer: what a caller of fit() uses -- the peer kernel first, RCCL / torch.distributed behind it)
+        red = make_reducer(m) if name == "p2p" else ShardReducer()
+        comm = red.comm
+        assert (name == "p2p") == isinstance(comm, PeerComm)
         m.compute_scales(lambda: [{"counts": sc}], all_reduce=red)
         rows_g = red.dataset_rows
         sync_seed(77)
