@@ -184,6 +184,23 @@ def _step_worker(rank, world, port, q):
             out["p2p_status"] = comm.status()
             dist.barrier()
             comm.close()
+    # the column-split step (version-5 calls: the all-reduce of the lower column half is issued while the column
+    # pass still produces the upper one) over the same kernel: two collectives per step on slices of the buffer
+    torch.manual_seed(5)
+    m2 = PoissonFactorization(latent_dim=3, feature_dim=D, u_tau_scale=1 / math.sqrt(N * D), device="cuda", panel_rows=64)
+    Dh = m2.enable_column_split(32)
+    sc2 = SparseCounts.from_any(X[r0:r1], "cuda", 64, col_split=Dh)
+    red2 = make_reducer(m2)
+    m2.compute_scales(lambda: [{"counts": sc2}], all_reduce=red2)
+    sync_seed(77)
+    params2 = m2.surrogate_distribution.sample(1)
+    parts2, grads2, _ = m2.energy_and_grads({"counts": sc2}, params2, all_reduce=red2)
+    torch.cuda.synchronize()
+    out["split_parts"] = {k: v.cpu().numpy() for k, v in parts2.items()}
+    out["split_grads"] = {k: v.cpu().numpy() for k, v in grads2.items()}
+    out["split_status"] = red2.comm.status()
+    dist.barrier()
+    red2.comm.close()
     out["final_equal"] = all(np.array_equal(a, b) for a, b in zip(finals["p2p"], finals["gloo"]))
     out["final_maxdiff"] = max(float(np.abs(a - b).max()) for a, b in zip(finals["p2p"], finals["gloo"]))
     q.put(out)
@@ -203,6 +220,12 @@ def test_sharded_step_and_captured_vi_step_over_the_peer_kernel_equal_gloo():
         assert d["p2p_replays"] >= 4 and d["gloo_replays"] == 0       # captured with the collective / eager
         assert d["final_equal"], d["final_maxdiff"]
         assert d["p2p_state"][11] == 6 and d["gloo_state"][11] == 6   # six applied steps each
+        # the column-split step over the peer kernel == the one-piece step (float atomics: to rounding)
+        assert d["split_status"][1] == 0 and d["split_status"][0] >= 2
+        for k, v in d["p2p_parts"].items():
+            np.testing.assert_allclose(d["split_parts"][k], v, rtol=1e-6, err_msg=k)
+        for k, v in d["p2p_grads"].items():
+            assert np.abs(d["split_grads"][k] - v).max() <= 1e-5 * np.abs(v).max(), k
     # and the replicas agree across the ranks
     a, b = res
     for k in a["p2p_grads"]:

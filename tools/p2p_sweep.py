@@ -1,0 +1,61 @@
+"""The peer-pointer all-reduce on ONE GPU (ranks = processes on the card, IPC): us per call of C3's accumulator length over
+the number of workgroups, world 2 and 4.  Not an xGMI number -- the protocol's own cost (launch, three flag
+hand-offs, 3 passes over the buffer through one GPU's memory).  usage: p2p_sweep.py"""
+import json
+import os
+import socket
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 1_300_076
+
+
+def worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from spmf_amd import PoissonFactorization
+    from spmf_amd.dist import PeerComm
+    m = PoissonFactorization(latent_dim=3, feature_dim=40, device="cuda", panel_rows=64)
+    out = {}
+    x = torch.randn(N, device="cuda")
+    for nchunk in (8, 16, 32, 64, 128):
+        comm = PeerComm(m, n_max=N, nchunk=nchunk)
+        for _ in range(5):
+            comm.all_reduce_(x)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            comm.all_reduce_(x)
+        torch.cuda.synchronize()
+        out[nchunk] = round(1e6 * (time.perf_counter() - t0) / 50, 2)
+        assert comm.status()[1] == 0
+        dist.barrier()
+        comm.close()
+        x.normal_()
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    for world in (2, 4):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        for p in ps:
+            p.start()
+        res = q.get(timeout=400)
+        for p in ps:
+            p.join(60)
+        print(json.dumps({"world": world, "floats": N, "us_per_call_by_workgroups": res}), flush=True)
