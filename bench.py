@@ -422,6 +422,13 @@ def _pick_collective(model, lib_comm, dev, world, rank, S, want, all_reduce_):
         torch.cuda.synchronize()
         us = torch.tensor([1e6 * (time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
         all_reduce_(us, dist.ReduceOp.MAX)
+        # the buffer after the timed calls against the same number of torch.distributed all-reduces: every call of
+        # the loop was a correct sum, not only the first (inbox parities, flags and the call counter all cycled)
+        for _ in range(reps):
+            all_reduce_(ref, dist.ReduceOp.SUM)
+        good = bool(torch.isfinite(y).all()) and float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        if not all_ok(good):
+            return False, float(us.item())
         return True, float(us.item())
 
     peer = None
@@ -431,7 +438,7 @@ def _pick_collective(model, lib_comm, dev, world, rank, S, want, all_reduce_):
         rec["allreduce_p2p_error"] = str(e)[:160]
     if not all_ok(peer is not None):
         if peer is not None:
-            peer.close()
+            peer.close(sync=False)
         rec.setdefault("allreduce_p2p_error", "unavailable on another rank")
         return lib_comm, transport_lib if lib_comm is not None else "torch.distributed", rec
     ok_p, us_p = check_and_time(peer)
@@ -966,6 +973,17 @@ def main():
                            "guide_l2_peak": 34.5}
             except Exception:
                 roof_l2 = None
+        # ... and what the counters say about that kernel's request path (measured once, round 5, on this
+        # workload; a record riding along, not re-measured by this run)
+        rp = os.path.join(ROOT, "profiles", "pmc_request_path.json")
+        if roof_l2 is not None and os.path.exists(rp) and args.workload == "c3" and args.rows is None:
+            try:
+                doc = json.load(open(rp))
+                roof_l2["request_path"] = dict(doc.get(dom, {}), guide_l2_bytes_per_clk_cu=doc.get("guide_l2_bytes_per_clk_cu"),
+                                               flat_probe_ceiling_requests_per_clk_cu=doc.get("flat_probe_ceiling_requests_per_clk_cu"),
+                                               source=doc.get("_source"))
+            except Exception:
+                pass
         _, _, b_tot_g = algorithmic_bytes(nnz_g, rows_g, D, K, S)
         out = {
             "metric": "elbo_steps_per_sec", "value": value, "unit": "steps/s",

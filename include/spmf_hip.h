@@ -425,12 +425,15 @@ int spmf_comm_destroy(spmf_ctx* ctx);
  *                     spmf_allreduce uses; spmf_p2p_connect leaves the kernel selected
  *   spmf_p2p_status   SYNCHRONISES; out3 = {calls completed, 0, first call in which a workgroup gave up
  *                     waiting for a peer (0 = none)}: every spin is bounded, a lost peer cannot hang the GPU
- *   spmf_p2p_destroy  unmaps and frees (also done by spmf_ctx_destroy)
+ *   spmf_p2p_disconnect / spmf_p2p_destroy   an orderly shutdown frees no region a peer still has mapped: every rank
+ *                     disconnects (unmaps the peers), the host synchronises the ranks, every rank destroys (unmaps
+ *                     what is left and frees; also done by spmf_ctx_destroy)
  * All ranks must call spmf_allreduce with the same n, the same number of times. */
 int spmf_p2p_init(spmf_ctx* ctx, int rank, int world, int64_t n_max, int nchunk, void* handle_out64);
 int spmf_p2p_connect(spmf_ctx* ctx, const void* handles);
 int spmf_p2p_enable(spmf_ctx* ctx, int on);   /* 0: spmf_allreduce goes back to RCCL (if spmf_comm_init was called); 1: the kernel again */
 int spmf_p2p_status(spmf_ctx* ctx, uint64_t out3[3]);
+int spmf_p2p_disconnect(spmf_ctx* ctx);   /* unmap the peers' regions, keep the own one (first half of an orderly shutdown) */
 int spmf_p2p_destroy(spmf_ctx* ctx);
 
 /* Phase 2: chain the accumulators to d/d(u,v,w,s), add the prior's parts and

@@ -146,6 +146,7 @@ SIGNATURES = {
     "spmf_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spmf_p2p_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "spmf_p2p_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "spmf_p2p_disconnect": (C.c_int, [C.c_void_p]),
     "spmf_p2p_destroy": (C.c_int, [C.c_void_p]),
     "spmf_nonfinite_argmin": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
                                         C.c_void_p, C.c_void_p]),

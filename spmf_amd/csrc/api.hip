@@ -1171,10 +1171,17 @@ int spmf_nonfinite_reduce(spmf_ctx* c, int64_t n, const float* ll, int pass, dou
 // ---- row-shard collective inside the library (spmf_allreduce) ---------
 // (1) hand-written, over peer pointers: p2p.hip.  Region layout of a rank:
 //     rs[2][kP2PMaxWorld][slice_cap] | ag[2][kP2PMaxWorld][slice_cap] | flags[2][2][kP2PMaxWorld][kP2PMaxChunks] | seq[8]
+static void p2p_unmap(spmf_ctx* c) {
+  spmf_ctx::P2P& p = c->p2p;
+  for (int i = 0; i < p.world; ++i) {
+    if (p.peer[i] && p.peer[i] != p.region) (void)hipIpcCloseMemHandle(p.peer[i]);
+    p.peer[i] = nullptr;
+  }
+  p.connected = 0;
+}
 static void p2p_release(spmf_ctx* c) {
   spmf_ctx::P2P& p = c->p2p;
-  for (int i = 0; i < p.world; ++i)
-    if (p.peer[i] && p.peer[i] != p.region) (void)hipIpcCloseMemHandle(p.peer[i]);
+  p2p_unmap(c);
   if (p.region) (void)hipFree(p.region);
   p = spmf_ctx::P2P();
 }
@@ -1244,6 +1251,19 @@ int spmf_p2p_init(spmf_ctx* c, int rank, int world, int64_t n_max, int nchunk, v
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "spmf_p2p_init hands out 64-byte handles");
   e = hipIpcGetMemHandle(&hnd, p.region);
   if (e != hipSuccess) {
+    // seen once (round 5, world 4, a region re-created in a process whose earlier region a peer had still mapped
+    // when it was freed): the runtime refused to export the new allocation.  One more try at another address.
+    (void)hipGetLastError();
+    void* again = nullptr;
+    if (hipExtMallocWithFlags(&again, p.bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+      (void)hipFree(p.region);
+      p.region = (char*)again;
+      (void)hipMemset(p.region + p.off_flags, 0, p.bytes - p.off_flags);
+      (void)hipDeviceSynchronize();
+      e = hipIpcGetMemHandle(&hnd, p.region);
+    }
+  }
+  if (e != hipSuccess) {
     (void)hipGetLastError();
     p2p_release(c);
     return fail(c, SPMF_E_HIP, std::string("p2p_init: hipIpcGetMemHandle: ") + hipGetErrorString(e));
@@ -1291,6 +1311,13 @@ int spmf_p2p_status(spmf_ctx* c, uint64_t out3[3]) {
   if (!c->p2p.region) return fail(c, SPMF_E_ARG, "p2p_status: spmf_p2p_init was not called");
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(out3, c->p2p.region + c->p2p.off_seq, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return SPMF_OK;
+}
+
+int spmf_p2p_disconnect(spmf_ctx* c) {
+  if (!c) return SPMF_E_ARG;
+  (void)hipDeviceSynchronize();
+  p2p_unmap(c);
   return SPMF_OK;
 }
 

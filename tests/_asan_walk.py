@@ -80,6 +80,7 @@ for flags in (0, 1, 2 | 1, 4, 4 | 2, 8, 16 | 1):
         assert lib.spmf_p2p_init(h, 0, 2, 0, 0, hb) == -1              # nothing to reduce
         assert lib.spmf_p2p_status(h, None) == -1
         assert lib.spmf_p2p_enable(h, 1) == -1 and lib.spmf_p2p_enable(h, 0) == 0
+        assert lib.spmf_p2p_disconnect(h) == 0
         assert lib.spmf_p2p_destroy(h) == 0
         assert lib.spmf_ctx_set_rows_event(h, None) == 0
         assert lib.spmf_comm_destroy(h) == 0
