@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N = 1_300_076
 
 
-def worker(rank, world, port, q):
+def worker(rank, world, port, q, chunks):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -26,7 +26,7 @@ def worker(rank, world, port, q):
     m = PoissonFactorization(latent_dim=3, feature_dim=40, device="cuda", panel_rows=64)
     out = {}
     x = torch.randn(N, device="cuda")
-    for nchunk in (8, 16, 32, 64, 128):
+    for nchunk in chunks:
         comm = PeerComm(m, n_max=N, nchunk=nchunk)
         for _ in range(5):
             comm.all_reduce_(x)
@@ -48,14 +48,24 @@ def worker(rank, world, port, q):
 
 
 if __name__ == "__main__":
+    # one set of processes per (world, workgroup count): a region is created once per process (re-creating the
+    # regions inside one process at world 4 is what stalled the first form of this sweep)
     for world in (2, 4):
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        ps = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
-        for p in ps:
-            p.start()
-        res = q.get(timeout=400)
-        for p in ps:
-            p.join(60)
+        res = {}
+        for nchunk in (8, 16, 32, 64, 128):
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            ctx = mp.get_context("spawn")
+            q = ctx.Queue()
+            ps = [ctx.Process(target=worker, args=(r, world, port, q, (nchunk,))) for r in range(world)]
+            for p in ps:
+                p.start()
+            try:
+                res.update(q.get(timeout=120))
+            except Exception:
+                res[nchunk] = "no answer in 120 s"
+            for p in ps:
+                p.join(30)
+                if p.is_alive():
+                    p.kill()
+            print(json.dumps({"world": world, "workgroups": nchunk, "us_per_call": res.get(nchunk)}), flush=True)
         print(json.dumps({"world": world, "floats": N, "us_per_call_by_workgroups": res}), flush=True)
