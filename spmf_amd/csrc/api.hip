@@ -94,7 +94,7 @@ struct spmf_ctx {
   // and the peers' regions as mapped into this process
   struct P2P {
     char* region = nullptr;          // own allocation: [rs | ag | flags | seq]
-    size_t bytes = 0, off_ag = 0, off_flags = 0, off_seq = 0;
+    size_t bytes = 0, alloc_bytes = 0, off_ag = 0, off_flags = 0, off_seq = 0;
     int64_t n_max = 0, slice_cap = 0;
     int rank = 0, world = 0, nchunk = 0, connected = 0;
     char* peer[kP2PMaxWorld] = {};   // peer regions (own rank: own region); opened with hipIpcOpenMemHandle
@@ -1223,28 +1223,47 @@ int spmf_p2p_init(spmf_ctx* c, int rank, int world, int64_t n_max, int nchunk, v
   if (nchunk <= 0) nchunk = 32;
   if (nchunk > kP2PMaxChunks) nchunk = kP2PMaxChunks;
   HIPCHK(c, hipSetDevice(c->device));
-  p2p_release(c);
+  HIPCHK(c, hipDeviceSynchronize());
   spmf_ctx::P2P& p = c->p2p;
+  const int64_t per = ((n_max + world - 1) / world + 3) & ~(int64_t)3;
+  const int64_t slice_cap = (per + 63) & ~(int64_t)63;           // 256-byte slots
+  const size_t box = (size_t)2 * kP2PMaxWorld * slice_cap * sizeof(float);
+  const size_t off_flags = 2 * box;
+  const size_t off_seq = off_flags + (size_t)2 * 2 * kP2PMaxWorld * kP2PMaxChunks * sizeof(uint64_t);
+  const size_t bytes = off_seq + 64;
+  // A context's region is allocated ONCE and re-used while it is large enough: freeing a region and exporting a
+  // new allocation inside one process is what the runtime's IPC bookkeeping did not survive (round 5, world 4:
+  // "hipIpcGetMemHandle: invalid argument", or peers that mapped something stale and never saw a flag).
+  p2p_unmap(c);
+  char* keep = (p.region && p.alloc_bytes >= bytes) ? p.region : nullptr;
+  const size_t keep_bytes = keep ? p.alloc_bytes : 0;
+  if (p.region && !keep) (void)hipFree(p.region);
+  p = spmf_ctx::P2P();
   p.rank = rank;
   p.world = world;
   p.nchunk = nchunk;
   p.n_max = n_max;
-  const int64_t per = ((n_max + world - 1) / world + 3) & ~(int64_t)3;
-  p.slice_cap = (per + 63) & ~(int64_t)63;                       // 256-byte slots
-  const size_t box = (size_t)2 * kP2PMaxWorld * p.slice_cap * sizeof(float);
+  p.slice_cap = slice_cap;
   p.off_ag = box;
-  p.off_flags = 2 * box;
-  p.off_seq = p.off_flags + (size_t)2 * 2 * kP2PMaxWorld * kP2PMaxChunks * sizeof(uint64_t);
-  p.bytes = p.off_seq + 64;
-  // fine-grained: coherent across agents INSIDE a kernel (a coarse-grained allocation is only
-  // coherent at kernel boundaries); what RCCL allocates for its own buffers
-  void* reg = nullptr;
-  hipError_t e = hipExtMallocWithFlags(&reg, p.bytes, hipDeviceMallocFinegrained);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    return fail(c, SPMF_E_HIP, std::string("p2p_init: hipExtMallocWithFlags(fine-grained): ") + hipGetErrorString(e));
+  p.off_flags = off_flags;
+  p.off_seq = off_seq;
+  p.bytes = bytes;
+  hipError_t e = hipSuccess;
+  if (keep) {
+    p.region = keep;
+    p.alloc_bytes = keep_bytes;
+  } else {
+    // fine-grained: coherent across agents INSIDE a kernel (a coarse-grained allocation is only
+    // coherent at kernel boundaries); what RCCL allocates for its own buffers
+    void* reg = nullptr;
+    e = hipExtMallocWithFlags(&reg, p.bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(c, SPMF_E_HIP, std::string("p2p_init: hipExtMallocWithFlags(fine-grained): ") + hipGetErrorString(e));
+    }
+    p.region = (char*)reg;
+    p.alloc_bytes = p.bytes;
   }
-  p.region = (char*)reg;
   HIPCHK(c, hipMemset(p.region + p.off_flags, 0, p.bytes - p.off_flags));
   HIPCHK(c, hipDeviceSynchronize());
   hipIpcMemHandle_t hnd;
@@ -1258,6 +1277,7 @@ int spmf_p2p_init(spmf_ctx* c, int rank, int world, int64_t n_max, int nchunk, v
     if (hipExtMallocWithFlags(&again, p.bytes, hipDeviceMallocFinegrained) == hipSuccess) {
       (void)hipFree(p.region);
       p.region = (char*)again;
+      p.alloc_bytes = p.bytes;
       (void)hipMemset(p.region + p.off_flags, 0, p.bytes - p.off_flags);
       (void)hipDeviceSynchronize();
       e = hipIpcGetMemHandle(&hnd, p.region);

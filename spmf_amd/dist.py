@@ -183,14 +183,15 @@ class PeerComm:
 
     def close(self, group=None, sync=True):
         """Orderly shutdown (collective when torch.distributed is up and ``sync``): every rank unmaps its peers'
-        regions, the ranks meet, every rank frees its own -- no region is freed while a peer still has it
+        regions and the ranks meet -- so no region is freed (with its model's context) while a peer still has it
         mapped.  ``sync=False``: this rank alone (error paths)."""
         from . import _lib
         lib, h = _lib.load(), self.model._handle()
         _lib.check(h, lib.spmf_p2p_disconnect(h), "spmf_p2p_disconnect")
         if sync and self.world > 1 and dist.is_initialized():
             dist.barrier(group=group)
-        _lib.check(h, lib.spmf_p2p_destroy(h), "spmf_p2p_destroy")
+        # (the own region stays with the model's context -- a later PeerComm on the same model re-uses it, and it
+        #  is freed with the context: regions are allocated once per context, spmf_p2p_init)
 
 
 class ShardReducer:

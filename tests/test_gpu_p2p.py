@@ -9,6 +9,7 @@ Checked bit for bit:
     reduced once, by its owner, in that order) -- lengths that are no multiple of 4 * world, shorter than
     the world, and the C3 accumulator length; many calls back to back (the inbox parities alternate);
   * a hipGraph that holds [refill, all-reduce] replays correctly (the call counter lives on the device);
+  * communicators created one after another on the same model (the region is allocated once per context);
   * the row-sharded energy + gradient step and the device-resident VI step (captured WITH the collective
     and replayed) over this transport == the same over gloo's host-staged sum (deterministic mode, so a
     rank's accumulators are the same bits run to run; world 2: a two-term sum has one association).
@@ -103,10 +104,26 @@ def _collective_worker(rank, world, port, q):
         torch.cuda.synchronize()
         graph_ok = graph_ok and torch.equal(buf.cpu(), want)
     done2, gave_up2 = comm.status()
-    q.put({"rank": rank, "bad": bad, "calls": done, "gave_up": gave_up, "graph_ok": graph_ok,
-           "calls2": done2, "gave_up2": gave_up2})
     dist.barrier()
     comm.close()
+    # a second and third communicator on the same model, other workgroup counts: the context's region is kept
+    # and re-used (spmf_p2p_init), the peers map it again -- the sequence that stalled at world 4 while every
+    # communicator freed and re-allocated its region
+    again = []
+    for nchunk in (16, 64):
+        comm = PeerComm(m, n_max=max(LENGTHS), nchunk=nchunk)
+        for rep in range(3):
+            call += 1
+            xs = _inputs(4099, world, call)
+            buf = xs[rank].cuda()
+            comm.all_reduce_(buf)
+            again.append(torch.equal(buf.cpu(), _ordered_sum(xs)))
+        again.append(comm.status() == (3, 0))
+        dist.barrier()
+        comm.close()
+    q.put({"rank": rank, "bad": bad, "calls": done, "gave_up": gave_up, "graph_ok": graph_ok,
+           "calls2": done2, "gave_up2": gave_up2, "again": again})
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -133,6 +150,7 @@ def test_peer_allreduce_is_the_rank_ordered_sum_on_every_rank(world):
         assert d["bad"] == [], d["bad"][:3]
         assert d["calls"] == 3 * len(LENGTHS) and d["calls2"] == d["calls"] + 5    # 1 eager + 4 replays
         assert d["graph_ok"]
+        assert all(d["again"]) and len(d["again"]) == 8, d["again"]
 
 
 def _data():

@@ -47,7 +47,32 @@ def worker(rank, world, port, q, chunks):
     dist.destroy_process_group()
 
 
+def one_set(world, chunks, wait):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=worker, args=(r, world, port, q, chunks)) for r in range(world)]
+    for p in ps:
+        p.start()
+    try:
+        res = q.get(timeout=wait)
+    except Exception:
+        res = {c: "no answer in %d s" % wait for c in chunks}
+    for p in ps:
+        p.join(30)
+        if p.is_alive():
+            p.kill()
+    return res
+
+
 if __name__ == "__main__":
+    if "--same-processes" in sys.argv:
+        # every workgroup count inside ONE set of processes: communicators created one after another on the same
+        # context, which keeps and re-uses its region (spmf_p2p_init)
+        for world in (2, 4):
+            print(json.dumps({"world": world, "floats": N, "same_processes": True,
+                              "us_per_call_by_workgroups": one_set(world, (8, 16, 32, 64, 128), 300)}), flush=True)
+        sys.exit(0)
     # one set of processes per (world, workgroup count): a region is created once per process (re-creating the
     # regions inside one process at world 4 is what stalled the first form of this sweep)
     for world in (2, 4):
