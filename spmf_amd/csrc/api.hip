@@ -306,7 +306,7 @@ int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   if (!out) return SPMF_E_ARG;
   *out = nullptr;
   if (K < 1 || K > 64 || D < 1) return SPMF_E_ARG;
-  if ((int64_t)D * 64 * 4 >= (1LL << 32)) return SPMF_E_ARG;   // 32-bit gather offsets into [D,KP]
+  if ((int64_t)D * 64 * 4 >= (1LL << 32) - 256) return SPMF_E_ARG;   // 32-bit gather offsets into [D,KP]; the last KP*4 bytes below 4 GiB are the padded slots' (common.h kPadRow)
   spmf_ctx* c = new spmf_ctx();
   c->device = device;
   c->K = K;
@@ -525,7 +525,7 @@ static int check_counts(spmf_ctx* c, const spmf_counts* ct) {
   if (ct->n_rows < 0 || ct->nnz < 0 || ct->nnz > 2147483647LL) return fail(c, SPMF_E_ARG,
       "counts: bad n_rows/nnz (nnz must fit int32)");
   // the kernels gather factor rows with 32-bit byte offsets: B*KP*4 must stay below 4 GiB
-  if (ct->n_rows * (int64_t)c->KP * 4 >= (1LL << 32)) return fail(c, SPMF_E_ARG,
+  if (ct->n_rows * (int64_t)c->KP * 4 >= (1LL << 32) - c->KP * 4) return fail(c, SPMF_E_ARG,
       "counts: too many rows in one batch for this K (B*KP*4 must be < 4 GiB)");
   if (!ct->row_ptr || (ct->nnz > 0 && (!ct->col_idx || !ct->val))) return fail(c, SPMF_E_ARG,
       "counts: null CSR arrays");

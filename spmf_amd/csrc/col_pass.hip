@@ -150,6 +150,9 @@ __global__ __launch_bounds__(256, EPL == 4 ? COL_WIDE_WAVES : 1) void col_pass_k
   }
   constexpr int LPN = KP / 4;
   constexpr int NG = 64 / LPN;                        // items per wave
+  // z and xi*gz as range-checked tables: the slots behind a list's end (and the lane groups without an item)
+  // ask for row kPadRow, which the address unit drops (common.h GTable)
+  const GTable zt = gtable(z, Brows, KP), gt = gtable(gzs, Brows, KP);
   // entries gathered back to back: COL_GRP of the 4 * LPN a wide fetch holds (also at K <= 8, where a lane group
   // is one or two lanes and used to keep ONE or two entries in flight); the narrow fetch holds LPN
   constexpr int GRP = EPL == 4 ? COL_GRP : (LPN < COL_GRP ? LPN : COL_GRP);
@@ -246,10 +249,10 @@ __global__ __launch_bounds__(256, EPL == 4 ? COL_WIDE_WAVES : 1) void col_pass_k
       const bool on = left > t;
       if (PACKED) {
         const uint32_t w = (uint32_t)f.r[t];
-        rr_[t] = on ? (int)(w >> 16) + pbase : 0;
+        rr_[t] = on ? (int)(w >> 16) + pbase : kPadRow;
         xx_[t] = on ? (float)(w & 0xffffu) : 0.f;
       } else {
-        rr_[t] = on ? f.r[t] + pbase : 0;
+        rr_[t] = on ? f.r[t] + pbase : kPadRow;
         xx_[t] = on ? f.x[t] : 0.f;
       }
       gx_[t] = on ? f.g[t] : 0.f;
@@ -279,8 +282,8 @@ __global__ __launch_bounds__(256, EPL == 4 ? COL_WIDE_WAVES : 1) void col_pass_k
           const int b = __shfl(rr0[q % EPL], src);
           xv[j] = __shfl(xx0[q % EPL], src);
           gv[j] = (LIK == 1 || LIK == 4) ? __shfl(gx0[q % EPL], src) : xv[j];
-          zz[j] = gather4<LPN>(z, b, sub);
-          gg[j] = gather4<LPN>(gzs, b, sub);
+          zz[j] = gather4<LPN>(zt, b, sub);
+          gg[j] = gather4<LPN>(gt, b, sub);
         }
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {

@@ -134,6 +134,50 @@ __device__ __forceinline__ float4 gather4(const float* __restrict__ base, int ro
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
 }
 
+// The same gather through a buffer descriptor whose record count is the table's size.  What it buys is the
+// hardware range check: a lane whose offset lies behind the table is DROPPED by the address unit -- it returns
+// zeros without a tag lookup in the vector cache and without a request to L2 -- so the padded slots of a row's
+// or list's last group of gathers (they used to read row 0 with weight 0: an L1 hit, but still one of the
+// vector cache's 64-B tag cycles per four lanes, and the sparse passes run that pipe at 98 % of its cycles:
+// DESIGN.md section 4, round 5 (e)) cost an issue slot and nothing else, with no branch and no exec mask in
+// the straight-line groups of loads.  A padded slot asks for row kPadRow: -1 wraps to the last KP*4 bytes
+// below 4 GiB, behind every table the host admits (api.hip checks rows*KP*4 < 4 GiB - KP*4).
+#ifndef SPMF_OOB_PAD
+#define SPMF_OOB_PAD 1
+#endif
+#if SPMF_OOB_PAD
+constexpr int kPadRow = -1;
+constexpr uint32_t kPadWord = 0xffff0000u;     // packed entry (column or panel row 65 535, count 0)
+struct GTable {
+  __amdgpu_buffer_rsrc_t r;
+};
+// base and rows must be wave-uniform (kernel arguments, blockIdx)
+__device__ __forceinline__ GTable gtable(const float* base, int64_t rows, int KP) {
+  GTable t;
+  t.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(uint32_t)((uint64_t)rows * KP * 4u),
+                                          0x00020000);
+  return t;
+}
+template <int LPN>
+__device__ __forceinline__ float4 gather4(const GTable& t, int row, int sub) {
+  const uint32_t off = ((uint32_t)row * (uint32_t)LPN + (uint32_t)sub) * 16u;
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  const u4 v = __builtin_amdgcn_raw_buffer_load_b128(t.r, (int)off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+#else
+constexpr int kPadRow = 0;
+constexpr uint32_t kPadWord = 0u;
+struct GTable {
+  const float* p;
+};
+__device__ __forceinline__ GTable gtable(const float* base, int64_t, int) { return GTable{base}; }
+template <int LPN>
+__device__ __forceinline__ float4 gather4(const GTable& t, int row, int sub) {
+  return gather4<LPN>(t.p, row, sub);
+}
+#endif
+
 // ---- DPP cross-lane adds (no LDS traffic, fold into v_add_f32_dpp) --------
 // ctrl: quad_perm[1,0,3,2]=0xB1 (xor 1), quad_perm[2,3,0,1]=0x4E (xor 2),
 // row_half_mirror=0x141 (i <-> 7-i), row_mirror=0x140 (i <-> 15-i),

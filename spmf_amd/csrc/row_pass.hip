@@ -18,7 +18,8 @@
 // (grp,sub) keeps the dot product of iteration `sub`.  col/val are read as
 // one coalesced 256-B wave load per 64 entries and distributed by
 // ds_bpermute.  Gathers are issued in straight-line groups of up to four
-// (padded entries read row 0 with weight 0) so several L2 round trips are in
+// (padded entries ask for a row behind the table: dropped by the buffer range
+// check, common.h GTable) so several L2 round trips are in
 // flight per wave; rows of <= 128 entries keep col/val in registers for both
 // sweeps.
 //
@@ -74,13 +75,13 @@ __device__ __forceinline__ void load_entry(const int32_t* __restrict__ col, cons
                                            const uint32_t* __restrict__ ent, int i, bool ok, int& ra,
                                            float& rb) {
   if (FMT == 1) {
-    ra = ok ? (int)(NT ? __builtin_nontemporal_load(&ent[i]) : ent[i]) : 0;
+    ra = ok ? (int)(NT ? __builtin_nontemporal_load(&ent[i]) : ent[i]) : (int)kPadWord;
     rb = 0.f;
   } else if (FMT == 2) {
-    ra = ok ? (int)(NT ? __builtin_nontemporal_load(&ent[i]) : ent[i]) : 0;
+    ra = ok ? (int)(NT ? __builtin_nontemporal_load(&ent[i]) : ent[i]) : (int)kPadWord;
     rb = ok ? (NT ? __builtin_nontemporal_load(&val[i]) : val[i]) : 0.f;
   } else {
-    ra = ok ? (NT ? __builtin_nontemporal_load(&col[i]) : col[i]) : 0;
+    ra = ok ? (NT ? __builtin_nontemporal_load(&col[i]) : col[i]) : kPadRow;
     rb = ok ? (NT ? __builtin_nontemporal_load(&val[i]) : val[i]) : 0.f;
   }
 }
@@ -106,8 +107,7 @@ struct RowCtx {
   static constexpr int LPN = KP / 4;
   static constexpr int NPI = 64 / LPN;
   static constexpr int GRP = LPN < ROW_GRP ? LPN : ROW_GRP;  // gathers issued back to back
-  const float* Ap;
-  const float* Vp;
+  GTable Ap, Vp;          // the gathered tables (common.h: slots behind a row's end are dropped by the range check)
   const float* phi;
   const uint8_t* ctype;   // LIK 3 (mixed): 1 = Bernoulli column
   int lane, sub, grp;
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
     __syncthreads();
   }
   RowCtx<KP, LIK, LDSPHI> cx;
-  cx.Ap = Ap;
-  cx.Vp = Vp;
+  cx.Ap = gtable(Ap, Dcols, KP);
+  cx.Vp = gtable(Vp, Dcols, KP);
   cx.phi = phi;
   cx.ctype = ctype;
   cx.lane = threadIdx.x & 63;
