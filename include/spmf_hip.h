@@ -177,7 +177,10 @@ size_t spmf_sizeof_counts(void);
 size_t spmf_sizeof_sur_var(void);
 size_t spmf_sizeof_adam_var(void);
 
-/* K = latent_dim, D = feature_dim (poisson.py:58,102-104). */
+/* K = latent_dim, D = feature_dim (poisson.py:58,102-104).  1 <= K <= 256 for the Poisson likelihood with
+ * the linear decoder (K <= 64: the lane-group sparse passes; above: one wave per factor row,
+ * csrc/widek.hip); 1 <= K <= 64 with SPMF_FLAG_LOG_TRANSFORM / BERNOULLI / MIXED (SPMF_E_UNSUPPORTED above)
+ * and for the deterministic mode. */
 int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out);
 void spmf_ctx_destroy(spmf_ctx* ctx);
 const char* spmf_last_error(const spmf_ctx* ctx); /* host string */

@@ -305,7 +305,10 @@ static void p2p_release(spmf_ctx* c);
 int spmf_ctx_create(int device, int K, int D, unsigned flags, spmf_ctx** out) {
   if (!out) return SPMF_E_ARG;
   *out = nullptr;
-  if (K < 1 || K > 64 || D < 1) return SPMF_E_ARG;
+  if (K < 1 || K > 256 || D < 1) return SPMF_E_ARG;
+  // K above 64: the whole-wave passes of widek.hip -- Poisson likelihood with the linear decoder only (the
+  // dense exp / sigmoid operators of the other contexts are built for K padded to 32 or 64)
+  if (K > 64 && (flags & (SPMF_FLAG_LOG_TRANSFORM | SPMF_FLAG_BERNOULLI | SPMF_FLAG_MIXED))) return SPMF_E_UNSUPPORTED;
   if ((int64_t)D * 64 * 4 >= (1LL << 32) - 256) return SPMF_E_ARG;   // 32-bit gather offsets into [D,KP]; the last KP*4 bytes below 4 GiB are the padded slots' (common.h kPadRow)
   spmf_ctx* c = new spmf_ctx();
   c->device = device;
@@ -591,6 +594,7 @@ int spmf_ctx_set_deterministic(spmf_ctx* c, void* scratch, size_t bytes) {
       "set_deterministic: Poisson likelihood with the linear decoder only (the dense sums of the other contexts "
       "accumulate with float atomics)");
   if (c->Dh > 0) return fail(c, SPMF_E_UNSUPPORTED, "set_deterministic: not together with the column split");
+  if (c->KP > 64) return fail(c, SPMF_E_UNSUPPORTED, "set_deterministic: latent dimensions up to 64 only");
   if ((uintptr_t)scratch & 255) return fail(c, SPMF_E_ARG, "set_deterministic: scratch must be 256-byte aligned");
   if (bytes < spmf_det_scratch_bytes(c, 0, 1)) return fail(c, SPMF_E_WORKSPACE, "set_deterministic: scratch too small");
   c->det_buf = (char*)scratch;

@@ -485,6 +485,7 @@ bool launch_col_pass(int KP, const ColArgs& a, hipStream_t st) {
     case 16: return launch_col_t<16>(a, st);
     case 32: return launch_col_t<32>(a, st);
     case 64: return launch_col_t<64>(a, st);
+    case 128: case 256: return launch_col_widek(KP, a, st);   // widek.hip
     default: return false;
   }
 }

@@ -332,6 +332,8 @@ void launch_nonfinite_patch(int KP, const NfPatchArgs& a, hipStream_t st) {
     case 16: SPMF_NFP(16); break;
     case 32: SPMF_NFP(32); break;
     case 64: SPMF_NFP(64); break;
+    case 128: SPMF_NFP(128); break;
+    case 256: SPMF_NFP(256); break;
     default: break;
   }
 #undef SPMF_NFP
@@ -351,6 +353,8 @@ void launch_dense_ll(int KP, const DenseLLArgs& a, hipStream_t st) {
     case 16: launch_dense_t<16>(a, st); break;
     case 32: launch_dense_t<32>(a, st); break;
     case 64: launch_dense_t<64>(a, st); break;
+    case 128: launch_dense_t<128>(a, st); break;
+    case 256: launch_dense_t<256>(a, st); break;
     default: return;
   }
   int64_t want = (a.B + 3) / 4;

@@ -118,6 +118,8 @@ void launch_finish(int KP, const FinishArgs& a, int phase, hipStream_t st) {
     case 16: launch_finish_t<16>(a, phase, st); break;
     case 32: launch_finish_t<32>(a, phase, st); break;
     case 64: launch_finish_t<64>(a, phase, st); break;
+    case 128: launch_finish_t<128>(a, phase, st); break;
+    case 256: launch_finish_t<256>(a, phase, st); break;
     default: break;
   }
 }
@@ -137,6 +139,8 @@ void launch_step_end(int KP, const FinishArgs& a, hipStream_t st) {
     case 16: launch_step_end_t<16>(a, st); break;
     case 32: launch_step_end_t<32>(a, st); break;
     case 64: launch_step_end_t<64>(a, st); break;
+    case 128: launch_step_end_t<128>(a, st); break;
+    case 256: launch_step_end_t<256>(a, st); break;
     default: break;
   }
 }

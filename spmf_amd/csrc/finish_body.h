@@ -276,6 +276,8 @@ __device__ __forceinline__ void finish_body(const FinishK& a_, const int bx, con
                                    // error of the quadratic term: 8e-6 of part 'u' at K ~ 60)
   __shared__ float gred[256];
   __shared__ int bern_s[FTD];
+  __shared__ float GAw[KP > 64 ? KP / 64 : 1][FTD];   // K above 64: per-wave parts of GA_d
+  __shared__ double rterm_s[KP > 64 ? KP : 1];
   const int t = threadIdx.x;
   const int d0 = bx * FTD;
   // column-split layout (common.h AccLayout): Dh is a multiple of FTD, so a block's
@@ -440,13 +442,27 @@ __device__ __forceinline__ void finish_body(const FinishK& a_, const int bx, con
       // GA_d = sum_k u*dA : fold over the LW lanes that share d
 #pragma unroll
       for (int m = 1; m < LW; m <<= 1) ga_u += __shfl_xor(ga_u, m);
-      if ((k % LW) == 0 && d < D) GAs[dl] = ga_u;   // one writer per dl
+      if constexpr (KP <= 64) {
+        if ((k % LW) == 0 && d < D) GAs[dl] = ga_u;   // one writer per dl
+      } else {
+        // K above 64: a column's KP values span KP / 64 waves (of one iteration: 256 % KP == 0); each leaves its
+        // part in its own slot, added in k order below
+        if ((k % LW) == 0 && d < D) GAw[k / 64][dl] = ga_u;
+      }
     }
     gut_acc += gut;
   }
   // fold gut over the threads that share k: t, t+KP, t+2KP, ... (256/KP of them)
   gred[t] = gut_acc;
   __syncthreads();
+  if constexpr (KP > 64) {
+    if (DATA && t < FTD) {
+      float g = 0.f;
+#pragma unroll
+      for (int j = 0; j < KP / 64; ++j) g += GAw[j][t];
+      GAs[t] = g;                       // read behind the next barriers ([.,D] vectors)
+    }
+  }
   if (t < KP) {
     float g = 0.f;
     for (int j = t; j < 256; j += KP) g += gred[j];
@@ -614,6 +630,17 @@ __device__ __forceinline__ void finish_body(const FinishK& a_, const int bx, con
     }
     __syncthreads();
     if (t < 12) ppart[t] = pred[t][0] + pred[t][1] + pred[t][2] + pred[t][3];
+  }
+  if constexpr (KP > 64) {               // rterm lives in lanes t < KP of KP / 64 waves: through LDS to the first
+    if (DATA && bx == 0) {               // (block-uniform)
+      if (t < KP) rterm_s[t] = rterm;
+      __syncthreads();
+      if (t < 64) {
+        rterm = 0.0;
+#pragma unroll
+        for (int j = 0; j < KP / 64; ++j) rterm += rterm_s[j * 64 + t];
+      }
+    }
   }
   if (DATA && bx == 0 && t < 64) {
     const double rsum = wave_sum(rterm);

@@ -56,6 +56,7 @@ struct RowArgs {
   int dyn_tail = 0;
 };
 bool launch_row_pass(int KP, const RowArgs& a, hipStream_t st);   // false: a.dual asked for a form this shape lacks (nothing launched)
+bool launch_row_widek(int KP, const RowArgs& a, hipStream_t st);  // KP = 128, 256 (widek.hip): Poisson / linear decoder, modes 0 and 1
 
 struct ColArgs {
   int D, n_panels, row_base;
@@ -175,6 +176,7 @@ struct NfPatchArgs {
 void launch_nonfinite_patch(int KP, const NfPatchArgs& a, hipStream_t st);
 void launch_nonfinite_lgamma(const DenseLLArgs& a, double* out, hipStream_t st);   // uses B, D, logt, ctype, CSR, rate
 bool launch_col_pass(int KP, const ColArgs& a, hipStream_t st);   // true: launched, with the pack block if asked
+bool launch_col_widek(int KP, const ColArgs& a, hipStream_t st);  // KP = 128, 256 (widek.hip)
 
 struct PackArgs {
   int KP;

@@ -22,7 +22,9 @@
 
 namespace spmf {
 
-constexpr int TD = 64;  // columns (features) per block
+// columns (features) per block: 64; 32 at K above 128 (the transpose tile is KP x (TD + 1) floats of static LDS)
+template <int KP>
+constexpr int prep_td() { return KP > 128 ? 32 : 64; }
 
 // Grid: tile blocks [0, nt) form A', V', phi for TD columns each and zero a slice of the
 // step's accumulators (the zero fill used to be a launch of its own); the (KP+1)*kPrepSeg
@@ -49,6 +51,7 @@ struct PrepK {
 template <int KP>
 __device__ __forceinline__ void prep_body(const PrepK& a_, const int bx, const int by, const int nby) {
   const int D = a_.D, K = a_.K;
+  constexpr int TD = prep_td<KP>();
   const float* __restrict__ u = a_.u;
   const float* __restrict__ v = a_.v;
   const float* __restrict__ w = a_.w;
@@ -169,19 +172,21 @@ __global__ __launch_bounds__(256) void begin_kernel(const PrepK pa, const Finish
   prep_body<KP>(pa, (int)blockIdx.x - nfin, blockIdx.y, gridDim.y);
 }
 
+template <int KP>
 static PrepK make_prep_k(const PrepArgs& a) {
+  constexpr int TD = prep_td<KP>();
   return PrepK{a.D, a.K, a.u, a.v, a.w, a.s, a.eta, a.Ap, a.Vp, a.phi, a.dprep, a.logt, a.ctype, a.dbias,
                (a.D + TD - 1) / TD, (uint4*)a.zero_p, a.zero_bytes / 16};
 }
 
 template <int KP>
 static void launch_prep_t(const PrepArgs& a, hipStream_t st) {
-  const PrepK k = make_prep_k(a);
+  const PrepK k = make_prep_k<KP>(a);
   hipLaunchKernelGGL(prep_kernel<KP>, dim3(k.nt + (KP + 1) * kPrepSeg, a.S > 1 ? a.S : 1), dim3(256), 0, st, k);
 }
 template <int KP>
 static void launch_begin_t(const PrepArgs& a, const FinishArgs& f, hipStream_t st) {
-  const PrepK k = make_prep_k(a);
+  const PrepK k = make_prep_k<KP>(a);
   const FinishK fk = make_finish_k(f);
   const int nfin = finish_blocks(f.D);
   const dim3 grid(nfin + k.nt + (KP + 1) * kPrepSeg, a.S > 1 ? a.S : 1);
@@ -196,6 +201,8 @@ void launch_prep(int KP, const PrepArgs& a, hipStream_t st) {
     case 16: launch_prep_t<16>(a, st); break;
     case 32: launch_prep_t<32>(a, st); break;
     case 64: launch_prep_t<64>(a, st); break;
+    case 128: launch_prep_t<128>(a, st); break;
+    case 256: launch_prep_t<256>(a, st); break;
     default: break;
   }
 }
@@ -208,6 +215,8 @@ void launch_step_begin(int KP, const PrepArgs& a, const FinishArgs& f, hipStream
     case 16: launch_begin_t<16>(a, f, st); break;
     case 32: launch_begin_t<32>(a, f, st); break;
     case 64: launch_begin_t<64>(a, f, st); break;
+    case 128: launch_begin_t<128>(a, f, st); break;
+    case 256: launch_begin_t<256>(a, f, st); break;
     default: break;
   }
 }

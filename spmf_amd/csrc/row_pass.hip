@@ -617,6 +617,7 @@ bool launch_row_pass(int KP, const RowArgs& a, hipStream_t st) {
     case 16: return launch_row_t<16>(a, st);
     case 32: return launch_row_t<32>(a, st);
     case 64: return launch_row_t<64>(a, st);
+    case 128: case 256: return launch_row_widek(KP, a, st);   // widek.hip: a factor row is the whole wave
     default: return false;
   }
 }

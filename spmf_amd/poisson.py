@@ -168,8 +168,9 @@ class PoissonFactorization:
                                  int(self.feature_dim), flags, C.byref(h))
         if rc != 0:
             raise SpmfError(
-                f"spmf_ctx_create failed (rc={rc}); latent_dim must be in "
-                f"1..64, got K={self.latent_dim}, D={self.feature_dim}")
+                f"spmf_ctx_create failed (rc={rc}); latent_dim must be in 1..256 (1..64 with "
+                f"log_transform and for the Bernoulli / mixed likelihoods), got K={self.latent_dim}, "
+                f"D={self.feature_dim}")
         _lib.check(h, lib.spmf_ctx_set_prior(
             h, float(self.u_tau_scale), float(self.s_tau_scale),
             float(self.symmetry_breaking_decay)), "spmf_ctx_set_prior")

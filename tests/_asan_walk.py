@@ -17,7 +17,7 @@ for name, (res, args) in _lib.SIGNATURES.items():
 
 assert lib.spmf_version() == 6 and lib.spmf_sizeof_counts() == C.sizeof(_lib.CountsStruct)
 h = C.c_void_p()
-assert lib.spmf_ctx_create(0, 100, 10, 0, C.byref(h)) == -1
+assert lib.spmf_ctx_create(0, 300, 10, 0, C.byref(h)) == -1
 assert lib.spmf_ctx_create(0, 0, 10, 0, C.byref(h)) == -1
 assert lib.spmf_ctx_create(0, 8, 10, _lib.FLAG_LOG_TRANSFORM | _lib.FLAG_MIXED, C.byref(h)) == -4
 for flags in (0, 1, 2 | 1, 4, 4 | 2, 8, 16 | 1):

@@ -265,7 +265,7 @@ def test_errors_are_loud():
     from spmf_amd import PoissonFactorization
     from spmf_amd._lib import SpmfError
     with pytest.raises(SpmfError):
-        m = PoissonFactorization(latent_dim=100, feature_dim=10, initialize_distributions=False,
+        m = PoissonFactorization(latent_dim=300, feature_dim=10, initialize_distributions=False,
                                  device="cuda")
         m._handle()
     cfg, x, params = make_problem(20, 10, 2, 1, 1, 0.5, empty=False)

@@ -84,7 +84,11 @@ def test_layout_builder_argument_errors_without_gpu(lib):
 
 def test_ctx_lifecycle_and_argument_errors_without_gpu(lib):
     h = C.c_void_p()
-    assert lib.spmf_ctx_create(0, 100, 10, 0, C.byref(h)) == -1      # K > 64
+    assert lib.spmf_ctx_create(0, 300, 10, 0, C.byref(h)) == -1      # K > 256
+    assert lib.spmf_ctx_create(0, 100, 10, 2, C.byref(h)) == -4   # dense-term contexts: K <= 64
+    assert lib.spmf_ctx_create(0, 100, 10, 0, C.byref(h)) == 0       # the whole-wave passes (csrc/widek.hip)
+    assert lib.spmf_padded_k(h) == 128
+    lib.spmf_ctx_destroy(h)
     assert lib.spmf_ctx_create(0, 16, 1000, 1, C.byref(h)) == 0
     assert lib.spmf_padded_k(h) == 16
     assert lib.spmf_ctx_set_prior(h, -1.0, 1.0, 0.99) == -1

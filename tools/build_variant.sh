@@ -10,7 +10,7 @@ out=$root/spmf_amd/variants
 tmp=$(mktemp -d)
 mkdir -p $out
 pids=()
-for f in api prep row_pass col_pass finish stats dense dense3 dense_ll surrogate layout p2p; do
+for f in api prep row_pass col_pass finish stats dense dense3 dense_ll surrogate layout p2p widek; do
   per=""
   [ $f = dense3 ] && per="-fno-slp-vectorize"      # as in csrc/Makefile
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -DSPMF_BUILD --offload-arch=gfx950 \
