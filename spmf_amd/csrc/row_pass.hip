@@ -47,6 +47,10 @@ static_assert(ROW_MAX_BLOCKS <= spmf::kDetMaxBlocks,
 #ifndef ROW_GRP
 #define ROW_GRP 4
 #endif
+// short rows: the V' gathers of a row's first chunk are issued before sweep 1 (RowCtx::s2_load)
+#ifndef ROW_V_AHEAD
+#define ROW_V_AHEAD 2
+#endif
 #ifndef ROW_WAVES_PER_SIMD
 #define ROW_WAVES_PER_SIMD 1
 #endif
@@ -161,6 +165,42 @@ struct RowCtx {
     }
   }
 
+  // The V' gathers of one chunk, ISSUED and not waited for (short rows, ROW_V_AHEAD: a row's first chunk asks for
+  // its V' rows before sweep 1 starts -- they depend on the column indices only, not on z -- so they are in
+  // flight beside the A' gathers and sweep 2 of that chunk starts on loaded registers; a later chunk asks for all
+  // of its groups at once instead of group by group)
+  __device__ __forceinline__ void s2_load(int c, int nchunk, float4 (&vv)[LPN]) const {
+#pragma unroll
+    for (int g0 = 0; g0 < LPN; g0 += GRP) {
+      if (g0 * NPI < nchunk) {
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const int d = __shfl(c, (g0 + j) * NPI + grp);
+          vv[g0 + j] = gather4<LPN>(Vp, d, sub);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) vv[g0 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  // sweep 2 of a chunk whose V' rows were asked for by s2_load
+  __device__ __forceinline__ void sweep2_loaded(int c, float x, int nchunk, const float4& z, float4& gz, float& ll,
+                                                double& nnf, const float4 (&vv)[LPN]) const {
+    float rmine = 0.f;
+#pragma unroll
+    for (int g0 = 0; g0 < LPN; g0 += GRP) {
+      if (g0 * NPI < nchunk) {
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const float dot = group_sum<LPN>(dot4(z, vv[g0 + j]));
+          if (sub == g0 + j) rmine = dot;
+        }
+      }
+    }
+    s2_cells(c, x, nchunk, rmine, vv, gz, ll, nnf);
+  }
+
   // rates, log-likelihood and gz partial over one chunk
   __device__ __forceinline__ void sweep2(int c, float x, int nchunk, const float4& z,
                                          float4& gz, float& ll, double& nnf) const {
@@ -171,6 +211,11 @@ struct RowCtx {
       if (g0 * NPI < nchunk) s2_gather<GRP>(c, g0, z, vv, rmine);
       else s2_gather<0>(c, g0, z, vv, rmine);
     }
+    s2_cells(c, x, nchunk, rmine, vv, gz, ll, nnf);
+  }
+  // the per-cell part of sweep 2 (one entry per lane) and the gz partial
+  __device__ __forceinline__ void s2_cells(int c, float x, int nchunk, float rmine, const float4 (&vv)[LPN],
+                                           float4& gz, float& ll, double& nnf) const {
     // one entry per lane: lane (grp,sub) owns slot sub*NPI+grp
     const int slot = sub * NPI + grp;
     const float xs = __shfl(x, slot);
@@ -363,6 +408,14 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
       unpack_entry<PACKED>(pc0, px0, c0, x0);
       unpack_entry<PACKED>(pc1, px1, c1, x1);
       const int n0 = min(n, 64), n1 = n - 64;
+      // ROW_V_AHEAD (K <= 32; at K = 64 a chunk's V' rows are 64 registers): 1 = the first chunk's V' gathers
+      // are issued before sweep 1, 3 = between sweep 1 and its cross-group sum, 2 = not ahead, but a chunk's
+      // sweep 2 issues all of its gathers before its first dot product; 0 = group by group (the round-3 form)
+      constexpr int VAHEAD = KP <= 32 ? ROW_V_AHEAD : 0;
+      float4 vv0[VAHEAD ? LPN : 1];
+      if constexpr (VAHEAD == 1) {
+        if (!encode_only) cx.s2_load(c0, n0, vv0);
+      }
       if (mode != 2) {
         if (PACKED == 2) {              // sweep 1 reads the encoder's values, not the counts
           cx.sweep1(c0, px0, n0, zacc);
@@ -371,6 +424,9 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
           cx.sweep1(c0, x0, n0, zacc);
           if (n1 > 0) cx.sweep1(c1, x1, n1, zacc);
         }
+        if constexpr (VAHEAD == 3) {
+          if (!encode_only) cx.s2_load(c0, n0, vv0);
+        }
         zacc = across_groups_sum4<LPN>(zacc);
         zacc.x *= xi; zacc.y *= xi; zacc.z *= xi; zacc.w *= xi;
         if (grp == 0) reinterpret_cast<float4*>(z)[(size_t)b * LPN + sub] = zacc;
@@ -378,8 +434,21 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
         zacc = gather4<LPN>(z, (int)b, sub);
       }
       if (!encode_only) {
-      cx.sweep2(c0, x0, n0, zacc, gz, llrow, nnf_acc);
-      if (n1 > 0) cx.sweep2(c1, x1, n1, zacc, gz, llrow, nnf_acc);
+      if constexpr (VAHEAD != 0) {
+        if constexpr (VAHEAD == 2) cx.s2_load(c0, n0, vv0);
+        if constexpr (VAHEAD == 3) {
+          if (mode == 2) cx.s2_load(c0, n0, vv0);
+        }
+        cx.sweep2_loaded(c0, x0, n0, zacc, gz, llrow, nnf_acc, vv0);
+        if (n1 > 0) {
+          float4 vv1[LPN];
+          cx.s2_load(c1, n1, vv1);
+          cx.sweep2_loaded(c1, x1, n1, zacc, gz, llrow, nnf_acc, vv1);
+        }
+      } else {
+        cx.sweep2(c0, x0, n0, zacc, gz, llrow, nnf_acc);
+        if (n1 > 0) cx.sweep2(c1, x1, n1, zacc, gz, llrow, nnf_acc);
+      }
       }
     } else {
       // ---- long row: stream the row twice (second read is L2 served) -----
