@@ -874,6 +874,7 @@ static int data_pass_impl(spmf_ctx* c, const spmf_counts* ct, int S, const float
       RowArgs r2{ct->n_rows, ct->row_ptr, ct->col_idx, ct->val, rscale, c->Ap, c->Vp, c->phi, dprep, c->z, c->gzs,
           dacc, 2, logt, c->gzd, c->ctype, 1, D, dacc_stride};
       r2.ent = ct->ent;
+      r2.dyn_tail = c->dyn_rows;   // (the encode-only launch above never touches the counters: this one has them alone)
       launch_row_pass(KP, r2, st);
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], st));

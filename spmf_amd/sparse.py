@@ -48,6 +48,11 @@ def balanced_panel_rows(n_rows, latent_dim, table_bytes=PANEL_TABLE_BYTES):
     while kp < int(latent_dim):
         kp *= 2
     target = max(1024, int(table_bytes) // (8 * kp))
+    if kp > 64 and table_bytes == PANEL_TABLE_BYTES:
+        # the whole-wave column pass of csrc/widek.hip (one wave and one set of 2*KP float atomics per work
+        # item): longer lists pay more than L2 residency -- C2's matrix at K = 256: 3.43 ms per step with
+        # 1408-row panels, 1.81 with 10 240 (profiles/r05_widek_probe.txt)
+        target = 10240
     if n_rows <= 2 * target:
         return n_rows
     n_panels = 8 * -(-n_rows // (8 * target))
