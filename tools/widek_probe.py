@@ -18,7 +18,9 @@ def main():
     dev = torch.device("cuda:0")
     rows, D, density, _K, _desc = bench.WORKLOADS["c2"]
     sweep = [(16, None), (64, None), (128, None), (256, None)]
-    if len(sys.argv) > 1:      # panel-rows sweep of the wide kernels: python tools/widek_probe.py 4096 8192 ...
+    if len(sys.argv) > 1 and sys.argv[1] == "only128":
+        sweep = [(128, None)]
+    elif len(sys.argv) > 1:      # panel-rows sweep of the wide kernels: python tools/widek_probe.py 4096 8192 ...
         sweep = [(K, int(a)) for K in (128, 256) for a in sys.argv[1:]]
     for K, pr_arg in sweep:
         pr = pr_arg or balanced_panel_rows(rows, K)
@@ -34,7 +36,7 @@ def main():
         model.xi_u_global = float(torch.nansum(cm))
         torch.manual_seed(20241218)
         params = model.surrogate_distribution.sample(1)
-        ms, t6, parts, nnf = bench._timed_steps(model, {"counts": sc}, params, 20, 3)
+        ms, t6, parts, nnf = bench._timed_steps(model, {"counts": sc}, params, 50, 10)
         nnz = int(sc.nnz)
         gathered = 4.0 * nnz * model._kp() * 4 if hasattr(model, "_kp") else None
         print(json.dumps({"K": K, "rows": rows, "cols": D, "nnz": nnz, "panel_rows": pr, "ms_per_step": round(ms, 4),
