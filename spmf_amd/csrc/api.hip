@@ -1318,6 +1318,24 @@ int spmf_p2p_connect(spmf_ctx* c, const void* handles) {
       return fail(c, SPMF_E_HIP, b);
     }
     p.peer[i] = (char*)ptr;
+    // a region that lives on ANOTHER device of this process's view (ranks = GPUs of one node): kernels here will
+    // store into it, so the link must be there -- an inaccessible peer is refused now (the caller falls back to
+    // RCCL: dist.PeerComm agrees on the failure over all ranks) instead of faulting in the first launch.
+    // Same device (ranks = processes on one GPU: the one-GPU tests) or attributes unavailable: nothing to check.
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ptr) == hipSuccess) {
+      if (at.device >= 0 && at.device != c->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, c->device, at.device) == hipSuccess && !can) {
+          char b[200];
+          snprintf(b, sizeof b, "p2p_connect: device %d has no peer access to device %d (rank %d)", c->device,
+                   at.device, i);
+          return fail(c, SPMF_E_UNSUPPORTED, b);
+        }
+      }
+    } else {
+      (void)hipGetLastError();
+    }
   }
   p.connected = 1;
   return SPMF_OK;
