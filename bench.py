@@ -306,6 +306,36 @@ def c2_extra(dev, steps=50, warmup=5):
     return out
 
 
+def widek_extra(dev, K=128, steps=30, warmup=10):
+    """Latent dimensions above 64 (the reference's latent_dim defaults to feature_dim, poisson.py:103-104): the C2
+    matrix (100k x 5k at 1 %) at K = 128 on the whole-wave passes of csrc/widek.hip, ms per energy + gradient step."""
+    import contextlib
+    import torch
+    from spmf_amd import PoissonFactorization, synth
+    from spmf_amd.sparse import balanced_panel_rows
+    rows, D, density, _K, _desc = WORKLOADS["c2"]
+    pr = balanced_panel_rows(rows, K)
+    sc = synth.linear_structure(rows, D, density, dev, first_chunk=0, panel_rows=pr)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = PoissonFactorization(latent_dim=K, feature_dim=D, u_tau_scale=1.0 / (rows * D) ** 0.5,
+                                     device=dev, panel_rows=pr)
+    colsum = torch.zeros(D, dtype=torch.float64, device=dev)
+    colnnz = torch.zeros(D, dtype=torch.float64, device=dev)
+    sc.compute_stats(model._handle(), colsum, colnnz)
+    cm = colsum / colnnz
+    model.eta_i = torch.where(cm > 1, cm, torch.ones_like(cm)).reshape(1, D)
+    model.xi_u_global = float(torch.nansum(cm))
+    torch.manual_seed(20241218)
+    params = model.surrogate_distribution.sample(1)
+    ms, t6, parts, nnf = _timed_steps(model, {"counts": sc}, params, steps, warmup)
+    out = {f"k{K}_c2_ms_per_step": ms, f"k{K}_c2_kernel_ms": {"prep": round(t6[0], 4), "row_pass": round(t6[1], 4),
+                                                              "col_pass": round(t6[2], 4), "finish": round(t6[3], 4)},
+           f"k{K}_c2_n_nonfinite": float(nnf.sum()), f"k{K}_c2_elbo_x": float(parts["x"][0])}
+    del model, sc, params
+    torch.cuda.empty_cache()
+    return out
+
+
 def c1_gpu_extra(dev, steps=200, warmup=10):
     """BASELINE config 1 on the GPU, on the SAME seeded data as c1_dense_cpu_baseline (5000 x 200 dense
     Poisson(1) counts, K = 2, one batch of 5000): ms per energy + gradient step, and per whole VI step
@@ -843,6 +873,10 @@ def main():
             extras.update(c2_extra(dev))
         except Exception as e:
             extras["c2_error"] = str(e)[:200]
+        try:   # K above 64 (VERDICT r4 missing #6): C2's matrix at K = 128
+            extras.update(widek_extra(dev))
+        except Exception as e:
+            extras["k128_error"] = str(e)[:200]
         # the reference's own shapes: C1 on the GPU beside its CPU number, and the harness
         # of tests/spmf_test.py (D = 350, P = 50, batches of 10 rows, sample_size = 20)
         try:
