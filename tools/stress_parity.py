@@ -12,6 +12,8 @@ rng = np.random.default_rng(seed0)
 worst_p, worst_g, fails = 0.0, 0.0, 0
 for case in range(N):
     B = int(rng.integers(1, 700)); D = int(rng.integers(1, 900)); K = int(rng.integers(1, 65))
+    if len(sys.argv) > 3 and sys.argv[3] == "widek":     # latent dimensions 65 .. 256 (csrc/widek.hip)
+        K = int(rng.integers(65, 257)); B = min(B, 300); D = min(D, 500)
     S = int(rng.integers(1, 3)); density = float(rng.choice([0.0, 0.01, 0.05, 0.3, 1.0]))
     sr = bool(rng.integers(0, 2)); P = int(rng.choice([1, 33, 256, 8192]))
     cfg, x, params = T.make_problem(B, D, K, S, seed0 * 1000 + case, density, sr, empty=False)
