@@ -366,7 +366,7 @@ class _TwoShardSplitReducer:
         raise AssertionError("column-split flow expected")
 
 
-@pytest.mark.parametrize("K", [4, 32])
+@pytest.mark.parametrize("K", [4, 32, 100])
 def test_column_split_step_equals_unsplit(K):
     """spmf_ctx_set_column_split + spmf_data_pass_split: two row shards, each
     all-reducing its accumulators in two column-half ranges == the oracle on the

@@ -115,3 +115,16 @@ def test_fit_trains_a_model_with_latent_dim_above_64():
     assert np.mean(losses[-3:]) < losses[0]
     z = m.encode(X)
     assert tuple(z.shape) == (N, K) and bool(torch.isfinite(z).all())
+
+
+def test_draws_in_turn_on_a_batch_too_big_for_one_launch_per_kernel():
+    """More than 2048 rows and S table pairs above 3 MB: the draws run back to back (api.hip batched_draws),
+    each through the K > 64 kernels with its own tables, row outputs and accumulators."""
+    B, D, K, S = 2100, 1700, 128, 2
+    cfg, x, params = make_problem(B, D, K, S, 4545, 0.01, empty=False)
+    parts_ref, grads_ref, _ = O.energy_and_grads(cfg, x, params)
+    m = build_model(cfg, 1024)
+    parts, grads, nnf = m.energy_and_grads({"counts": x}, params)
+    assert float(nnf.sum()) == 0
+    assert_close_parts(parts, parts_ref)
+    assert_close_grads(grads, grads_ref, O.energy_grad_scales(cfg, x, params))
