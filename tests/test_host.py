@@ -320,6 +320,12 @@ def test_balanced_panel_rows_fill_l2_and_count_in_eights():
     assert balanced_panel_rows(125_000, 32) == 7872         # 16 panels (an 8-GPU shard of C3)
     assert balanced_panel_rows(20_000, 16) == 20_000        # a reference-sized minibatch: one panel
     assert balanced_panel_rows(5, 2) == 5 and balanced_panel_rows(0, 2) == 1
+    # latent dimensions above 64 (csrc/widek.hip: one work item per wave, 2*KP float atomics per item): 10k-row
+    # panels whatever KP is, still a multiple of 8 of them
+    for K in (65, 128, 200, 256):
+        pr = balanced_panel_rows(100_000, K)
+        assert pr == 6272 and (-(-100_000 // pr)) % 8 == 0
+        assert balanced_panel_rows(15_000, K) == 15_000       # up to two such panels: one panel
 
 
 def test_packed_entries_only_for_integer_counts_in_16_bits():
