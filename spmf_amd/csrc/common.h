@@ -187,6 +187,19 @@ __device__ __forceinline__ float dpp_add(float v) {
   const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
   return v + __int_as_float(t);
 }
+// keep + (send of the DPP partner)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_to(float keep, float send) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, true);
+  return keep + __int_as_float(t);
+}
+// <a, b> with the packed forms (v_pk_mul_f32, v_pk_fma_f32, one add: three instructions instead of four)
+__device__ __forceinline__ float dot4p(const float4& a, const float4& b) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 p = f2{a.x, a.y} * f2{b.x, b.y};
+  p = __builtin_elementwise_fma(f2{a.z, a.w}, f2{b.z, b.w}, p);
+  return p.x + p.y;
+}
 // Sum over the aligned group of N lanes (N = 1,2,4,8,16); every lane of the
 // group ends up with the total.
 template <int N>

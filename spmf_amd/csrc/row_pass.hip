@@ -104,6 +104,35 @@ __device__ __forceinline__ void unpack_entry(int ra, float rb, int& c, float& x)
   }
 }
 
+// Lane `base/4 + IMM` 's value: ds_bpermute with the compile-time part of the source lane in the instruction's
+// offset field (the row pass broadcasts from lanes (g0 + j) * NPI + grp and grp * LPN + g0 + j: one base
+// register per form for the whole kernel instead of a shift / add per broadcast -- ROW_BPERM_IMM)
+// sweep 2 at K = 32: the chunk's eight dot products through one transpose-reduce (RowCtx::sweep2_loaded)
+// (measured: 1.443 against 1.411 ms on C3 -- the fourteen selects and two spilled registers cost more than the
+//  seventeen folds they replace; built, parity-tested, off: profiles/r05_row_valu_ab.txt)
+#ifndef ROW_DOT_BUTTERFLY
+#define ROW_DOT_BUTTERFLY 0
+#endif
+// sweep 2's dot products with the packed multiply / fma (three instructions instead of four): measured, no
+// difference (1.409 against 1.402 ms): off
+#ifndef ROW_DOT_PK
+#define ROW_DOT_PK 0
+#endif
+#ifndef ROW_BPERM_IMM
+#define ROW_BPERM_IMM 1
+#endif
+// (imm_lanes is a constant after the unrolled callers are inlined)
+__device__ __forceinline__ int bperm_i(int base_bytes, int imm_lanes, int v) {
+#if ROW_BPERM_IMM
+  return __builtin_amdgcn_ds_bpermute(base_bytes + imm_lanes * 4, v);
+#else
+  return __shfl(v, (base_bytes >> 2) + imm_lanes);
+#endif
+}
+__device__ __forceinline__ float bperm_f(int base_bytes, int imm_lanes, float v) {
+  return __int_as_float(bperm_i(base_bytes, imm_lanes, __float_as_int(v)));
+}
+
 // LIK: 0 Poisson / linear decoder, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
 // LDSPHI: phi is read from the workgroup's LDS copy instead of global memory
 template <int KP, int LIK, bool LDSPHI = false>
@@ -115,6 +144,7 @@ struct RowCtx {
   const float* phi;
   const uint8_t* ctype;   // LIK 3 (mixed): 1 = Bernoulli column
   int lane, sub, grp;
+  int bp_grp, bp_row;     // byte addresses of lanes grp and grp * LPN (bperm_i / bperm_f)
 
   // z partial: zacc += sum over the chunk of x * A'_d
   template <int CNT>
@@ -123,9 +153,8 @@ struct RowCtx {
     float xv[CNT];
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
-      const int src = (g0 + j) * NPI + grp;
-      const int d = __shfl(c, src);
-      xv[j] = __shfl(x, src);
+      const int d = bperm_i(bp_grp, (g0 + j) * NPI, c);
+      xv[j] = bperm_f(bp_grp, (g0 + j) * NPI, x);
       a[j] = gather4<LPN>(Ap, d, sub);
     }
 #pragma unroll
@@ -144,7 +173,7 @@ struct RowCtx {
                                             float& rmine) const {
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
-      const int d = __shfl(c, (g0 + j) * NPI + grp);
+      const int d = bperm_i(bp_grp, (g0 + j) * NPI, c);
       vv[g0 + j] = gather4<LPN>(Vp, d, sub);
     }
 #pragma unroll
@@ -155,12 +184,13 @@ struct RowCtx {
 #pragma unroll
     for (int j = CNT; j < GRP; ++j) vv[g0 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  template <int CNT>
+  template <int CNT, bool PERM = false>
   __device__ __forceinline__ void s2_back(float cc, int g0, const float4 (&vv)[LPN],
                                           float4& gz) const {
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
-      const float cb = __shfl(cc, grp * LPN + g0 + j);
+      const int q = g0 + j;                                  // the lane of the group that owns gather q's weight
+      const float cb = bperm_f(bp_row, PERM ? (q < 4 ? q : 11 - q) : q, cc);
       gz = fma4(cb, vv[g0 + j], gz);
     }
   }
@@ -175,7 +205,7 @@ struct RowCtx {
       if (g0 * NPI < nchunk) {
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
-          const int d = __shfl(c, (g0 + j) * NPI + grp);
+          const int d = bperm_i(bp_grp, (g0 + j) * NPI, c);
           vv[g0 + j] = gather4<LPN>(Vp, d, sub);
         }
       } else {
@@ -187,13 +217,41 @@ struct RowCtx {
   // sweep 2 of a chunk whose V' rows were asked for by s2_load
   __device__ __forceinline__ void sweep2_loaded(int c, float x, int nchunk, const float4& z, float4& gz, float& ll,
                                                 double& nnf, const float4 (&vv)[LPN]) const {
+    if constexpr (LPN == 8 && ROW_DOT_BUTTERFLY) {
+      // Eight dot products over eight lanes as ONE transpose-reduce instead of eight three-step folds + eight
+      // selects: at every step a lane keeps half of its values and hands the other half to its partner, so it
+      // ends with the ONE total it owns (7 exchanges + 14 selects against 24 + 8; the row pass is as close
+      // to its VALU issue rate as to its request rate: DESIGN section 4 "Round 5 (g)").  Partners: lane ^ 1, lane ^ 2
+      // (quad_perm), then 7 - lane (row_half_mirror: the upper quad therefore keeps by the complement of its lane
+      // bits, eff), so lane `sub` ends with the total of gather own(sub) = sub < 4 ? sub : 11 - sub.
+      float d[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d[j] = dot4p(z, vv[j]);
+      const int eff = sub < 4 ? sub : 7 - sub;
+      const bool m0 = (eff & 1) != 0, m1 = (eff & 2) != 0, hi = sub >= 4;
+      float r4[4], q2[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float keep = m0 ? d[2 * i + 1] : d[2 * i], send = m0 ? d[2 * i] : d[2 * i + 1];
+        r4[i] = dpp_add_to<0xB1>(keep, send);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float keep = m1 ? r4[2 * i + 1] : r4[2 * i], send = m1 ? r4[2 * i] : r4[2 * i + 1];
+        q2[i] = dpp_add_to<0x4E>(keep, send);
+      }
+      const float keep = hi ? q2[1] : q2[0], send = hi ? q2[0] : q2[1];
+      const float rmine = dpp_add_to<0x141>(keep, send);
+      s2_cells<true>(c, x, nchunk, rmine, vv, gz, ll, nnf);
+      return;
+    }
     float rmine = 0.f;
 #pragma unroll
     for (int g0 = 0; g0 < LPN; g0 += GRP) {
       if (g0 * NPI < nchunk) {
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
-          const float dot = group_sum<LPN>(dot4(z, vv[g0 + j]));
+          const float dot = group_sum<LPN>(ROW_DOT_PK ? dot4p(z, vv[g0 + j]) : dot4(z, vv[g0 + j]));
           if (sub == g0 + j) rmine = dot;
         }
       }
@@ -214,10 +272,13 @@ struct RowCtx {
     s2_cells(c, x, nchunk, rmine, vv, gz, ll, nnf);
   }
   // the per-cell part of sweep 2 (one entry per lane) and the gz partial
+  // PERM: the lane owns gather own(sub) = sub < 4 ? sub : 11 - sub (what the transpose-reduce of sweep2_loaded leaves)
+  template <bool PERM = false>
   __device__ __forceinline__ void s2_cells(int c, float x, int nchunk, float rmine, const float4 (&vv)[LPN],
                                            float4& gz, float& ll, double& nnf) const {
-    // one entry per lane: lane (grp,sub) owns slot sub*NPI+grp
-    const int slot = sub * NPI + grp;
+    // one entry per lane: lane (grp,sub) owns slot own*NPI+grp
+    const int own = PERM ? (sub < 4 ? sub : 11 - sub) : sub;
+    const int slot = own * NPI + grp;
     const float xs = __shfl(x, slot);
     const int cs = __shfl(c, slot);
     float cc = 0.f;
@@ -256,7 +317,7 @@ struct RowCtx {
     }
 #pragma unroll
     for (int g0 = 0; g0 < LPN; g0 += GRP) {
-      if (g0 * NPI < nchunk) s2_back<GRP>(cc, g0, vv, gz);
+      if (g0 * NPI < nchunk) s2_back<GRP, PERM>(cc, g0, vv, gz);
     }
   }
 };
@@ -301,6 +362,8 @@ __global__ __launch_bounds__(BT, BT == 256 ? ROW_WAVES_PER_SIMD : 4) void row_pa
   cx.lane = threadIdx.x & 63;
   cx.sub = cx.lane % LPN;
   cx.grp = cx.lane / LPN;
+  cx.bp_grp = cx.grp * 4;
+  cx.bp_row = cx.grp * LPN * 4;
   const int lane = cx.lane, sub = cx.sub, grp = cx.grp;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
