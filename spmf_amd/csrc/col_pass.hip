@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256, EPL == 4 ? COL_WIDE_WAVES : 1) void col_pass_k
   __shared__ __attribute__((aligned(16))) float stage[4][NG][2 * KP];
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPN, grp = lane / LPN;
+  const int bp_row = grp * LPN * 4;                   // byte address of the group's first lane (ds_bpermute)
   const int wid = threadIdx.x >> 6;
   // block id -> (panel, block of 4*NG items); blockIdx % 8 = panel residue
   // (batches of fewer than 8 panels use a flat mapping: the residue mapping
@@ -278,10 +279,13 @@ __global__ __launch_bounds__(256, EPL == 4 ? COL_WIDE_WAVES : 1) void col_pass_k
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
           const int q = g0 + j;                       // entry q of the fetch: lane q / EPL, component q % EPL
-          const int src = grp * LPN + q / EPL;
-          const int b = __shfl(rr0[q % EPL], src);
-          xv[j] = __shfl(xx0[q % EPL], src);
-          gv[j] = (LIK == 1 || LIK == 4) ? __shfl(gx0[q % EPL], src) : xv[j];
+          // (source lane grp * LPN + q / EPL: the lane-dependent part is one byte-address register of the kernel,
+          //  the compile-time part an add -- __shfl shifts the index per call; row_pass.hip ROW_BPERM_IMM)
+          const int sa = bp_row + (q / EPL) * 4;
+          const int b = __builtin_amdgcn_ds_bpermute(sa, rr0[q % EPL]);
+          xv[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(xx0[q % EPL])));
+          gv[j] = (LIK == 1 || LIK == 4) ? __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(gx0[q % EPL])))
+                                         : xv[j];
           zz[j] = gather4<LPN>(zt, b, sub);
           gg[j] = gather4<LPN>(gt, b, sub);
         }
