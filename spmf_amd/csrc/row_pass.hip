@@ -121,16 +121,17 @@ __device__ __forceinline__ void unpack_entry(int ra, float rb, int& c, float& x)
 #ifndef ROW_BPERM_IMM
 #define ROW_BPERM_IMM 1
 #endif
-// (imm_lanes is a constant after the unrolled callers are inlined)
+// (imm_lanes is a constant after the unrolled callers are inlined.  BASE false = the __shfl form: at K = 64 the
+//  sixteen base + constant sums of a chunk get hoisted into registers the kernel does not have -- 132 instead of
+//  76 bytes of scratch, C4's row launches 12.7 -> 13.2 ms -- so that instantiation keeps the shift per call)
+template <bool BASE>
 __device__ __forceinline__ int bperm_i(int base_bytes, int imm_lanes, int v) {
-#if ROW_BPERM_IMM
-  return __builtin_amdgcn_ds_bpermute(base_bytes + imm_lanes * 4, v);
-#else
-  return __shfl(v, (base_bytes >> 2) + imm_lanes);
-#endif
+  if constexpr (BASE) return __builtin_amdgcn_ds_bpermute(base_bytes + imm_lanes * 4, v);
+  else return __shfl(v, (base_bytes >> 2) + imm_lanes);
 }
+template <bool BASE>
 __device__ __forceinline__ float bperm_f(int base_bytes, int imm_lanes, float v) {
-  return __int_as_float(bperm_i(base_bytes, imm_lanes, __float_as_int(v)));
+  return __int_as_float(bperm_i<BASE>(base_bytes, imm_lanes, __float_as_int(v)));
 }
 
 // LIK: 0 Poisson / linear decoder, 1 Poisson / log_transform, 2 Bernoulli(logits) / linear
@@ -140,6 +141,9 @@ struct RowCtx {
   static constexpr int LPN = KP / 4;
   static constexpr int NPI = 64 / LPN;
   static constexpr int GRP = LPN < ROW_GRP ? LPN : ROW_GRP;  // gathers issued back to back
+  // broadcasts through a base register: K <= 32; not the exp decoder's instantiations (they have no register to
+  // spare either: 12 - 20 bytes of scratch with it)
+  static constexpr bool BPI = ROW_BPERM_IMM && LPN <= 8 && LIK != 1;
   GTable Ap, Vp;          // the gathered tables (common.h: slots behind a row's end are dropped by the range check)
   const float* phi;
   const uint8_t* ctype;   // LIK 3 (mixed): 1 = Bernoulli column
@@ -153,8 +157,8 @@ struct RowCtx {
     float xv[CNT];
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
-      const int d = bperm_i(bp_grp, (g0 + j) * NPI, c);
-      xv[j] = bperm_f(bp_grp, (g0 + j) * NPI, x);
+      const int d = bperm_i<BPI>(bp_grp, (g0 + j) * NPI, c);
+      xv[j] = bperm_f<BPI>(bp_grp, (g0 + j) * NPI, x);
       a[j] = gather4<LPN>(Ap, d, sub);
     }
 #pragma unroll
@@ -173,7 +177,7 @@ struct RowCtx {
                                             float& rmine) const {
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
-      const int d = bperm_i(bp_grp, (g0 + j) * NPI, c);
+      const int d = bperm_i<BPI>(bp_grp, (g0 + j) * NPI, c);
       vv[g0 + j] = gather4<LPN>(Vp, d, sub);
     }
 #pragma unroll
@@ -190,7 +194,7 @@ struct RowCtx {
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
       const int q = g0 + j;                                  // the lane of the group that owns gather q's weight
-      const float cb = bperm_f(bp_row, PERM ? (q < 4 ? q : 11 - q) : q, cc);
+      const float cb = bperm_f<BPI>(bp_row, PERM ? (q < 4 ? q : 11 - q) : q, cc);
       gz = fma4(cb, vv[g0 + j], gz);
     }
   }
@@ -205,7 +209,7 @@ struct RowCtx {
       if (g0 * NPI < nchunk) {
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
-          const int d = bperm_i(bp_grp, (g0 + j) * NPI, c);
+          const int d = bperm_i<BPI>(bp_grp, (g0 + j) * NPI, c);
           vv[g0 + j] = gather4<LPN>(Vp, d, sub);
         }
       } else {
