@@ -25,3 +25,4 @@ f=$(find $o/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && { cp "$f" $o/kernel_stats_c3.csv; head -8 "$f" | cut -c1-200; }
 timeout -k 10 300 python tools/widek_probe.py > $o/widek_probe.jsonl 2> $o/widek_probe.err
 cut -c1-240 $o/widek_probe.jsonl
+rm -rf $o/prof

@@ -14,3 +14,6 @@ echo "--- pmc_r05.sh"
 bash tools/pmc_r05.sh $o/pmc5 > $o/pmc5.log 2>&1 || { tail -5 $o/pmc5.log; exit 1; }
 python3 tools/pmc_r05_report.py $o/pmc5 > $o/pmc_sparse_passes.txt 2> $o/report.err || tail -3 $o/report.err
 grep -A8 "derived, vector" $o/pmc_sparse_passes.txt | head -40
+# keep what is merged back small: the raw rocprofv3 output directories stay on the box
+rm -rf $o/stats $o/pmc/p*/ $o/pmc5/p*/
+du -sh $o | tail -1
